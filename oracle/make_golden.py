@@ -1,0 +1,161 @@
+"""
+oracle/make_golden.py -- TEST INFRASTRUCTURE (build container only; needs /root/reference).
+
+1. runs the UNMODIFIED reference (via oracle/ref_runner.py) on small seeded problems with injected noise,
+2. runs the restatement (oracle/epropnp_oracle.py) on the same inputs,
+3. asserts that they agree (this is what pins the oracle), and
+4. writes inputs + reference outputs as small fixtures to tests/golden/*.npz.
+
+Usage:  python oracle/make_golden.py            (regenerates every fixture, prints the max deviations)
+The fixtures are what travels to the GPU box; /root/reference does not.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import epropnp_oracle as orc  # noqa: E402
+import ref_runner as ref  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+torch.set_num_threads(4)
+REPORT = []
+
+
+def _maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max()) if a.numel() else 0.0
+
+
+def check(name, key, a, b, tol):
+    d = _maxdiff(a, b)
+    REPORT.append((name, key, d, tol))
+    assert d <= tol, f'{name}.{key}: reference vs restatement differ by {d:.3e} > {tol:.1e}'
+
+
+def save(name, **arrays):
+    flat = {}
+    for k, v in arrays.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f'{k}.{kk}'] = vv.numpy() if isinstance(vv, torch.Tensor) else np.asarray(vv)
+        else:
+            flat[k] = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **flat)
+
+
+def cam_of(prob):
+    return orc.Cam(prob['cam_mats'], 0.1, prob.get('lb'), prob.get('ub'))
+
+
+def case_evaluate(name, dof, B, N, bounds, seed):
+    prob = orc.make_problem(B, N, dof, seed=seed, bounds=bounds)
+    cam = cam_of(prob)
+    pose = prob['pose_init']
+    r_res, r_cost, r_jac = ref.run_evaluate(prob, pose, jac=True, clip_jac=True)
+    o_res, o_cost, o_jac = orc.evaluate(prob['x3d'], prob['x2d'], prob['w2d'], pose, cam, prob['delta'], True, True)
+    check(name, 'res', r_res, o_res, 1e-6)
+    check(name, 'cost', r_cost, o_cost, 1e-6)
+    check(name, 'jac', r_jac, o_jac, 2e-5 * float(r_jac.abs().max()))
+    # multi-pose cost-only sweep (the AMIS integrand), poses (P,B,p)
+    g = torch.Generator().manual_seed(seed + 100)
+    P = 5
+    poses = pose.unsqueeze(0).repeat(P, 1, 1)
+    poses[..., :3] += 0.3 * torch.randn(P, B, 3, generator=g)
+    if dof == 6:
+        q = poses[..., 3:] + 0.2 * torch.randn(P, B, 4, generator=g)
+        poses[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+    else:
+        poses[..., 3] += 0.5 * torch.randn(P, B, generator=g)
+    poses[0, 0, 2] = -3.0    # one pose behind the camera: exercises the z_min clamp
+    r_costs = ref.run_evaluate(prob, poses)[1]
+    o_costs = orc.evaluate(prob['x3d'], prob['x2d'], prob['w2d'], poses, cam, prob['delta'], want_cost=True)[1]
+    check(name, 'costs', r_costs, o_costs, 2e-5 * float(r_costs.abs().max()))
+    jtj = r_jac.transpose(-1, -2).double() @ r_jac.double()
+    jtr = (r_jac.transpose(-1, -2).double() @ r_res.double().unsqueeze(-1)).squeeze(-1)
+    save(name, prob=prob, pose=pose, poses=poses, res=r_res, cost=r_cost, jac=r_jac, costs=r_costs,
+         jtj=jtj.float(), jtr=jtr.float(), dof=dof)
+
+
+def case_lm(name, dof, B, N, lm_iter, fast_mode, bounds, seed):
+    prob = orc.make_problem(B, N, dof, seed=seed, bounds=bounds)
+    r_pose, r_cov, r_cost = ref.run_lm(prob, dof, lm_iter, fast_mode)
+    o_pose, o_cov, o_cost, hist = orc.lm_solve(prob['x3d'], prob['x2d'], prob['w2d'], cam_of(prob), prob['delta'],
+                                               prob['pose_init'], fast_mode=fast_mode, with_pose_cov=True,
+                                               with_cost=True, num_iter=lm_iter)
+    check(name, 'pose_opt', r_pose, o_pose, 2e-5)
+    check(name, 'cost', r_cost, o_cost, 1e-5 * max(1.0, float(r_cost.abs().max())))
+    check(name, 'pose_cov', r_cov, o_cov, 2e-3 * float(r_cov.abs().max()))
+    # fp64 reference of the same solve (for conditioning-aware tolerances in the tests)
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in prob.items()}
+    d_pose, d_cov, d_cost, _ = orc.lm_solve(p64['x3d'], p64['x2d'], p64['w2d'], cam_of(p64), p64['delta'],
+                                            p64['pose_init'], fast_mode=fast_mode, with_pose_cov=True,
+                                            with_cost=True, num_iter=lm_iter)
+    save(name, prob=prob, pose_opt=r_pose, pose_cov=r_cov, cost=r_cost, pose_opt64=d_pose, pose_cov64=d_cov,
+         cost64=d_cost, dof=dof, lm_iter=lm_iter, fast_mode=int(fast_mode),
+         accepts=torch.stack(hist).to(torch.int32) if hist else torch.zeros(0, B, dtype=torch.int32))
+
+
+def case_mc(name, dof, B, N, S, K, lm_iter, seed, normalize=False, rslm=None, with_pose_opt_plus=False,
+            bounds=None, cam_kind='pinhole800', tol_logw=2e-3):
+    prob = orc.make_problem(B, N, dof, seed=seed, bounds=bounds, cam_kind=cam_kind)
+    noise = orc.make_noise(B, S, K, dof, seed=seed + 1)
+    rn = orc.make_rslm_noise(prob, dof, rslm['num_points'], rslm['num_proposals'], seed + 2) if rslm else None
+    r = ref.run_mc(prob, noise, dof, S, K, lm_iter, normalize=normalize, rslm=rslm, rslm_noise=rn,
+                   with_pose_opt_plus=with_pose_opt_plus)
+    rslm_kw = dict(num_iter=rslm['num_iter']) if rslm else None
+    o = orc.run_mc(prob, noise, dof, S, K, lm_iter, normalize=normalize, rslm_kw=rslm_kw, rslm_noise=rn,
+                   with_pose_opt_plus=with_pose_opt_plus)
+    o64 = orc.run_mc(prob, noise, dof, S, K, lm_iter, normalize=normalize, rslm_kw=rslm_kw, rslm_noise=rn,
+                     with_pose_opt_plus=with_pose_opt_plus, dtype=torch.float64)
+    check(name, 'pose_opt', r['pose_opt'], o['pose_opt'], 2e-5)
+    check(name, 'cost_init', r['cost_init'], o['cost_init'], 1e-5 * max(1.0, float(r['cost_init'].abs().max())))
+    check(name, 'pose_samples', r['pose_samples'], o['pose_samples'], 5e-3)
+    check(name, 'logweights', r['logweights'], o['logweights'], tol_logw * max(1.0, float(r['logweights'].abs().max())))
+    check(name, 'loss_obj', r['loss_obj'], o['loss_obj'], 1e-3)
+    for k in ('gx3d', 'gx2d', 'gw2d'):
+        check(name, k, r[k], o[k], 2e-3 * float(r[k].abs().max()))
+    if with_pose_opt_plus:
+        check(name, 'pose_opt_plus', r['pose_opt_plus'], o['pose_opt_plus'], 5e-5)
+    REPORT.append((name, 'loss_obj fp32-vs-fp64 oracle', _maxdiff(o['loss_obj'], o64['loss_obj']), float('nan')))
+    REPORT.append((name, 'pose_opt fp32-vs-fp64 oracle', _maxdiff(o['pose_opt'], o64['pose_opt']), float('nan')))
+    extra = {}
+    if rn is not None:
+        extra['rslm'] = rn
+    save(name, prob=prob, noise=noise, ref=r, o64={k: v.float() for k, v in o64.items()}, dof=dof, S=S, K=K,
+         lm_iter=lm_iter, normalize=int(normalize), with_pose_opt_plus=int(with_pose_opt_plus),
+         rslm_cfg=np.array([rslm['num_points'], rslm['num_proposals'], rslm['num_iter']] if rslm else [0, 0, 0]),
+         **extra)
+
+
+def main():
+    case_evaluate('eval6', 6, 6, 40, None, 10)
+    case_evaluate('eval6_clip', 6, 6, 40, 'tight', 11)
+    case_evaluate('eval4_clip', 4, 6, 40, 'tight', 12)
+    case_lm('lm6_tr', 6, 8, 64, 5, False, None, 20)
+    case_lm('lm6_gn', 6, 8, 64, 3, True, None, 21)
+    case_lm('lm6_tr_clip', 6, 8, 48, 5, False, 'tight', 22)
+    case_lm('lm4_tr', 4, 8, 64, 5, False, 'tensor', 23)
+    case_lm('lm4_gn', 4, 8, 33, 5, True, None, 24)
+    case_mc('mc6', 6, 4, 64, 64, 4, 3, 30)
+    case_mc('mc6_n100', 6, 3, 100, 128, 4, 3, 31)
+    case_mc('mc4', 4, 4, 64, 64, 4, 5, 32, bounds='tensor')
+    case_mc('mc4_norm', 4, 3, 32, 32, 2, 5, 33, normalize=True, bounds='tensor')
+    case_mc('mc6_demo', 6, 2, 64, 64, 4, 10, 34, rslm=dict(num_points=8, num_proposals=16, num_iter=5),
+            with_pose_opt_plus=True, cam_kind='identity')
+    case_mc('mc4_rslm', 4, 2, 48, 32, 4, 5, 35, rslm=dict(num_points=16, num_proposals=8, num_iter=3),
+            with_pose_opt_plus=True, normalize=True, bounds='tensor')
+    w = max(len(n) for n, *_ in REPORT)
+    for n, k, d, tol in REPORT:
+        print(f'{n:<{w}}  {k:<32} maxdiff {d:.3e}   tol {tol:.1e}')
+    with open(os.path.join(OUT, 'PINNING_REPORT.txt'), 'w') as f:
+        f.write('reference (/root/reference/epropnp, unmodified, injected noise) vs oracle/epropnp_oracle.py\n')
+        for n, k, d, tol in REPORT:
+            f.write(f'{n:<{w}}  {k:<32} maxdiff {d:.3e}   tol {tol:.1e}\n')
+
+
+if __name__ == '__main__':
+    main()
