@@ -1,0 +1,75 @@
+"""Build libepropnp_hip.so (gfx950 code object + C ABI) in-tree with hipcc.
+
+    python epro-pnp_amd/build.py            # -> epro-pnp_amd/lib/libepropnp_hip.so
+    python epro-pnp_amd/build.py --emu      # -> tests/emu/_build/libepropnp_emu.so (CPU logic emulation, tests only)
+
+hipcc cross-compiles for gfx950 without a GPU.  No torch involved: the library is a plain C ABI.
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['eval_kernels.hip', 'lm_kernel.hip', 'amis_kernels.hip', 'c_api.hip']
+HEADERS = ['pnp_math.h', 'wave_ops.h', 'pnp_sweep.h', 'pnp_host.h', 'dispatch.h']
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(' '.join(cmd) + '\n' + r.stdout + r.stderr)
+        raise RuntimeError('build failed: ' + cmd[-1])
+    return r.stdout + r.stderr
+
+
+def build(emu=False, force=False, verbose=False):
+    deps_common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, 'include', 'epropnp_hip.h')]
+    if emu:
+        out_dir = os.path.join(ROOT, 'tests', 'emu', '_build')
+        lib = os.path.join(out_dir, 'libepropnp_emu.so')
+        shim = os.path.join(ROOT, 'tests', 'emu', 'hip_emu.h')
+        deps_common.append(shim)
+        cc = ['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-x', 'c++', '-include', shim, '-Wno-unknown-pragmas',
+              '-Wno-attributes']
+    else:
+        out_dir = os.path.join(HERE, 'lib')
+        lib = os.path.join(out_dir, 'libepropnp_hip.so')
+        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        cc = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value']
+    os.makedirs(out_dir, exist_ok=True)
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(out_dir, src.replace('.hip', '.emu.o' if emu else '.o'))
+        objs.append(obj)
+        if force or _stale(obj, [sp] + deps_common):
+            jobs.append(cc + ['-c', sp, '-o', obj])
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for out in ex.map(_run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    if jobs or force or _stale(lib, objs):
+        link = (['g++'] if emu else [cc[0], '--offload-arch=gfx950']) + ['-shared', '-fPIC', '-o', lib] + objs
+        _run(link)
+    return lib
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--emu', action='store_true')
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('-v', '--verbose', action='store_true')
+    a = ap.parse_args()
+    print(build(a.emu, a.force, a.verbose))

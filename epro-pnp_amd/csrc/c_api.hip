@@ -1,0 +1,47 @@
+// c_api.hip -- extern "C" surface of libepropnp_hip.so (declared in include/epropnp_hip.h).
+#include "pnp_host.h"
+
+namespace pnp {
+char* last_error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+}  // namespace pnp
+
+extern "C" {
+
+int epropnp_abi_version(void) { return EPROPNP_ABI_VERSION; }
+
+const char* epropnp_last_error(void) { return pnp::last_error_buffer(); }
+
+int epropnp_noise_stride(int dof) { return dof == 6 ? 8 : (dof == 4 ? 4 + 3 * 16 : -1); }
+
+int epropnp_evaluate_cost(const epropnp_problem* prob, const float* poses, int32_t num_poses, float* cost, void* stream) {
+  return pnp::launch_evaluate_cost(prob, poses, num_poses, cost, (hipStream_t)stream);
+}
+
+int epropnp_normal_equations(const epropnp_problem* prob, const float* pose, int32_t clip_jac, float* jtj, float* jtr,
+                             float* cost, void* stream) {
+  return pnp::launch_normal_equations(prob, pose, clip_jac, jtj, jtr, cost, (hipStream_t)stream);
+}
+
+int epropnp_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
+                     float* pose_cov, float* cost, int32_t* accept_mask, void* stream) {
+  return pnp::launch_lm_solve(prob, lm, pose_init, pose_opt, pose_cov, cost, accept_mask, (hipStream_t)stream);
+}
+
+int epropnp_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
+                         const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
+                         float* proposals, void* stream) {
+  return pnp::launch_amis_forward(prob, amis, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
+                                  (hipStream_t)stream);
+}
+
+int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                          int32_t mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
+                          float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream) {
+  return pnp::launch_amis_backward(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init, grad_x3d,
+                                   grad_x2d, grad_w2d, grad_delta, (hipStream_t)stream);
+}
+
+}  // extern "C"

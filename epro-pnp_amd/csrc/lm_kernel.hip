@@ -1,0 +1,200 @@
+// lm_kernel.hip -- the whole Levenberg-Marquardt / Gauss-Newton PnP solve in ONE kernel for gfx950.
+//
+// Replaces LMSolver.solve with a given starting pose (epropnp/levenberg_marquardt.py:132-190), _lm_iter
+// (:192-241) and pose_add (:255-265).  The reference launches ~40 ATen kernels per iteration and keeps two
+// (B,2N,d) Jacobians in memory; here one workgroup owns one object, its N correspondences are read from HBM
+// once and stay in registers for all 1+L sweeps, J^T J / J^T r / cost are wave-reduced with DPP, and the
+// d x d damped system is solved in registers (fp64 Cholesky: the matrix is SPD by construction; the
+// reference's LU with pivoting gives the same solution up to rounding).
+#include "dispatch.h"
+#include "pnp_host.h"
+
+namespace pnp {
+
+struct LmParams {
+  int num_iter, fast_mode;
+  float min_diag, max_diag, min_rel_decrease, radius0, radius_max, eps;
+};
+
+template <int DOF, int PPL, bool BOUNDS>
+struct LmState {
+  static constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
+};
+
+// acc (upper-tri JtJ | Jtr | cost)  ->  dense symmetric fp64 matrix
+template <int DOF>
+PNP_FN void unpack_h(const float (&acc)[NormalEq<DOF>::NV], double (&H)[DOF][DOF]) {
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < DOF; ++i)
+#pragma unroll
+    for (int j = i; j < DOF; ++j) {
+      H[i][j] = (double)acc[idx];
+      H[j][i] = (double)acc[idx];
+      ++idx;
+    }
+}
+
+template <int DOF, int PPL, bool BOUNDS, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams lm, const float* __restrict__ pose_init,
+                                                               float* __restrict__ pose_opt, float* __restrict__ pose_cov,
+                                                               float* __restrict__ cost_out, int* __restrict__ accept_out) {
+  constexpr int PL = PoseLen<DOF>::value;
+  constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
+  __shared__ float scratch[NV * 16];
+  const int b = object_of_block(p.B);
+  if (b >= p.B) return;
+
+  float K[9], delta;
+  Bounds bd;
+  load_camera(p, b, K, bd, delta);
+  Point pts[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) pts[k] = load_point(p, b, (int)threadIdx.x + k * (int)blockDim.x);
+
+  float pose[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) pose[i] = pose_init[(size_t)b * PL + i];
+
+  // one sweep: normal equations + cost of all points at pose `ps`
+  auto sweep = [&](const float* ps, bool clip, float (&acc)[NV]) {
+    float R[9];
+    pose_to_rot<DOF>(ps, R);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, ps, p.z_min, delta, bd, clip, acc);
+    block_sum<NV>(acc, scratch);
+  };
+
+  float cur[NV];
+  int accepted_bits = 0;
+  const double eps = (double)lm.eps;
+
+  if (lm.fast_mode) {
+    // Gauss-Newton (levenberg_marquardt.py:136-152): J^T J + eps I, no clip_jac; pose_cov / cost come from the
+    // last EVALUATED (pre-update) point.
+    for (int it = 0; it < lm.num_iter; ++it) {
+      sweep(pose, false, cur);
+      double H[DOF][DOF], g[DOF];
+      unpack_h<DOF>(cur, H);
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) {
+        H[i][i] += eps;
+        g[i] = (double)cur[NH + i];
+      }
+      cholesky<DOF, double>(H);
+      cholesky_solve<DOF, double>(H, g);
+      float step[DOF], nxt[PL];
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) step[i] = (float)(-g[i]);
+      pose_add<DOF>(pose, step, nxt);
+#pragma unroll
+      for (int i = 0; i < PL; ++i) pose[i] = nxt[i];
+    }
+    if (lm.num_iter == 0) sweep(pose, false, cur);
+  } else {
+    // trust-region LM (Ceres-style), levenberg_marquardt.py:154-169 + _lm_iter
+    sweep(pose, true, cur);
+    float radius = lm.radius0, decrease = 2.0f;
+    for (int it = 0; it < lm.num_iter; ++it) {
+      double H[DOF][DOF], Hlm[DOF][DOF], g[DOF], st[DOF];
+      unpack_h<DOF>(cur, H);
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) {
+#pragma unroll
+        for (int j = 0; j < DOF; ++j) Hlm[i][j] = H[i][j];
+        // diagonal += clamp(diagonal, min, max) / radius + eps   (fp32 like the reference, :210-211)
+        const float d = cur[/*diag index*/ i * DOF - i * (i - 1) / 2];
+        const float add = fminf(fmaxf(d, lm.min_diag), lm.max_diag) / radius + lm.eps;
+        Hlm[i][i] = (double)(d + add);
+        g[i] = (double)cur[NH + i];
+        st[i] = g[i];
+      }
+      cholesky<DOF, double>(Hlm);
+      cholesky_solve<DOF, double>(Hlm, st);   // st = Hlm^-1 g ; step = -st
+      float step[DOF], pose_new[PL];
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) step[i] = (float)(-st[i]);
+      pose_add<DOF>(pose, step, pose_new);
+
+      float nxt[NV];
+      sweep(pose_new, true, nxt);
+
+      // model_cost_change = -step^T (H step / 2 + g)     (:225), in fp32 step like the reference
+      double mcc = 0.0;
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) {
+        double hs = 0.0;
+#pragma unroll
+        for (int j = 0; j < DOF; ++j) hs += H[i][j] * (double)step[j];
+        mcc -= (double)step[i] * (0.5 * hs + g[i]);
+      }
+      const float model_change = (float)mcc;
+      const float rel = (cur[NV - 1] - nxt[NV - 1]) / model_change;
+      const bool ok = (rel >= lm.min_rel_decrease) && (model_change > 0.0f);
+      if (ok) {   // wave-uniform
+        accepted_bits |= (1 << (it & 31));
+#pragma unroll
+        for (int i = 0; i < PL; ++i) pose[i] = pose_new[i];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
+        const float t3 = 2.0f * rel - 1.0f;
+        radius = radius / fmaxf(1.0f - t3 * t3 * t3, 1.0f / 3.0f);
+      }
+      radius = fminf(fmaxf(radius, lm.eps), lm.radius_max);   // clamp applies to every object (:235)
+      if (ok) {
+        decrease = 2.0f;
+      } else {
+        radius = radius / decrease;   // reject path is not re-clamped in the same iteration (:239)
+        decrease *= 2.0f;
+      }
+    }
+  }
+
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < PL; ++i) pose_opt[(size_t)b * PL + i] = pose[i];
+    if (cost_out) cost_out[b] = cur[NV - 1];
+    if (accept_out) accept_out[b] = accepted_bits;
+    if (pose_cov) {   // inverse(J^T J + eps I) at the final accepted point (:170-181)
+      double H[DOF][DOF], Hi[DOF][DOF];
+      unpack_h<DOF>(cur, H);
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) H[i][i] = (double)(cur[i * DOF - i * (i - 1) / 2] + lm.eps);
+      spd_inverse<DOF, double>(H, Hi);
+#pragma unroll
+      for (int i = 0; i < DOF; ++i)
+#pragma unroll
+        for (int j = 0; j < DOF; ++j) pose_cov[(size_t)b * DOF * DOF + i * DOF + j] = (float)Hi[i][j];
+    }
+  }
+}
+
+int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
+                    float* pose_cov, float* cost, int32_t* accept_mask, hipStream_t st) {
+  if (int rc = check_problem(prob)) return rc;
+  if (!lm) return fail(EPROPNP_EINVAL, "lm_solve: params NULL");
+  if (prob->num_obj == 0) return EPROPNP_OK;
+  if (!pose_init || !pose_opt) return fail(EPROPNP_EINVAL, "lm_solve: NULL pose pointer");
+  if (lm->num_iter < 0 || lm->num_iter > 31 * 1000) return fail(EPROPNP_EINVAL, "lm_solve: bad num_iter");
+  if (prob->num_pts > kMaxResidentPoints)
+    return fail(EPROPNP_EINVAL, "lm_solve: num_pts %d exceeds the register-resident limit %d", prob->num_pts,
+                kMaxResidentPoints);
+  const Problem d = to_device_problem(prob);
+  LmParams k;
+  k.num_iter = lm->num_iter; k.fast_mode = lm->fast_mode;
+  k.min_diag = lm->min_lm_diagonal; k.max_diag = lm->max_lm_diagonal;
+  k.min_rel_decrease = lm->min_relative_decrease; k.radius0 = lm->initial_trust_region_radius;
+  k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps;
+  const Shape s = choose_shape(d.B, d.N);
+  const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
+  dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
+    PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),
+               grid, block, 0, st, d, k, pose_init, pose_opt, pose_cov, cost, accept_mask);
+    return 0;
+  });
+  return check_launch("lm_solve_kernel");
+}
+
+}  // namespace pnp

@@ -1,0 +1,80 @@
+// pnp_host.h -- host-side plumbing shared by the launchers: argument checks, error reporting, workgroup
+// shape selection.  No torch types anywhere: the library is a plain C ABI over device pointers.
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/epropnp_hip.h"
+#include "pnp_sweep.h"
+
+namespace pnp {
+
+char* last_error_buffer();   // thread-local, defined in c_api.hip
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(EPROPNP_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return EPROPNP_OK;
+}
+
+inline int check_problem(const epropnp_problem* p) {
+  if (p == nullptr) return fail(EPROPNP_EINVAL, "problem is NULL");
+  if (p->dof != 4 && p->dof != 6) return fail(EPROPNP_EINVAL, "dof must be 4 or 6, got %d", p->dof);
+  if (p->num_obj < 0 || p->num_pts < 0) return fail(EPROPNP_EINVAL, "negative sizes");
+  if (p->num_obj > 0 && p->num_pts > 0 &&
+      (!p->x3d || !p->x2d || !p->w2d || !p->cam_mats || !p->delta))
+    return fail(EPROPNP_EINVAL, "NULL device pointer in problem");
+  return EPROPNP_OK;
+}
+
+inline Problem to_device_problem(const epropnp_problem* p) {
+  Problem d;
+  d.x3d = p->x3d; d.x2d = p->x2d; d.w2d = p->w2d; d.cam = p->cam_mats;
+  d.lb = p->lb; d.ub = p->ub; d.delta = p->delta;
+  d.z_min = p->z_min; d.B = p->num_obj; d.N = p->num_pts;
+  return d;
+}
+
+inline bool has_bounds(const epropnp_problem* p) { return p->lb != nullptr && p->ub != nullptr; }
+
+constexpr int kMaxResidentPoints = 64 * 16 * 8;   // 16 waves x 64 lanes x 8 points per lane
+
+// Pick waves-per-object and points-per-lane for kernels that keep the object's points in registers.
+// Few objects -> more waves per object (fill the 1024 SIMDs); many objects -> fewer, fatter waves.
+inline Shape choose_shape(int B, int N, int max_ppl = 8, int want_waves_total = 4096) {
+  Shape s;
+  int wmin = 1;
+  while (64 * wmin * max_ppl < N && wmin < 16) wmin *= 2;
+  int wmax = 1;
+  while (64 * wmax < N && wmax < 16) wmax *= 2;
+  int w = wmin;
+  while (w < wmax && (long)B * w < want_waves_total) w *= 2;
+  s.waves = w;
+  int ppl = 1;
+  while (64 * w * ppl < N) ppl *= 2;
+  s.ppl = ppl;
+  return s;
+}
+
+// launchers (one per .hip translation unit)
+int launch_evaluate_cost(const epropnp_problem* prob, const float* poses, int num_poses, float* cost, hipStream_t st);
+int launch_normal_equations(const epropnp_problem* prob, const float* pose, int clip_jac, float* jtj, float* jtr,
+                            float* cost, hipStream_t st);
+int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
+                    float* pose_cov, float* cost, int32_t* accept_mask, hipStream_t st);
+int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
+                        const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
+                        float* proposals, hipStream_t st);
+int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                         int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
+                         float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);
+
+}  // namespace pnp

@@ -1,0 +1,345 @@
+// pnp_math.h -- per-thread math of the EPro-PnP hot path (register-resident, no memory traffic).
+//
+// Follows the formulas of the reference (paths relative to the reference checkout):
+//   rotation / tangent map ....... epropnp/common.py:21-64, epropnp/camera.py:145-165
+//   projection + clamp ........... epropnp/camera.py:10-30,81-93
+//   Jacobian + clip .............. epropnp/camera.py:100-143
+//   Huber cost / rescaling ....... epropnp/cost_fun.py:8-20,45-84
+//   pose update .................. epropnp/levenberg_marquardt.py:255-265
+//   Student-t / ACG / vM-mixture . pyro MultivariateStudentT, epropnp/distributions.py:15-79,
+//                                  torch/distributions/von_mises.py:24-89
+// The small dense algebra (6x6 / 4x4 / 3x3) is fully unrolled so that everything lives in VGPRs.
+#pragma once
+#ifndef EPROPNP_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <math.h>
+#include <stdint.h>
+
+#define PNP_FN __device__ __forceinline__
+
+namespace pnp {
+
+// ---------------------------------------------------------------------------------------------------
+// fast reciprocal / rsqrt for the VALU-bound AMIS sweeps (1 ulp hardware approximations);
+// the LM path uses IEEE division and sqrtf.
+// ---------------------------------------------------------------------------------------------------
+PNP_FN float fast_rcp(float x) {
+#ifndef EPROPNP_EMU
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+PNP_FN float fast_rsqrt(float x) {
+#ifndef EPROPNP_EMU
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+PNP_FN float fast_sqrt(float x) {
+#ifndef EPROPNP_EMU
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
+
+template <int DOF>
+struct PoseLen {
+  static constexpr int value = (DOF == 6) ? 7 : 4;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// rotations
+// ---------------------------------------------------------------------------------------------------
+// unit quaternion [w,i,j,k] -> row-major R; same association as the reference's no-grad branch:
+// R = 2 (w [v]x + v v^T) + (w^2 - v.v) I, quaternion not normalised.
+PNP_FN void quat_to_rot(float w, float x, float y, float z, float (&R)[9]) {
+  const float dd = w * w - (x * x + y * y + z * z);
+  R[0] = 2.f * (x * x) + dd;
+  R[1] = 2.f * (x * y - w * z);
+  R[2] = 2.f * (x * z + w * y);
+  R[3] = 2.f * (x * y + w * z);
+  R[4] = 2.f * (y * y) + dd;
+  R[5] = 2.f * (y * z - w * x);
+  R[6] = 2.f * (x * z - w * y);
+  R[7] = 2.f * (y * z + w * x);
+  R[8] = 2.f * (z * z) + dd;
+}
+
+PNP_FN void yaw_to_rot(float yaw, float (&R)[9]) {
+  const float c = cosf(yaw), s = sinf(yaw);
+  R[0] = c;   R[1] = 0.f; R[2] = s;
+  R[3] = 0.f; R[4] = 1.f; R[5] = 0.f;
+  R[6] = -s;  R[7] = 0.f; R[8] = c;
+}
+
+template <int DOF>
+PNP_FN void pose_to_rot(const float* pose, float (&R)[9]) {
+  if (DOF == 6) quat_to_rot(pose[3], pose[4], pose[5], pose[6], R);
+  else yaw_to_rot(pose[3], R);
+}
+
+// project_b operands: KR = K R, Kt = K t  (epropnp/camera.py:23-27)
+PNP_FN void compose_kr_kt(const float (&K)[9], const float (&R)[9], const float* t, float (&KR)[9], float (&Kt)[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) KR[r * 3 + c] = K[r * 3] * R[c] + K[r * 3 + 1] * R[3 + c] + K[r * 3 + 2] * R[6 + c];
+    Kt[r] = K[r * 3] * t[0] + K[r * 3 + 1] * t[1] + K[r * 3 + 2] * t[2];
+  }
+}
+
+// pose_new = pose (+) step   (levenberg_marquardt.py:255-265; T(q) from camera.py:158-165)
+template <int DOF>
+PNP_FN void pose_add(const float* pose, const float* step, float* out) {
+  out[0] = pose[0] + step[0];
+  out[1] = pose[1] + step[1];
+  out[2] = pose[2] + step[2];
+  if (DOF == 4) {
+    out[3] = pose[3] + step[3];
+  } else {
+    const float w = pose[3], i = pose[4], j = pose[5], k = pose[6];
+    const float a = step[3], b = step[4], c = step[5];
+    float q0 = w + (i * a + j * b + k * c);
+    float q1 = i + (-w * a - k * b + j * c);
+    float q2 = j + (k * a - w * b - i * c);
+    float q3 = k + (-j * a + i * b - w * c);
+    const float n = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+    out[3] = q0 / n; out[4] = q1 / n; out[5] = q2 / n; out[6] = q3 / n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one 2D-3D correspondence, as kept in registers
+// ---------------------------------------------------------------------------------------------------
+struct Point {
+  float X, Y, Z;    // x3d
+  float u, v;       // x2d
+  float wu, wv;     // w2d
+};
+
+struct Bounds {   // projection clamp; only used when the kernel is instantiated with BOUNDS = true
+  float lbx, lby, ubx, uby;
+};
+
+// Huber cost of one point under pose (KR, Kt): cost-only path (project_b).  FAST selects the 1-ulp
+// hardware rcp/sqrt (AMIS sweeps); otherwise IEEE division / sqrt (cost_init, evaluate_cost).
+template <bool BOUNDS, bool FAST>
+PNP_FN float point_cost(const Point& p, const float (&KR)[9], const float (&Kt)[3], float z_min, float delta,
+                        const Bounds& bd) {
+  const float hx = fmaf(KR[0], p.X, fmaf(KR[1], p.Y, fmaf(KR[2], p.Z, Kt[0])));
+  const float hy = fmaf(KR[3], p.X, fmaf(KR[4], p.Y, fmaf(KR[5], p.Z, Kt[1])));
+  const float hz = fmaf(KR[6], p.X, fmaf(KR[7], p.Y, fmaf(KR[8], p.Z, Kt[2])));
+  const float z = fmaxf(hz, z_min);
+  float px, py;
+  if (FAST) {
+    const float rz = fast_rcp(z);
+    px = hx * rz;
+    py = hy * rz;
+  } else {
+    px = hx / z;
+    py = hy / z;
+  }
+  if (BOUNDS) {
+    px = fminf(fmaxf(px, bd.lbx), bd.ubx);
+    py = fminf(fmaxf(py, bd.lby), bd.uby);
+  }
+  const float rx = (px - p.u) * p.wu;
+  const float ry = (py - p.v) * p.wv;
+  const float s = fmaf(rx, rx, ry * ry);
+  const float rho = FAST ? fast_sqrt(s) : sqrtf(s);
+  // huber: rho <= delta ? rho^2/2 : delta*rho - delta^2/2  ==  m*(rho - m/2), m = min(rho, delta)
+  const float m = fminf(rho, delta);
+  return m * fmaf(-0.5f, m, rho);
+}
+
+// Exact-form Huber (same expression as cost_fun.py:8-12) for the non-fast paths.
+PNP_FN float huber_exact(float rho, float delta) {
+  return (rho <= delta) ? 0.5f * rho * rho : delta * rho - 0.5f * delta * delta;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tiny dense linear algebra, fully unrolled
+// ---------------------------------------------------------------------------------------------------
+// Cholesky A = L L^T in place on the lower triangle; returns false when a pivot is not positive/finite.
+template <int D, typename T>
+PNP_FN bool cholesky(T (&A)[D][D]) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    T d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    ok = ok && (d > T(0)) && (d < T(1e300));
+    const T l = sqrt(d > T(0) ? d : T(1));
+    A[j][j] = l;
+    const T inv = T(1) / l;
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      T s = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
+      A[i][j] = s * inv;
+    }
+  }
+  return ok;
+}
+
+// solve L L^T x = b in place (L lower)
+template <int D, typename T>
+PNP_FN void cholesky_solve(const T (&L)[D][D], T (&b)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    T s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[i][k] * b[k];
+    b[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = D - 1; i >= 0; --i) {
+    T s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < D; ++k) s -= L[k][i] * b[k];
+    b[i] = s / L[i][i];
+  }
+}
+
+// inverse of a lower-triangular matrix (result lower-triangular, upper part zeroed)
+template <int D, typename T>
+PNP_FN void tri_inverse(const T (&L)[D][D], T (&Li)[D][D]) {
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      if (i < j) {
+        Li[i][j] = T(0);
+      } else if (i == j) {
+        Li[i][j] = T(1) / L[i][i];
+      } else {
+        T s = T(0);
+#pragma unroll
+        for (int k = j; k < i; ++k) s -= L[i][k] * Li[k][j];
+        Li[i][j] = s / L[i][i];
+      }
+    }
+  }
+}
+
+// SPD inverse through Cholesky: A^-1 = L^-T L^-1.  A is overwritten by its Cholesky factor.
+// Returns false when A is not positive definite (result then undefined).
+template <int D, typename T>
+PNP_FN bool spd_inverse(T (&A)[D][D], T (&Ainv)[D][D]) {
+  const bool ok = cholesky<D, T>(A);
+  T Li[D][D];
+  tri_inverse<D, T>(A, Li);
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      T s = T(0);
+#pragma unroll
+      for (int k = i; k < D; ++k) s += Li[k][i] * Li[k][j];
+      Ainv[i][j] = s;
+      Ainv[j][i] = s;
+    }
+  return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// proposal densities
+// ---------------------------------------------------------------------------------------------------
+constexpr float kLogPi = 1.1447298858494002f;
+constexpr float kLog2Pi = 1.8378770664093453f;
+
+// Student-t (df = 3, n = 3) normaliser:  sum log diag L + 1.5 log 3 + 1.5 log pi + lgamma(1.5) - lgamma(3)
+//   lgamma(1.5) = log(sqrt(pi)/2), lgamma(3) = log 2
+PNP_FN float student_t3_log_norm(float sum_log_diag) {
+  return sum_log_diag + 1.5f * 1.0986122886681098f + 1.5f * kLogPi + (-0.12078223763524522f) - 0.6931471805599453f;
+}
+PNP_FN float student_t3_logprob(float maha, float log_norm) { return -3.0f * log1pf(maha * (1.0f / 3.0f)) - log_norm; }
+
+// ACG on S^3 (q = 4): -2 log(maha) - sum log diag L - log(2 pi^2)
+PNP_FN float acg4_logprob(float maha, float sum_log_diag) {
+  return -2.0f * logf(maha) - sum_log_diag - 2.9826069522587457f;
+}
+
+// log I0(x), polynomial of torch/distributions/von_mises.py:24-89 (Abramowitz & Stegun 9.8.1 / 9.8.2)
+PNP_FN float log_i0(float x) {
+  if (x < 3.75f) {
+    float y = x / 3.75f;
+    y = y * y;
+    float r = 0.45813e-2f;
+    r = 0.360768e-1f + y * r;
+    r = 0.2659732f + y * r;
+    r = 1.2067492f + y * r;
+    r = 3.0899424f + y * r;
+    r = 3.5156229f + y * r;
+    r = 1.0f + y * r;
+    return logf(r);
+  }
+  const float y = 3.75f / x;
+  float r = 0.392377e-2f;
+  r = -0.1647633e-1f + y * r;
+  r = 0.2635537e-1f + y * r;
+  r = -0.2057706e-1f + y * r;
+  r = 0.916281e-2f + y * r;
+  r = -0.157565e-2f + y * r;
+  r = 0.225319e-2f + y * r;
+  r = 0.1328592e-1f + y * r;
+  r = 0.39894228f + y * r;
+  return x - 0.5f * logf(x) + logf(r);
+}
+
+// 0.75 von Mises + 0.25 uniform on the circle (epropnp/distributions.py:74-79); log_i0k = log_i0(kappa)
+PNP_FN float vm_mix_logprob(float x, float loc, float kappa, float log_i0k) {
+  const float a = kappa * cosf(x - loc) - kLog2Pi - log_i0k + (-0.2876820724517809f);   // + log 0.75
+  const float b = -3.224171427529236f;                                                  // log(0.25 / 2pi)
+  const float mx = fmaxf(a, b);
+  return mx + log1pf(expf(-fabsf(a - b)));
+}
+
+PNP_FN float log_add_exp(float a, float b) {
+  const float mx = fmaxf(a, b);
+  if (mx == -INFINITY) return -INFINITY;
+  return mx + log1pf(expf(-fabsf(a - b)));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// counter-based RNG: Philox4x32-10 (Salmon et al., SC'11), Box-Muller normals
+// ---------------------------------------------------------------------------------------------------
+struct Philox4 {
+  uint32_t v[4];
+};
+
+PNP_FN uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+PNP_FN Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Philox4 out;
+  out.v[0] = c0; out.v[1] = c1; out.v[2] = c2; out.v[3] = c3;
+  return out;
+}
+
+// uint32 -> uniform in (0, 1]
+PNP_FN float u01(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+
+// two independent N(0,1) from two uint32
+PNP_FN void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float r = sqrtf(-2.0f * logf(u01(a)));
+  const float th = 6.283185307179586f * u01(b);
+  n0 = r * cosf(th);
+  n1 = r * sinf(th);
+}
+
+}  // namespace pnp

@@ -1,0 +1,141 @@
+// pnp_sweep.h -- device-side view of one batch of PnP problems, point loading, and the per-point
+// "evaluate with Jacobian -> normal equations" body shared by the sweep kernel and the fused LM kernel.
+#pragma once
+#include "pnp_math.h"
+#include "wave_ops.h"
+
+namespace pnp {
+
+// by-value kernel argument (device pointers); mirrors epropnp_problem of include/epropnp_hip.h
+struct Problem {
+  const float* __restrict__ x3d;
+  const float* __restrict__ x2d;
+  const float* __restrict__ w2d;
+  const float* __restrict__ cam;
+  const float* __restrict__ lb;
+  const float* __restrict__ ub;
+  const float* __restrict__ delta;
+  float z_min;
+  int B, N;
+};
+
+// XCD-aware object index: the dispatcher is observed to place workgroup g on XCD g % 8, so give each XCD
+// a contiguous range of objects -- neighbouring objects then share an L2 and their partial-line output
+// writes ((S,B,.) layouts put objects b, b+1 in the same cache line) merge there.  Speed only.
+__device__ __forceinline__ int object_of_block(int B) {
+  const int g = (int)blockIdx.x;
+  const int per = (B + 7) >> 3;
+  const int b = (g & 7) * per + (g >> 3);
+  return b;   // may be >= B for the padded tail: caller must check
+}
+__host__ __device__ __forceinline__ int padded_object_grid(int B) { return ((B + 7) >> 3) << 3; }
+
+__device__ __forceinline__ Point load_point(const Problem& p, int b, int n) {
+  Point q;
+  if (n < p.N) {
+    const size_t i = (size_t)b * (size_t)p.N + (size_t)n;
+    const float* a = p.x3d + i * 3;
+    q.X = a[0]; q.Y = a[1]; q.Z = a[2];
+    const float2 u = *reinterpret_cast<const float2*>(p.x2d + i * 2);
+    const float2 w = *reinterpret_cast<const float2*>(p.w2d + i * 2);
+    q.u = u.x; q.v = u.y; q.wu = w.x; q.wv = w.y;
+  } else {   // padding: zero weight => zero cost, zero Jacobian, zero gradient
+    q.X = q.Y = q.Z = q.u = q.v = q.wu = q.wv = 0.f;
+  }
+  return q;
+}
+
+__device__ __forceinline__ void load_camera(const Problem& p, int b, float (&K)[9], Bounds& bd, float& delta) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) K[i] = p.cam[(size_t)b * 9 + i];
+  if (p.lb != nullptr && p.ub != nullptr) {
+    bd.lbx = p.lb[(size_t)b * 2]; bd.lby = p.lb[(size_t)b * 2 + 1];
+    bd.ubx = p.ub[(size_t)b * 2]; bd.uby = p.ub[(size_t)b * 2 + 1];
+  } else {
+    bd.lbx = bd.lby = -INFINITY;
+    bd.ubx = bd.uby = INFINITY;
+  }
+  delta = p.delta[b];
+}
+
+template <int DOF>
+struct NormalEq {
+  static constexpr int NH = DOF * (DOF + 1) / 2;   // upper triangle of J^T J, row-major
+  static constexpr int NV = NH + DOF + 1;          // + J^T r + cost
+};
+
+// One point's contribution to (J^T J, J^T r, cost) at pose (R, t): the Jacobian path
+// project_a -> clamp -> Jacobian -> clip -> Huber rescale  (camera.py:10-18,81-143; cost_fun.py:45-84).
+// IEEE division / sqrt throughout: this path feeds the trust-region accept test.
+template <int DOF, bool BOUNDS>
+PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R)[9], const float* t, float z_min,
+                            float delta, const Bounds& bd, bool clip, float (&acc)[NormalEq<DOF>::NV]) {
+  const float xr0 = R[0] * p.X + R[1] * p.Y + R[2] * p.Z;
+  const float xr1 = R[3] * p.X + R[4] * p.Y + R[5] * p.Z;
+  const float xr2 = R[6] * p.X + R[7] * p.Y + R[8] * p.Z;
+  const float c0 = xr0 + t[0], c1 = xr1 + t[1], c2 = xr2 + t[2];
+  const float hx = c0 * K[0] + c1 * K[1] + c2 * K[2];
+  const float hy = c0 * K[3] + c1 * K[4] + c2 * K[5];
+  const float hz = c0 * K[6] + c1 * K[7] + c2 * K[8];
+  const float z = fmaxf(hz, z_min);
+  float px = hx / z, py = hy / z;
+  if (BOUNDS) {
+    px = fminf(fmaxf(px, bd.lbx), bd.ubx);
+    py = fminf(fmaxf(py, bd.lby), bd.uby);
+  }
+  float J0[DOF], J1[DOF];
+  J0[0] = K[0] / z; J0[1] = K[1] / z; J0[2] = (K[2] - px) / z;
+  J1[0] = K[3] / z; J1[1] = K[4] / z; J1[2] = (K[5] - py) / z;
+  if (DOF == 6) {
+    const float ax = 2.f * xr0, ay = 2.f * xr1, az = 2.f * xr2;
+    J0[3] = J0[1] * az - J0[2] * ay;
+    J0[4] = J0[2] * ax - J0[0] * az;
+    J0[5] = J0[0] * ay - J0[1] * ax;
+    J1[3] = J1[1] * az - J1[2] * ay;
+    J1[4] = J1[2] * ax - J1[0] * az;
+    J1[5] = J1[0] * ay - J1[1] * ax;
+  } else {
+    J0[3] = J0[0] * xr2 - J0[2] * xr0;
+    J1[3] = J1[0] * xr2 - J1[2] * xr0;
+  }
+  const float rx = (px - p.u) * p.wu;
+  const float ry = (py - p.v) * p.wv;
+  const float rho = sqrtf(rx * rx + ry * ry);
+  const float gam = sqrtf(fminf(delta / fmaxf(rho, 1e-10f), 1.0f));
+  float s0 = p.wu * gam, s1 = p.wv * gam;
+  if (clip) {
+    const bool zc = (z == z_min);
+    bool k0 = zc, k1 = zc;
+    if (BOUNDS) {
+      k0 = k0 || (px == bd.lbx) || (px == bd.ubx);
+      k1 = k1 || (py == bd.lby) || (py == bd.uby);
+    }
+    s0 = k0 ? 0.f : s0;
+    s1 = k1 ? 0.f : s1;
+  }
+  const float e0 = rx * gam, e1 = ry * gam;
+#pragma unroll
+  for (int i = 0; i < DOF; ++i) {
+    J0[i] *= s0;
+    J1[i] *= s1;
+  }
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < DOF; ++i)
+#pragma unroll
+    for (int j = i; j < DOF; ++j) {
+      acc[idx] = fmaf(J0[i], J0[j], fmaf(J1[i], J1[j], acc[idx]));
+      ++idx;
+    }
+#pragma unroll
+  for (int i = 0; i < DOF; ++i) acc[NormalEq<DOF>::NH + i] = fmaf(J0[i], e0, fmaf(J1[i], e1, acc[NormalEq<DOF>::NH + i]));
+  acc[NormalEq<DOF>::NV - 1] += huber_exact(rho, delta);
+}
+
+// workgroup shape chosen by the host for kernels that keep an object's points in registers
+struct Shape {
+  int waves;   // waves per object (1..16)
+  int ppl;     // points per lane (1,2,4,8);  64 * waves * ppl >= N
+};
+
+}  // namespace pnp

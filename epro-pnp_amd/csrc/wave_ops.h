@@ -1,0 +1,107 @@
+// wave_ops.h -- wavefront (64 lanes) and workgroup reduction / broadcast primitives for gfx950.
+//
+// On the device these are DPP row rotations (v_add_f32 ... row_ror) plus v_readlane, i.e. they never touch
+// LDS memory.  The reduction order is fixed, so results are run-to-run deterministic.
+// (tests/emu/hip_emu.h supplies a CPU stand-in for the same five primitives; it is test infrastructure.)
+#pragma once
+
+#ifndef EPROPNP_EMU
+#include <hip/hip_runtime.h>
+#define PNP_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define PNP_DYN_SMEM(type, name)                                                  \
+  extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_smem[]; \
+  type* name = reinterpret_cast<type*>(name##_raw_smem)
+#endif
+
+namespace pnp {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+#ifndef EPROPNP_EMU
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+
+// value of `x` held by lane `src` (wave-uniform `src`) -> scalar register
+__device__ __forceinline__ float wave_bcast(float x, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+}
+__device__ __forceinline__ int wave_bcast(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
+
+// sum over the 64 lanes, result in every lane.  row_ror:8/4/2/1 inside each 16-lane row, then 4 readlanes.
+__device__ __forceinline__ float wave_sum(float x) {
+  x += dpp_mov<0x128>(x);
+  x += dpp_mov<0x124>(x);
+  x += dpp_mov<0x122>(x);
+  x += dpp_mov<0x121>(x);
+  return (wave_bcast(x, 0) + wave_bcast(x, 16)) + (wave_bcast(x, 32) + wave_bcast(x, 48));
+}
+
+__device__ __forceinline__ float wave_max(float x) {
+  x = fmaxf(x, dpp_mov<0x128>(x));
+  x = fmaxf(x, dpp_mov<0x124>(x));
+  x = fmaxf(x, dpp_mov<0x122>(x));
+  x = fmaxf(x, dpp_mov<0x121>(x));
+  return fmaxf(fmaxf(wave_bcast(x, 0), wave_bcast(x, 16)), fmaxf(wave_bcast(x, 32), wave_bcast(x, 48)));
+}
+
+#else  // CPU stand-in (tests only)
+
+__device__ __forceinline__ float wave_bcast(float x, int src) { return emu::shfl(x, src); }
+__device__ __forceinline__ int wave_bcast(int x, int src) { return emu::shfl(x, src); }
+__device__ __forceinline__ float wave_sum(float x) {
+  for (int m : {8, 4, 2, 1}) {
+    int l = lane_id();
+    x += emu::shfl(x, (l & ~15) | ((l + m) & 15));
+  }
+  return (wave_bcast(x, 0) + wave_bcast(x, 16)) + (wave_bcast(x, 32) + wave_bcast(x, 48));
+}
+__device__ __forceinline__ float wave_max(float x) {
+  for (int m : {32, 16, 8, 4, 2, 1}) x = fmaxf(x, emu::shfl(x, lane_id() ^ m));
+  return x;
+}
+
+#endif
+
+// Sum NV per-thread values over the whole workgroup; every thread receives the totals.
+// `scratch` must hold NV * (blockDim.x / 64) floats of LDS.  Two barriers (none for a single-wave group).
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* scratch) {
+  const int nw = (int)(blockDim.x >> 6);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  if (nw == 1) return;
+  const int w = wave_id();
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) scratch[w * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float s = scratch[i];
+    for (int k = 1; k < nw; ++k) s += scratch[k * NV + i];
+    v[i] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float block_max(float x, float* scratch) {
+  const int nw = (int)(blockDim.x >> 6);
+  x = wave_max(x);
+  if (nw == 1) return x;
+  if (lane_id() == 0) scratch[wave_id()] = x;
+  __syncthreads();
+  float m = scratch[0];
+  for (int k = 1; k < nw; ++k) m = fmaxf(m, scratch[k]);
+  __syncthreads();
+  return m;
+}
+
+}  // namespace pnp

@@ -1,0 +1,110 @@
+"""ctypes binding of libepropnp_hip.so (C ABI declared in include/epropnp_hip.h).
+
+There is no CPU implementation behind this module: if the shared library has not been built
+(`python epro-pnp_amd/build.py`) or a tensor does not live on a HIP device, calls raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libepropnp_hip.so')
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+class Problem(C.Structure):
+    _fields_ = [('x3d', C.c_void_p), ('x2d', C.c_void_p), ('w2d', C.c_void_p), ('cam_mats', C.c_void_p),
+                ('lb', C.c_void_p), ('ub', C.c_void_p), ('delta', C.c_void_p), ('z_min', C.c_float),
+                ('num_obj', C.c_int32), ('num_pts', C.c_int32), ('dof', C.c_int32)]
+
+
+class LmParams(C.Structure):
+    _fields_ = [('num_iter', C.c_int32), ('fast_mode', C.c_int32), ('min_lm_diagonal', C.c_float),
+                ('max_lm_diagonal', C.c_float), ('min_relative_decrease', C.c_float),
+                ('initial_trust_region_radius', C.c_float), ('max_trust_region_radius', C.c_float),
+                ('eps', C.c_float)]
+
+
+class AmisParams(C.Structure):
+    _fields_ = [('mc_samples', C.c_int32), ('num_iter', C.c_int32), ('eps', C.c_float),
+                ('acg_mle_iter', C.c_int32), ('acg_dispersion', C.c_float), ('seed', C.c_uint64),
+                ('offset', C.c_uint64)]
+
+
+ABI_VERSION = 1
+_lib = None
+_emulated = False     # True only when a test installed the CPU logic-emulation build (tests/emu)
+
+
+def _declare(lib):
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.epropnp_abi_version.restype = C.c_int
+    lib.epropnp_last_error.restype = C.c_char_p
+    lib.epropnp_noise_stride.argtypes = [C.c_int]
+    lib.epropnp_evaluate_cost.argtypes = [C.POINTER(Problem), vp, i32, vp, vp]
+    lib.epropnp_normal_equations.argtypes = [C.POINTER(Problem), vp, i32, vp, vp, vp, vp]
+    lib.epropnp_lm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), vp, vp, vp, vp, vp, vp]
+    lib.epropnp_amis_forward.argtypes = [C.POINTER(Problem), C.POINTER(AmisParams), vp, vp, vp, vp, vp, vp, vp]
+    lib.epropnp_amis_backward.argtypes = [C.POINTER(Problem), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    for name in ('evaluate_cost', 'normal_equations', 'lm_solve', 'amis_forward', 'amis_backward'):
+        getattr(lib, 'epropnp_' + name).restype = C.c_int
+    return lib
+
+
+EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 'epropnp_evaluate_cost',
+           'epropnp_normal_equations', 'epropnp_lm_solve', 'epropnp_amis_forward', 'epropnp_amis_backward')
+
+
+def lib():
+    """The loaded library; raises if it was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: the HIP extension has not been built '
+                '(run `python epro-pnp_amd/build.py`); there is no CPU fallback')
+        loaded = _declare(C.CDLL(LIB_PATH))
+        if loaded.epropnp_abi_version() != ABI_VERSION:
+            raise RuntimeError('libepropnp_hip.so ABI version mismatch')
+        _lib = loaded
+    return _lib
+
+
+def _use_emulation_library(path):
+    """TESTS ONLY: route calls to the CPU logic-emulation build of the same kernel sources (tests/emu).
+    Never called by product code; lets `pytest -m "not gpu"` exercise kernel + host logic without a GPU."""
+    global _lib, _emulated
+    _lib = _declare(C.CDLL(path)) if path else None
+    _emulated = bool(path)
+
+
+def is_emulated():
+    return _emulated
+
+
+def check_device(t, name):
+    if _emulated:
+        if t.is_cuda:
+            raise RuntimeError('emulation library installed but a device tensor was passed')
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must live on a HIP device (got {t.device}); the EPro-PnP HIP path has no CPU fallback')
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    if _emulated:
+        return None
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def call(fn_name, *args):
+    rc = getattr(lib(), fn_name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{fn_name} failed ({rc}): {lib().epropnp_last_error().decode()}')

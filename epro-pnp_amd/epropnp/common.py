@@ -1,0 +1,63 @@
+"""SE(3) helpers, evaluate_pnp, pnp_normalize / pnp_denormalize.
+
+API mirror of the reference's epropnp/common.py.  PyTorch, autograd-capable; used by the framework-level API and
+by the differentiable Gauss-Newton step.  The HIP kernels restate the same math in registers (csrc/pnp_math.h).
+"""
+import torch
+
+
+def skew(x):
+    """(*,3) -> (*,3,3) cross-product matrices."""
+    a, b, c = x.unbind(-1)
+    o = torch.zeros_like(a)
+    return torch.stack((o, -c, b, c, o, -a, -b, a, o), dim=-1).reshape(x.shape[:-1] + (3, 3))
+
+
+def quaternion_to_rot_mat(quaternions):
+    """(*,4) [w,i,j,k] (assumed unit, not normalised here) -> (*,3,3).
+    R = (w^2 - |v|^2) I + 2 v v^T + 2 w [v]x  (reference: epropnp/common.py:21-42)."""
+    w = quaternions[..., :1]
+    v = quaternions[..., 1:]
+    outer = v.unsqueeze(-1) * v.unsqueeze(-2)
+    eye = torch.eye(3, dtype=quaternions.dtype, device=quaternions.device)
+    scal = (w * w - (v * v).sum(-1, keepdim=True)).unsqueeze(-1)
+    return 2 * (w.unsqueeze(-1) * skew(v) + outer) + scal * eye
+
+
+def yaw_to_rot_mat(yaw):
+    """(*) -> (*,3,3) rotation about the Y axis (reference: epropnp/common.py:45-64)."""
+    c, s = torch.cos(yaw), torch.sin(yaw)
+    o, i = torch.zeros_like(c), torch.ones_like(c)
+    return torch.stack((c, o, s, o, i, o, -s, o, c), dim=-1).reshape(yaw.shape + (3, 3))
+
+
+def pose_rotation(pose):
+    return yaw_to_rot_mat(pose[..., 3]) if pose.size(-1) == 4 else quaternion_to_rot_mat(pose[..., 3:])
+
+
+def evaluate_pnp(x3d, x2d, w2d, pose, camera, cost_fun, out_jacobian=False, out_residual=False, out_cost=False,
+                 **kwargs):
+    """Project, then apply the robust cost.  Each out_* is False (skip), True (return) or a tensor (filled).
+    Returns (residual (*,2n) | None, cost (*) | None, jacobian (*,2n,4|6) | None).
+    Reference: epropnp/common.py:67-100."""
+    jac_buf = out_jacobian
+    if isinstance(out_jacobian, torch.Tensor):
+        jac_buf = out_jacobian.view(x2d.shape[:-1] + (2, out_jacobian.size(-1)))
+    x2d_proj, jac_cam = camera.project(x3d, pose, out_jac=jac_buf, **kwargs)
+    return cost_fun.compute(x2d_proj, x2d, w2d, jac_cam=jac_cam, out_residual=out_residual, out_cost=out_cost,
+                            out_jacobian=out_jacobian)
+
+
+def pnp_normalize(x3d, pose=None, detach_transformation=True):
+    """Centre x3d on its mean; shift the pose translation accordingly.  -> offset (*,3), x3d_norm, pose_norm|None."""
+    offset = (x3d.detach() if detach_transformation else x3d).mean(dim=-2)
+    x3d_norm = x3d - offset.unsqueeze(-2)
+    if pose is None:
+        return offset, x3d_norm, None
+    shift = torch.matmul(pose_rotation(pose), offset.unsqueeze(-1)).squeeze(-1)
+    return offset, x3d_norm, torch.cat((pose[..., :3] + shift, pose[..., 3:]), dim=-1)
+
+
+def pnp_denormalize(offset, pose_norm):
+    shift = torch.matmul(pose_rotation(pose_norm), offset.unsqueeze(-1)).squeeze(-1)
+    return torch.cat((pose_norm[..., :3] - shift, pose_norm[..., 3:]), dim=-1)

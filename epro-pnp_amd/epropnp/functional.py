@@ -1,0 +1,174 @@
+"""Tensor-level wrappers over the C ABI (include/epropnp_hip.h) + the autograd node of the AMIS path.
+
+Everything here runs on the current HIP stream of the input tensors' device; nothing synchronises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name}: the HIP path computes in fp32, got {t.dtype}')
+    _hip.check_device(t, name)
+    return t.detach().contiguous()
+
+
+class PnPProblem:
+    """Contiguous fp32 device views of one batch of correspondences + camera + Huber threshold.
+
+    Built from the duck-typed `camera` / `cost_fun` objects of the reference API:
+    camera.cam_mats (*,3,3), camera.z_min, camera.lb / camera.ub (None | float | (*,2) tensor),
+    cost_fun.delta (float | (*,) tensor).
+    """
+
+    def __init__(self, x3d, x2d, w2d, camera, cost_fun, dof):
+        assert x3d.dim() == x2d.dim() == w2d.dim() == 3, 'x3d/x2d/w2d must be (num_obj, num_pts, C)'
+        B, N, _ = x2d.shape
+        self.B, self.N, self.dof = B, N, dof
+        self.pose_len = 7 if dof == 6 else 4
+        self.x3d, self.x2d, self.w2d = _f32c(x3d, 'x3d'), _f32c(x2d, 'x2d'), _f32c(w2d, 'w2d')
+        dev = self.x2d.device
+        self.device = dev
+        eps = getattr(cost_fun, 'eps', 1e-10)
+        if abs(eps - 1e-10) > 1e-16:
+            raise NotImplementedError('HuberPnPCost.eps other than 1e-10 is not supported by the HIP kernels')
+        cam = camera.cam_mats
+        self.cam = _f32c(cam.to(dev).expand(B, 3, 3), 'cam_mats')
+        self.z_min = float(camera.z_min)
+        lb, ub = camera.lb, camera.ub
+        if lb is not None and ub is not None:
+            self.lb = self._bound(lb, B, dev)
+            self.ub = self._bound(ub, B, dev)
+        else:
+            self.lb = self.ub = None
+        delta = cost_fun.delta
+        if not isinstance(delta, torch.Tensor):
+            delta = torch.full((B,), float(delta), dtype=torch.float32, device=dev)
+        self.delta = _f32c(delta.to(dev).expand(B) if delta.dim() <= 1 else delta.reshape(B), 'delta')
+        self.c = _hip.Problem(_hip.ptr(self.x3d), _hip.ptr(self.x2d), _hip.ptr(self.w2d), _hip.ptr(self.cam),
+                              _hip.ptr(self.lb), _hip.ptr(self.ub), _hip.ptr(self.delta), self.z_min, B, N, dof)
+        self.stream = _hip.stream_of(self.x2d)
+
+    @staticmethod
+    def _bound(v, B, dev):
+        if isinstance(v, torch.Tensor):
+            return _f32c(v.to(device=dev, dtype=torch.float32).expand(B, 2), 'bound')
+        return torch.full((B, 2), float(v), dtype=torch.float32, device=dev)
+
+    def new(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+
+def evaluate_cost(prob, poses):
+    """poses (P,B,pose_len) or (B,pose_len)  ->  Huber cost (P,B) / (B,)."""
+    squeeze = poses.dim() == 2
+    ps = _f32c(poses.unsqueeze(0) if squeeze else poses, 'poses')
+    P = ps.shape[0]
+    assert ps.shape[1:] == (prob.B, prob.pose_len), f'poses shape {tuple(poses.shape)}'
+    cost = prob.new(P, prob.B)
+    _hip.call('epropnp_evaluate_cost', C.byref(prob.c), _hip.ptr(ps), P, _hip.ptr(cost), prob.stream)
+    return cost[0] if squeeze else cost
+
+
+def normal_equations(prob, pose, clip_jac=True):
+    """pose (B,pose_len) -> JtJ (B,d,d), Jtr (B,d), cost (B,) of the Huber-rescaled residual/Jacobian."""
+    ps = _f32c(pose, 'pose')
+    d = prob.dof
+    jtj, jtr, cost = prob.new(prob.B, d, d), prob.new(prob.B, d), prob.new(prob.B)
+    _hip.call('epropnp_normal_equations', C.byref(prob.c), _hip.ptr(ps), int(bool(clip_jac)), _hip.ptr(jtj),
+              _hip.ptr(jtr), _hip.ptr(cost), prob.stream)
+    return jtj, jtr, cost
+
+
+def lm_solve(prob, pose_init, num_iter, fast_mode=False, with_pose_cov=False, with_cost=False, with_accepts=False,
+             min_lm_diagonal=1e-6, max_lm_diagonal=1e32, min_relative_decrease=1e-3,
+             initial_trust_region_radius=30.0, max_trust_region_radius=1e16, eps=1e-5):
+    ps = _f32c(pose_init, 'pose_init')
+    assert ps.shape == (prob.B, prob.pose_len)
+    d = prob.dof
+    pose_opt = prob.new(prob.B, prob.pose_len)
+    cov = prob.new(prob.B, d, d) if with_pose_cov else None
+    cost = prob.new(prob.B) if with_cost else None
+    acc = prob.new(prob.B, dtype=torch.int32) if with_accepts else None
+    par = _hip.LmParams(int(num_iter), int(bool(fast_mode)), min_lm_diagonal, max_lm_diagonal, min_relative_decrease,
+                        initial_trust_region_radius, max_trust_region_radius, eps)
+    _hip.call('epropnp_lm_solve', C.byref(prob.c), C.byref(par), _hip.ptr(ps), _hip.ptr(pose_opt), _hip.ptr(cov),
+              _hip.ptr(cost), _hip.ptr(acc), prob.stream)
+    if with_accepts:
+        return pose_opt, cov, cost, acc
+    return pose_opt, cov, cost
+
+
+def noise_stride(dof):
+    return _hip.lib().epropnp_noise_stride(dof)
+
+
+def amis_forward(prob, pose_opt, pose_cov, mc_samples, num_iter, eps=1e-5, acg_mle_iter=3, acg_dispersion=0.001,
+                 noise=None, seed=0, offset=0, with_proposals=False):
+    """-> pose_samples (S,B,pose_len), logweights (S,B) [, proposals (B,K,40)]."""
+    po, pc = _f32c(pose_opt, 'pose_opt'), _f32c(pose_cov, 'pose_cov')
+    S, B = int(mc_samples), prob.B
+    samples, logw = prob.new(S, B, prob.pose_len), prob.new(S, B)
+    props = prob.new(B, num_iter, 40) if with_proposals else None
+    nz = None
+    if noise is not None:
+        nz = _f32c(noise, 'noise')
+        assert nz.shape == (B, num_iter, S // num_iter, noise_stride(prob.dof)), f'noise shape {tuple(nz.shape)}'
+    par = _hip.AmisParams(S, int(num_iter), eps, int(acg_mle_iter), acg_dispersion, int(seed), int(offset))
+    _hip.call('epropnp_amis_forward', C.byref(prob.c), C.byref(par), _hip.ptr(po), _hip.ptr(pc), _hip.ptr(nz),
+              _hip.ptr(samples), _hip.ptr(logw), _hip.ptr(props), prob.stream)
+    return (samples, logw, props) if with_proposals else (samples, logw)
+
+
+def amis_backward(prob, pose_samples, grad_logweights, pose_init=None, grad_cost_init=None):
+    """-> grad_x3d (B,N,3), grad_x2d (B,N,2), grad_w2d (B,N,2), grad_delta (B,)."""
+    B, N = prob.B, prob.N
+    S = 0 if pose_samples is None else pose_samples.shape[0]
+    smp = None if S == 0 else _f32c(pose_samples, 'pose_samples')
+    glw = None if S == 0 else _f32c(grad_logweights, 'grad_logweights')
+    pin = gin = None
+    if pose_init is not None and grad_cost_init is not None:
+        pin, gin = _f32c(pose_init, 'pose_init'), _f32c(grad_cost_init, 'grad_cost_init')
+    gx3d, gx2d, gw2d, gdel = prob.new(B, N, 3), prob.new(B, N, 2), prob.new(B, N, 2), prob.new(B)
+    _hip.call('epropnp_amis_backward', C.byref(prob.c), _hip.ptr(smp), _hip.ptr(glw), S, _hip.ptr(pin), _hip.ptr(gin),
+              _hip.ptr(gx3d), _hip.ptr(gx2d), _hip.ptr(gw2d), _hip.ptr(gdel), prob.stream)
+    return gx3d, gx2d, gw2d, gdel
+
+
+class _MonteCarloCost(torch.autograd.Function):
+    """Differentiable part of monte_carlo_forward: (x3d, x2d, w2d, delta) -> (logweights, cost_init).
+
+    Forward runs the AMIS kernel (samples are drawn, never differentiated); backward recomputes the cost sweep
+    (nothing but the pose samples is kept alive, vs ~12 MB/object of autograd state in the reference).
+    """
+
+    @staticmethod
+    def forward(ctx, x3d, x2d, w2d, delta, prob, pose_opt, pose_cov, pose_init, cost_init_value, cfg):
+        samples, logw = amis_forward(prob, pose_opt, pose_cov, **cfg)
+        ctx.prob, ctx.pose_init = prob, pose_init
+        ctx.save_for_backward(samples)
+        ctx.mark_non_differentiable(samples)
+        ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
+        if cost_init_value is None:
+            return samples, logw
+        return samples, logw, cost_init_value.clone()
+
+    @staticmethod
+    def backward(ctx, _g_samples, g_logw, g_cost_init=None):
+        (samples,) = ctx.saved_tensors
+        prob = ctx.prob
+        if g_logw is None:
+            g_logw = torch.zeros(samples.shape[:2], dtype=torch.float32, device=samples.device)
+        gx3d, gx2d, gw2d, gdel = amis_backward(prob, samples, g_logw, ctx.pose_init, g_cost_init)
+        gdelta = None
+        if ctx.delta_shape is not None and ctx.needs_input_grad[3]:
+            gdelta = gdel.sum() if len(ctx.delta_shape) == 0 else gdel.reshape(ctx.delta_shape)
+        return (gx3d if ctx.needs_input_grad[0] else None, gx2d if ctx.needs_input_grad[1] else None,
+                gw2d if ctx.needs_input_grad[2] else None, gdelta, None, None, None, None, None, None)
+
+
+def monte_carlo_cost(x3d, x2d, w2d, delta, prob, pose_opt, pose_cov, pose_init, cost_init_value, cfg):
+    return _MonteCarloCost.apply(x3d, x2d, w2d, delta, prob, pose_opt, pose_cov, pose_init, cost_init_value, cfg)

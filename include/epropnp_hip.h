@@ -1,0 +1,123 @@
+/*
+ * epropnp_hip.h -- C ABI of libepropnp_hip.so, the MI355X (gfx950) implementation of the EPro-PnP hot path.
+ *
+ * The reference (tjiiv-cprg/EPro-PnP) has no FFI layer: its boundary is the Python class API of `epropnp/`.
+ * Each entry point below replaces a span of that Python code (cited per function, paths relative to the
+ * reference checkout); the Python classes in epro-pnp_amd/epropnp/ keep the reference's names/signatures and
+ * call these through ctypes (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (HBM), owned by the caller; outputs are caller-allocated;
+ *   - `stream` is a hipStream_t (passed as void*); the call enqueues work on it and returns without synchronising;
+ *   - return value: 0 on success, negative EPROPNP_E* code on error; epropnp_last_error() gives the message
+ *     (thread-local).  Nothing is ever computed on the host: without a HIP device the calls fail.
+ *   - dof is 6 (pose = [x,y,z, w,i,j,k], unit quaternion) or 4 (pose = [x,y,z, yaw], rotation about Y).
+ *   - B objects, N points per object; x3d (B,N,3), x2d (B,N,2), w2d (B,N,2).
+ */
+#ifndef EPROPNP_HIP_H
+#define EPROPNP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPROPNP_OK 0
+#define EPROPNP_EINVAL (-1)   /* bad argument (null pointer, unsupported dof, size limit)        */
+#define EPROPNP_ELAUNCH (-2)  /* HIP launch/runtime error                                         */
+#define EPROPNP_ENODEV (-3)   /* no HIP device / not a gfx950 code object                         */
+
+#define EPROPNP_ABI_VERSION 1
+
+/* Correspondences + camera + robust-cost parameters of one batch of objects.
+ * Mirrors the state of PerspectiveCamera (epropnp/camera.py:35-62) and HuberPnPCost.delta
+ * (epropnp/cost_fun.py:25-31,123-126) after the callers' set_param(). */
+typedef struct epropnp_problem {
+  const float* x3d;      /* (B,N,3) */
+  const float* x2d;      /* (B,N,2) */
+  const float* w2d;      /* (B,N,2) */
+  const float* cam_mats; /* (B,3,3) row-major */
+  const float* lb;       /* (B,2) lower bound [x,y] of the projection clamp, or NULL (camera.py:81-93)  */
+  const float* ub;       /* (B,2) upper bound, or NULL; the clamp is applied only if both are non-NULL  */
+  const float* delta;    /* (B,) Huber threshold per object                                             */
+  float z_min;           /* camera.py:16,28                                                             */
+  int32_t num_obj;       /* B */
+  int32_t num_pts;       /* N */
+  int32_t dof;           /* 6 or 4 */
+} epropnp_problem;
+
+/* Trust-region parameters of LMSolver.__init__ (epropnp/levenberg_marquardt.py:31-53). */
+typedef struct epropnp_lm_params {
+  int32_t num_iter;
+  int32_t fast_mode;                 /* 1: Gauss-Newton, no trust region, no clip_jac (:136-152) */
+  float min_lm_diagonal;
+  float max_lm_diagonal;
+  float min_relative_decrease;
+  float initial_trust_region_radius;
+  float max_trust_region_radius;
+  float eps;
+} epropnp_lm_params;
+
+/* AMIS parameters of EProPnPBase/EProPnP6DoF.__init__ (epropnp/epropnp.py:47-62,273-280). */
+typedef struct epropnp_amis_params {
+  int32_t mc_samples;     /* S, multiple of num_iter */
+  int32_t num_iter;       /* K                        */
+  float eps;              /* 1e-5                     */
+  int32_t acg_mle_iter;   /* 3     (6-DoF only)       */
+  float acg_dispersion;   /* 0.001 (6-DoF only)       */
+  uint64_t seed;          /* Philox key when `noise` is NULL */
+  uint64_t offset;        /* Philox counter offset (advance by 1 per call for fresh draws) */
+} epropnp_amis_params;
+
+int epropnp_abi_version(void);
+const char* epropnp_last_error(void);
+
+/* Floats per (iteration, sample, object) of an injected-noise buffer for the given dof (8 for 6-DoF:
+ * [z0,z1,z2, chi2, g0..g3]; 4 + 3*16 for 4-DoF: [z0,z1,z2, chi2, u | 16x(u1,u2,u3)]). */
+int epropnp_noise_stride(int dof);
+
+/* evaluate_pnp(..., out_cost=True) for P poses per object: the cost-only path
+ * epropnp/common.py:67-100 -> camera.py:21-30,81-93 (project_b + clamp) -> cost_fun.py:45-61 (Huber).
+ *   poses (P,B,pose_len)  ->  cost (P,B) */
+int epropnp_evaluate_cost(const epropnp_problem* prob, const float* poses, int32_t num_poses, float* cost,
+                          void* stream);
+
+/* evaluate_pnp(..., out_jacobian, out_residual, out_cost) fused with the normal equations the LM solver forms
+ * from them: common.py:67-100 -> camera.py:10-18,81-143 (project_a, Jacobian, clip_jac) -> cost_fun.py:63-84
+ * (robust rescaling) -> levenberg_marquardt.py:205-214 (JtJ, Jtr).  The (B,2N,dof) Jacobian is never written.
+ *   pose (B,pose_len) -> jtj (B,dof,dof), jtr (B,dof), cost (B,) */
+int epropnp_normal_equations(const epropnp_problem* prob, const float* pose, int32_t clip_jac, float* jtj,
+                             float* jtr, float* cost, void* stream);
+
+/* LMSolver.solve with a given starting pose (epropnp/levenberg_marquardt.py:132-190, _lm_iter :192-241,
+ * pose_add :255-265): the whole iteration runs inside one kernel, points stay in registers.
+ *   pose_init (B,pose_len) -> pose_opt (B,pose_len); pose_cov (B,dof,dof) or NULL; cost (B,) or NULL;
+ *   accept_mask (B,) int32 or NULL: bit i = step i accepted (diagnostics for the trust-region flip rate). */
+int epropnp_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init,
+                     float* pose_opt, float* pose_cov, float* cost, int32_t* accept_mask, void* stream);
+
+/* The AMIS loop of EProPnPBase.monte_carlo_forward (epropnp/epropnp.py:132-182) including initial_fit,
+ * gen_new_distr/gen_old_distr, estimate_params (:199-342), the proposal densities (epropnp/distributions.py,
+ * pyro MultivariateStudentT) and the weight algebra (:156-169).
+ *   pose_opt (B,pose_len), pose_cov (B,dof,dof) from the solver
+ *   noise: NULL (on-device Philox) or (B,K,S/K,epropnp_noise_stride(dof)) injected base draws
+ *   -> pose_samples (S,B,pose_len), logweights (S,B)
+ *   -> proposals (optional, may be NULL): (B,K,40) fitted proposal parameters, for diagnostics/tests. */
+int epropnp_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
+                         const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
+                         float* proposals, void* stream);
+
+/* Backward of  sum_b [ g_init[b]*cost(pose_init[b]) + sum_j g_logw[j,b]*logw[j,b] ]  w.r.t. x3d, x2d, w2d, delta:
+ * what autograd replays through evaluate_pnp in the reference, recomputed
+ * from the points instead of stored activations.  logw = -cost - const  =>  weight of sample j is -g_logw[j,b].
+ *   pose_samples (S,B,pose_len), grad_logweights (S,B), pose_init (B,pose_len) or NULL, grad_cost_init (B,) or NULL
+ *   -> grad_x3d (B,N,3), grad_x2d (B,N,2), grad_w2d (B,N,2), grad_delta (B,) */
+int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                          int32_t mc_samples, const float* pose_init, const float* grad_cost_init,
+                          float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPROPNP_HIP_H */

@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 'epro-pnp_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests'), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver with -m gpu)')
+
+
+_EMU_LIB = None
+
+
+def _emu_lib():
+    """Build (once) the CPU logic-emulation of the kernel sources; test infrastructure only."""
+    global _EMU_LIB
+    if _EMU_LIB is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('epropnp_build', os.path.join(ROOT, 'epro-pnp_amd', 'build.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _EMU_LIB = mod.build(emu=True)
+    return _EMU_LIB
+
+
+@pytest.fixture(params=['emu', pytest.param('hip', marks=pytest.mark.gpu)])
+def backend(request):
+    """'hip': the real library on cuda:0.  'emu': the same kernel sources compiled for the CPU fiber emulator
+    (tests/emu) -- exercises kernel logic + host glue where no GPU exists; never a product path."""
+    from epropnp import _hip
+    if request.param == 'hip':
+        assert torch.cuda.is_available(), 'gpu test selected but no HIP device is visible'
+        _hip._use_emulation_library(None)
+        yield torch.device('cuda:0')
+    else:
+        _hip._use_emulation_library(_emu_lib())
+        yield torch.device('cpu')
+        _hip._use_emulation_library(None)

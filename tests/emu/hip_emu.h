@@ -1,0 +1,198 @@
+// tests/emu/hip_emu.h -- TEST INFRASTRUCTURE ONLY (never part of the product build).
+//
+// A tiny single-OS-thread emulation of the HIP execution model, used to run the kernel sources of
+// epro-pnp_amd/csrc on the CPU of the build container (which has no GPU) so that kernel LOGIC can be
+// debugged and regression-tested under `pytest -m "not gpu"`.  Every GPU thread of a workgroup is a
+// ucontext fiber; __syncthreads() and the wave-level exchange primitives are cooperative yields, so
+// execution is deterministic and race-free.  Workgroups run one after another.
+//
+// The product library (libepropnp_hip.so) is compiled by hipcc from the same sources WITHOUT this header;
+// the Python package never loads the emulation build (tests load it explicitly through ctypes).
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define EPROPNP_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+
+namespace emu {
+
+struct Idx3 {
+  unsigned x, y, z;
+};
+
+struct Fiber {
+  ucontext_t ctx;
+  bool done;
+  Idx3 tid;
+};
+
+struct Block {
+  std::vector<Fiber> fibers;
+  std::vector<char> stacks;
+  int cur = 0, alive = 0, bar_count = 0, bar_gen = 0;
+  std::vector<int> w_alive, w_count, w_gen;
+  std::vector<std::array<uint64_t, 64>> w_buf;
+  Idx3 bid{0, 0, 0};
+  dim3 bdim, gdim;
+  ucontext_t sched;
+  std::function<void()> body;
+  std::vector<char> dyn_smem;
+};
+
+inline Block& blk() {
+  static Block b;
+  return b;
+}
+
+constexpr size_t kStack = 512 * 1024;
+
+inline void yield() {
+  Block& b = blk();
+  swapcontext(&b.fibers[b.cur].ctx, &b.sched);
+}
+
+inline void trampoline() {
+  Block& b = blk();
+  b.body();
+  Fiber& f = b.fibers[b.cur];
+  f.done = true;
+  b.alive--;
+  b.w_alive[f.tid.x / 64]--;
+  swapcontext(&f.ctx, &b.sched);
+}
+
+inline void syncthreads() {
+  Block& b = blk();
+  int gen = b.bar_gen;
+  b.bar_count++;
+  while (b.bar_gen == gen) {
+    if (b.bar_count >= b.alive) {
+      b.bar_count = 0;
+      b.bar_gen++;
+      break;
+    }
+    yield();
+  }
+}
+
+inline void wave_sync() {
+  Block& b = blk();
+  int w = b.fibers[b.cur].tid.x / 64;
+  int gen = b.w_gen[w];
+  b.w_count[w]++;
+  while (b.w_gen[w] == gen) {
+    if (b.w_count[w] >= b.w_alive[w]) {
+      b.w_count[w] = 0;
+      b.w_gen[w]++;
+      break;
+    }
+    yield();
+  }
+}
+
+template <class T>
+inline T shfl(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shfl payload");
+  Block& b = blk();
+  unsigned t = b.fibers[b.cur].tid.x;
+  int w = t / 64, lane = t % 64;
+  uint64_t bits = 0;
+  std::memcpy(&bits, &v, sizeof(T));
+  b.w_buf[w][lane] = bits;
+  wave_sync();
+  T r;
+  uint64_t got = b.w_buf[w][src & 63];
+  std::memcpy(&r, &got, sizeof(T));
+  wave_sync();
+  return r;
+}
+
+inline void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
+  Block& b = blk();
+  unsigned nthreads = block.x * block.y * block.z;
+  if (block.y != 1 || block.z != 1 || nthreads % 64 != 0) {
+    std::fprintf(stderr, "emu: only 1-D blocks that are multiples of 64 are supported\n");
+    std::abort();
+  }
+  unsigned nw = nthreads / 64;
+  b.bdim = block;
+  b.gdim = grid;
+  b.body = std::move(body);
+  b.dyn_smem.assign(smem + 64, 0);
+  if (b.stacks.size() < nthreads * kStack) b.stacks.resize(nthreads * kStack);
+  b.fibers.resize(nthreads);
+  for (unsigned gz = 0; gz < grid.z; ++gz)
+    for (unsigned gy = 0; gy < grid.y; ++gy)
+      for (unsigned gx = 0; gx < grid.x; ++gx) {
+        b.bid = Idx3{gx, gy, gz};
+        b.alive = (int)nthreads;
+        b.bar_count = 0;
+        b.w_alive.assign(nw, 64);
+        b.w_count.assign(nw, 0);
+        b.w_gen.assign(nw, 0);
+        b.w_buf.assign(nw, std::array<uint64_t, 64>{});
+        for (unsigned t = 0; t < nthreads; ++t) {
+          Fiber& f = b.fibers[t];
+          f.done = false;
+          f.tid = Idx3{t, 0, 0};
+          getcontext(&f.ctx);
+          f.ctx.uc_stack.ss_sp = b.stacks.data() + (size_t)t * kStack;
+          f.ctx.uc_stack.ss_size = kStack;
+          f.ctx.uc_link = nullptr;
+          makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        while (b.alive > 0) {
+          for (unsigned t = 0; t < nthreads; ++t) {
+            if (b.fibers[t].done) continue;
+            b.cur = (int)t;
+            swapcontext(&b.sched, &b.fibers[t].ctx);
+          }
+        }
+      }
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::blk().fibers[emu::blk().cur].tid)
+#define blockIdx (emu::blk().bid)
+#define blockDim (emu::blk().bdim)
+#define gridDim (emu::blk().gdim)
+inline void __syncthreads() { emu::syncthreads(); }
+
+#define PNP_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define PNP_DYN_SMEM(type, name) \
+  type* name = reinterpret_cast<type*>((reinterpret_cast<uintptr_t>(emu::blk().dyn_smem.data()) + 15) & ~uintptr_t(15))
+
+using std::max;
+using std::min;
+struct float2 {
+  float x, y;
+};
+inline float2 make_float2(float x, float y) { return float2{x, y}; }

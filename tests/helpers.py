@@ -1,0 +1,55 @@
+"""Shared test helpers: golden fixtures, oracle <-> kernel noise layout, problem construction."""
+import os
+
+import numpy as np
+import torch
+
+import epropnp_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    out = {}
+    for k in z.files:
+        v = torch.from_numpy(z[k]) if z[k].ndim > 0 else z[k].item()
+        if '.' in k:
+            a, b = k.split('.', 1)
+            out.setdefault(a, {})[b] = v
+        else:
+            out[k] = v
+    return out
+
+
+def pack_noise(noise, dof):
+    """oracle noise dict ((K,s,B,.) tensors) -> kernel layout (B,K,s,stride)."""
+    z, chi2 = noise['z'], noise['chi2']
+    K, s, B, _ = z.shape
+    if dof == 6:
+        flat = torch.cat((z, chi2.unsqueeze(-1), noise['g']), -1)                    # (K,s,B,8)
+    else:
+        T = orc.VM_MAX_TRIES
+        tail = torch.zeros(K, s, B, 3 * T, dtype=z.dtype)
+        n_u = noise['u'].shape[1]
+        tail[:, :n_u, :, 0] = noise['u'][..., 0]
+        tail[:, n_u:] = noise['vm'].reshape(K, s - n_u, B, 3 * T)
+        flat = torch.cat((z, chi2.unsqueeze(-1), tail), -1)
+    return flat.permute(2, 0, 1, 3).contiguous().float()
+
+
+def to_dev(d, device):
+    return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+def make_layer_objects(prob, device, relative_delta=None):
+    """reference-API camera / cost_fun objects for a problem dict (from a fixture or orc.make_problem)."""
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost, HuberPnPCost
+    p = to_dev(prob, device)
+    cam = PerspectiveCamera(cam_mats=p['cam_mats'], z_min=0.1, lb=p.get('lb'), ub=p.get('ub'))
+    if relative_delta is None:
+        cf = HuberPnPCost(delta=p['delta'])
+    else:
+        cf = AdaptiveHuberPnPCost(relative_delta=relative_delta)
+    return p, cam, cf
