@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py -- EPro-PnP hot path throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic objects:
+    cost(pose_init) -> fused LM solve (1+L sweeps) -> fused AMIS sampler (S pose evaluations) -> Monte-Carlo pose
+    loss -> backward to d/dx3d, d/dx2d, d/dw2d (one recompute kernel + autograd through set_param / the loss).
+Workload (BASELINE.json configs[1], "C2"): B=4096 objects x N=512 points, S=512 samples, K=4 AMIS iterations,
+L=3 LM iterations, 6-DoF, fp32, inputs resident in HBM before the timed region.  Objects shard over ranks with no
+data-path collective (every rank owns B objects: weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the Jacobian sweep of the fused LM kernel (HBM-bound by
+construction, SURVEY.md 8d: 28 B/point per logical sweep); `roofline_valu` reports the VALU-bound AMIS kernels
+against the fp32 vector peak.  `cpu_baseline` is the oracle (a PyTorch-CPU restatement with the reference's op
+structure, pinned to the reference) timed on a bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'epro-pnp_amd'))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VECTOR_PEAK_TF = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def synth_problem(B, N, device, seed, dof=6):
+    """SURVEY.md 8(d) generator, on `device`: x3d ~ N(0,0.5^2); gt t ~ N(0,I), t_z += 5; q ~ normalised N(0,I4);
+    K = [[800,0,320],[0,800,240],[0,0,1]]; x2d = project(gt) + N(0,1 px); w2d = softmax_N(U(0,1)) * 2;
+    pose_init = gt perturbed (t += 0.1 N, q = normalize(q + 0.05 N))."""
+    from epropnp.camera import project_b
+    g = torch.Generator(device=device).manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g, device=device)
+    x3d = rn(B, N, 3) * 0.5
+    t = rn(B, 3)
+    t[:, 2] += 5 if dof == 6 else 10
+    if dof == 6:
+        q = torch.nn.functional.normalize(rn(B, 4), dim=-1)
+        pose_gt = torch.cat((t, q), -1)
+    else:
+        pose_gt = torch.cat((t, rn(B, 1)), -1)
+    K = torch.tensor([[800., 0, 320], [0, 800., 240], [0, 0, 1]], device=device).expand(B, 3, 3)
+    x2d = project_b(x3d, pose_gt, K, 0.1)[0] + rn(B, N, 2)
+    w2d = torch.softmax(torch.rand(B, N, 2, generator=g, device=device), dim=1) * 2.0
+    if dof == 6:
+        qi = torch.nn.functional.normalize(pose_gt[:, 3:] + 0.05 * rn(B, 4), dim=-1)
+        pose_init = torch.cat((pose_gt[:, :3] + 0.1 * rn(B, 3), qi), -1)
+    else:
+        pose_init = torch.cat((pose_gt[:, :3] + 0.1 * rn(B, 3), pose_gt[:, 3:] + 0.05 * rn(B, 1)), -1)
+    return dict(x3d=x3d.contiguous(), x2d=x2d.contiguous(), w2d=w2d.contiguous(), cam_mats=K, pose_init=pose_init)
+
+
+class KernelTimer:
+    """HIP events (on the stream the kernels are launched on = torch's current stream) around one entry point of the
+    C ABI; sums the per-launch durations inside the timed region."""
+
+    def __init__(self, module, name):
+        self.module, self.name, self.orig = module, name, getattr(module, name)
+        self.events, self.enabled = [], False
+        timer = self
+
+        def wrapped(*a, **k):
+            if not timer.enabled:
+                return timer.orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = timer.orig(*a, **k)
+            e1.record()
+            timer.events.append((e0, e1))
+            return out
+        setattr(module, name, wrapped)
+
+    def mean_ms(self):
+        if not self.events:
+            return float('nan')
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+
+def cpu_baseline(N, S, K, L, sample_objects, budget_s=25.0):
+    """The oracle (oracle/epropnp_oracle.py) timed on the host cores on `sample_objects` objects of the same
+    workload: monte_carlo_forward + MC loss + backward.  Test/baseline infrastructure -- never the product path."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import epropnp_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    prob = synth_problem(sample_objects, N, torch.device('cpu'), seed=0)
+    noise = orc.make_noise(sample_objects, S, K, 6, seed=1)
+    times = []
+    t_start = time.perf_counter()
+    for it in range(4):
+        t0 = time.perf_counter()
+        orc.run_mc(prob, noise, 6, S, K, L)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return dict(value=round(sample_objects / best, 2), unit='instances/s', cores=cores, kind='port',
+                sample=f'{sample_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd), best of {max(1, len(times) - 1)} '
+                       f'after 1 warm-up, torch-CPU {torch.get_num_threads()} threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--objects', type=int, default=4096, help='objects per GPU')
+    ap.add_argument('--points', type=int, default=512)
+    ap.add_argument('--samples', type=int, default=512)
+    ap.add_argument('--amis-iters', type=int, default=4)
+    ap.add_argument('--lm-iters', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=96)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus or world == 1 and args.gpus == 1, f'WORLD_SIZE={world} but --gpus {args.gpus}'
+
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    from epropnp.epropnp import EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver
+
+    B, N, S, K, L = args.objects, args.points, args.samples, args.amis_iters, args.lm_iters
+    prob = synth_problem(B, N, dev, seed=1000 + rank)      # every rank owns its own shard of objects
+    x3d, x2d, w2d = (prob[k].requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+    camera = PerspectiveCamera(cam_mats=prob['cam_mats'], z_min=0.1)
+    cost_fun = AdaptiveHuberPnPCost(relative_delta=0.5)
+    layer = EProPnP6DoF(mc_samples=S, num_iter=K, solver=LMSolver(dof=6, num_iter=L), seed=1 + rank)
+
+    timers = {n: KernelTimer(F, n) for n in ('lm_solve', 'amis_forward', 'amis_backward', 'evaluate_cost')}
+
+    def step():
+        for t in (x3d, x2d, w2d):
+            t.grad = None
+        cost_fun.set_param(x2d.detach(), w2d)
+        _, _, _, _, logw, cost_init = layer.monte_carlo_forward(x3d, x2d, w2d, camera, cost_fun,
+                                                                pose_init=prob['pose_init'], force_init_solve=False)
+        loss = (cost_init + torch.logsumexp(logw, dim=0)).mean()       # Monte-Carlo pose (KL) loss
+        loss.backward()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    for t in timers.values():
+        t.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    loss_val = float(loss)
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        t_lm = timers['lm_solve'].mean_ms()
+        t_fw = timers['amis_forward'].mean_ms()
+        t_bw = timers['amis_backward'].mean_ms()
+        t_ci = timers['evaluate_cost'].mean_ms()
+        sweeps = 1 + L
+        lm_bytes = sweeps * 28.0 * B * N + B * 4.0 * (7 + 9 + 1) + B * 4.0 * (7 + 36 + 1)
+        lm_gbs = lm_bytes / (t_lm * 1e-3) / 1e9
+        fw_tf = 40.0 * S * N * B / (t_fw * 1e-3) / 1e12
+        bw_tf = 80.0 * (S + 1) * N * B / (t_bw * 1e-3) / 1e12
+        out = {
+            'metric': 'PnP instances/sec (fwd+bwd, N=512 pts, 512 samples)',
+            'value': round(value, 1), 'unit': 'instances/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'C2 batched synthetic: {B} objects/GPU x N={N} points, S={S} MC samples, '
+                                   f'K={K} AMIS iters, L={L} LM iters, EProPnP6DoF fwd+bwd',
+                       'objects_per_gpu': B, 'num_points': N, 'mc_samples': S, 'amis_iters': K, 'lm_iters': L,
+                       'dof': 6, 'parallelism': f'objects sharded x{world}, no data-path collective'},
+            'roofline': {'kernel': 'lm_solve_kernel (Jacobian sweep, fused 1+L sweeps)', 'bound': 'hbm',
+                         'achieved': round(lm_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(lm_gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'algorithmic_bytes_per_launch': lm_bytes, 'logical_sweeps': sweeps,
+                         'launch_ms': round(t_lm, 4)},
+            'roofline_valu': {
+                'amis_forward_kernel': {'bound': 'valu_fp32', 'achieved': round(fw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
+                                        'unit': 'TFLOP/s', 'frac': round(fw_tf / FP32_VECTOR_PEAK_TF, 4),
+                                        'flops_per_point_pose': 40, 'launch_ms': round(t_fw, 4)},
+                'amis_backward_kernel': {'bound': 'valu_fp32', 'achieved': round(bw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
+                                         'unit': 'TFLOP/s', 'frac': round(bw_tf / FP32_VECTOR_PEAK_TF, 4),
+                                         'flops_per_point_pose': 80, 'launch_ms': round(t_bw, 4)}},
+            'kernel_ms': {'evaluate_cost': round(t_ci, 4), 'lm_solve': round(t_lm, 4), 'amis_forward': round(t_fw, 4),
+                          'amis_backward': round(t_bw, 4)},
+            'loss': round(loss_val, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(N, S, K, L, args.cpu_sample)
+            out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

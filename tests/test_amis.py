@@ -1,0 +1,151 @@
+"""AMIS sampler (forward + backward kernels) vs the reference fixtures and the restatement, with injected noise."""
+import pytest
+import torch
+
+import epropnp_oracle as orc
+from helpers import load_golden, make_layer_objects, pack_noise
+
+KL_TOL = 1e-3       # north-star tolerance on the Monte-Carlo (KL) loss
+
+
+def _layer(dof, S, K, lm_iter, normalize=False, rslm=None):
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+    init = RSLMSolver(dof=dof, **rslm) if rslm else None
+    cls = EProPnP6DoF if dof == 6 else EProPnP4DoF
+    return cls(mc_samples=S, num_iter=K, normalize=normalize, solver=LMSolver(dof=dof, num_iter=lm_iter, init_solver=init))
+
+
+def run_layer(backend, prob, noise, dof, S, K, lm_iter, normalize=False, relative_delta=0.5):
+    """monte_carlo_forward + MC loss + backward through the product API; same contract as orc.run_mc."""
+    p, cam, cf = make_layer_objects(prob, backend, relative_delta=relative_delta)
+    x3d, x2d, w2d = (p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+    cf.set_param(x2d.detach(), w2d)
+    layer = _layer(dof, S, K, lm_iter, normalize)
+    out = layer.monte_carlo_forward(x3d, x2d, w2d, cam, cf, pose_init=p['pose_init'], force_init_solve=False,
+                                    with_cost=True, noise=pack_noise(noise, dof).to(backend))
+    pose_opt, cost, _, samples, logw, cost_init = out
+    loss_obj = cost_init + torch.logsumexp(logw, dim=0)
+    loss_obj.mean().backward()
+    res = dict(pose_opt=pose_opt, cost=cost, pose_samples=samples, logweights=logw, cost_init=cost_init,
+               loss_obj=loss_obj, gx3d=x3d.grad, gx2d=x2d.grad, gw2d=w2d.grad)
+    return {k: v.detach().cpu() for k, v in res.items()}
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-12)).item()
+
+
+@pytest.mark.parametrize('name', ['mc6', 'mc6_n100', 'mc4', 'mc4_norm'])
+def test_monte_carlo_forward_backward_matches_reference(backend, name):
+    g = load_golden(name)
+    dof, S, K = int(g['dof']), int(g['S']), int(g['K'])
+    r = run_layer(backend, g['prob'], g['noise'], dof, S, K, int(g['lm_iter']), normalize=bool(g['normalize']))
+    ref, o64 = g['ref'], g['o64']
+    # how far the reference's own fp32 arithmetic is from fp64 on this input (the AMIS proposal fit inverts
+    # 4x4 matrices of condition ~1e5 in fp32): a second correct implementation cannot be closer than that
+    drift = (ref['loss_obj'] - o64['loss_obj']).abs().max().item()
+    assert (r['pose_opt'] - ref['pose_opt']).abs().max().item() <= 1e-4 + 2 * (ref['pose_opt'] - o64['pose_opt']).abs().max().item()
+    torch.testing.assert_close(r['cost_init'], ref['cost_init'], rtol=2e-5, atol=1e-5)
+    # KL / Monte-Carlo loss: per object and batch mean
+    assert (r['loss_obj'] - ref['loss_obj']).abs().max().item() <= KL_TOL + 2 * drift
+    assert abs(r['loss_obj'].mean().item() - ref['loss_obj'].mean().item()) <= KL_TOL
+    assert (r['loss_obj'] - o64['loss_obj']).abs().max().item() <= KL_TOL + 2 * drift
+    # gradients of the loss (dominated by the highest-weight samples)
+    gdrift = {k: _rel(ref[k], o64[k]) for k in ('gx3d', 'gx2d', 'gw2d')}
+    for k in ('gx3d', 'gx2d', 'gw2d'):
+        assert _rel(r[k], ref[k]) <= 5e-3 + 3 * gdrift[k], (k, _rel(r[k], ref[k]), gdrift[k])
+    assert (r['pose_samples'] - ref['pose_samples']).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize('dof', [6, 4])
+def test_logweights_consistent_with_own_samples(backend, dof):
+    """Tight check that does not depend on the (ill-conditioned) proposal fit: recompute cost and proposal mixture
+    density with the oracle AT THE KERNEL'S OWN samples and fitted proposals; log-weights must agree to 1e-4."""
+    from epropnp import functional as F
+    B, N, S, K = 3, 96, 64, 4
+    prob = orc.make_problem(B, N, dof, seed=7)
+    noise = orc.make_noise(B, S, K, dof, seed=8)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
+    samples, logw, props = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=pack_noise(noise, dof).to(backend),
+                                          with_proposals=True)
+    samples, logw, props = samples.cpu(), logw.cpu(), props.cpu()
+    ocam = orc.Cam(prob['cam_mats'], 0.1)
+    cost = orc.evaluate(prob['x3d'], prob['x2d'], prob['w2d'], samples, ocam, prob['delta'], want_cost=True)[1]
+    s = S // K
+
+    def tril(v, n):
+        L = torch.zeros(v.shape[:-1] + (n, n))
+        idx = torch.tril_indices(n, n)
+        L[..., idx[0], idx[1]] = v
+        return L
+    lq = []
+    for j in range(K):
+        rec = props[:, j]
+        lp = orc.student_t_logprob(samples[..., :3], rec[:, 0:3], tril(rec[:, 3:9], 3))
+        if dof == 6:
+            lp = lp + orc.acg_logprob(samples[..., 3:], tril(rec[:, 16:26], 4))
+        else:
+            lp = lp + orc.vm_mix_logprob(samples[..., 3:], rec[:, 16:17], rec[:, 17:18]).squeeze(-1)
+        lq.append(lp)
+    mix = torch.logsumexp(torch.stack(lq, 0), 0) - torch.log(torch.tensor(float(K)))
+    expect = -cost - mix
+    assert (logw - expect).abs().max().item() <= 2e-4 * max(1.0, expect.abs().max().item())
+
+
+def test_backward_matches_autograd_of_oracle_at_fixed_samples(backend):
+    """The backward kernel alone: arbitrary upstream gradients, samples fixed -> compare with autograd through the
+    oracle's evaluate (which is what the reference's autograd replays)."""
+    from epropnp import functional as F
+    for dof, bounds in ((6, None), (4, 'tight'), (6, 'tight')):
+        B, N, S = 3, 150, 40
+        prob = orc.make_problem(B, N, dof, seed=11, bounds=bounds)
+        g = torch.Generator().manual_seed(5)
+        poses = prob['pose_gt'].unsqueeze(0).repeat(S, 1, 1)
+        poses[..., :3] += 0.2 * torch.randn(S, B, 3, generator=g)
+        if dof == 6:
+            q = poses[..., 3:] + 0.1 * torch.randn(S, B, 4, generator=g)
+            poses[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+        else:
+            poses[..., 3] += 0.3 * torch.randn(S, B, generator=g)
+        poses[0, 0, 2] = -1.0                     # behind the camera: z clamp active
+        g_logw = torch.randn(S, B, generator=g)
+        g_logw[3] = 0.0                           # exact zeros are skipped by the kernel
+        g_init = torch.randn(B, generator=g)
+        x3d, x2d, w2d, delta = (prob[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta'))
+        ocam = orc.Cam(prob['cam_mats'], 0.1, prob.get('lb'), prob.get('ub'))
+        c_s = orc.evaluate(x3d, x2d, w2d, poses, ocam, delta, want_cost=True)[1]
+        c_i = orc.evaluate(x3d, x2d, w2d, prob['pose_init'], ocam, delta, want_cost=True)[1]
+        ((-c_s) * g_logw).sum().add((c_i * g_init).sum()).backward()
+
+        p, cam, cf = make_layer_objects(prob, backend)
+        hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+        gx3d, gx2d, gw2d, gdel = F.amis_backward(hp, poses.to(backend), g_logw.to(backend), p['pose_init'],
+                                                 g_init.to(backend))
+        for mine, ref in ((gx3d, x3d.grad), (gx2d, x2d.grad), (gw2d, w2d.grad), (gdel, delta.grad)):
+            assert _rel(mine.cpu(), ref) <= 2e-4, (dof, bounds, _rel(mine.cpu(), ref))
+
+
+def test_philox_sampler_statistics(backend):
+    """Production mode (on-device Philox): loss agrees with the injected-noise oracle within Monte-Carlo error,
+    and two calls draw different samples."""
+    B, N, S, K, dof = 6, 64, 256, 4, 6
+    prob = orc.make_problem(B, N, dof, seed=21)
+    p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
+    cf.set_param(p['x2d'], p['w2d'])
+    layer = _layer(dof, S, K, 3)
+    layer.seed = 1234
+    outs = [layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'],
+                                      force_init_solve=False) for _ in range(2)]
+    assert (outs[0][3] - outs[1][3]).abs().max() > 1e-3          # fresh draws per call
+    q = outs[0][3][..., 3:]
+    assert (q.norm(dim=-1) - 1).abs().max() < 1e-5
+    lse = torch.stack([torch.logsumexp(o[4], 0) for o in outs]).cpu()
+    noise = orc.make_noise(B, S, K, dof, seed=3)
+    o = orc.run_mc(prob, noise, dof, S, K, 3)
+    ref_lse = o['loss_obj'] - o['cost_init']
+    # seed-to-seed std of the per-object estimate is ~0.05-0.1 at S=256
+    assert (lse - ref_lse).abs().max().item() < 0.6
+    assert (lse.mean(1) - ref_lse.mean()).abs().max().item() < 0.25
