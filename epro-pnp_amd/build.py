@@ -33,7 +33,7 @@ def _run(cmd):
     return r.stdout + r.stderr
 
 
-def build(emu=False, force=False, verbose=False):
+def build(emu=False, force=False, verbose=False, defines=(), tag=None):
     deps_common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, 'include', 'epropnp_hip.h')]
     if emu:
         out_dir = os.path.join(ROOT, 'tests', 'emu', '_build')
@@ -43,10 +43,11 @@ def build(emu=False, force=False, verbose=False):
         cc = ['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-x', 'c++', '-include', shim, '-Wno-unknown-pragmas',
               '-Wno-attributes']
     else:
-        out_dir = os.path.join(HERE, 'lib')
+        out_dir = os.path.join(HERE, 'lib') if not tag else os.path.join(HERE, 'lib', 'variants', tag)
         lib = os.path.join(out_dir, 'libepropnp_hip.so')
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
         cc = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value']
+        cc += ['-D' + d for d in defines]
     os.makedirs(out_dir, exist_ok=True)
     objs, jobs = [], []
     for src in SOURCES:
@@ -71,5 +72,7 @@ if __name__ == '__main__':
     ap.add_argument('--emu', action='store_true')
     ap.add_argument('--force', action='store_true')
     ap.add_argument('-v', '--verbose', action='store_true')
+    ap.add_argument('-D', dest='defines', action='append', default=[], help='extra -D for a tuning variant')
+    ap.add_argument('--tag', default=None, help='build into lib/variants/<tag>/ (tuning variants)')
     a = ap.parse_args()
-    print(build(a.emu, a.force, a.verbose))
+    print(build(a.emu, a.force, a.verbose, a.defines, a.tag))

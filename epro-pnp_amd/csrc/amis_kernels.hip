@@ -17,6 +17,14 @@
 
 namespace pnp {
 
+// minimum waves per SIMD requested from the register allocator for the <= 256-thread instantiations
+#ifndef PNP_FWD_OCC
+#define PNP_FWD_OCC 3
+#endif
+#ifndef PNP_BWD_OCC
+#define PNP_BWD_OCC 4
+#endif
+
 constexpr int kPropStride = 40;   // floats per fitted proposal (layout below)
 // proposal record:  [0..2] t-mode | [3..8] L_t (lower, row-major packed) | [9..14] L_t^-1 | [15] Student-t log-norm
 //   6-DoF: [16..25] L_r (lower 4x4 packed) | [26..35] L_r^-1 | [36] sum log diag L_r
@@ -32,13 +40,19 @@ struct AmisParams {
   unsigned long long seed, offset;
 };
 
+// The fp64 proposal fits run on one lane a handful of times per object; keeping them out of line stops their
+// ~100 live fp64 registers from inflating the allocation of the VALU-bound sweep loops (occupancy).
+#ifndef PNP_FIT_FN
+#define PNP_FIT_FN __device__ __forceinline__
+#endif
+
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
 // ---- proposal fitting helpers (run by thread 0 only; fp64 so that the ill-conditioned 4x4 inversions of the
 // ---- reference's fp32 LAPACK path are at least not made worse) ----------------------------------------------
 
 // pack Cholesky factor / its inverse / log-normaliser of a 3x3 translation covariance into rec[3..15]
-PNP_FN void fit_translation(double (&C)[3][3], const float* fallback_diag, float* rec) {
+PNP_FIT_FN void fit_translation(double (&C)[3][3], const float* fallback_diag, float* rec) {
   const bool ok = cholesky<3, double>(C);
   if (!ok) {
 #pragma unroll
@@ -62,7 +76,7 @@ PNP_FN void fit_translation(double (&C)[3][3], const float* fallback_diag, float
 }
 
 // rot_cov (4x4 SPD, trace ~ 1) -> + det^(1/4) * dispersion * I -> Cholesky -> rec[16..36]   (epropnp.py:301-302,341-342)
-PNP_FN void fit_rotation_acg(double (&Rc)[4][4], float dispersion, float* rec) {
+PNP_FIT_FN void fit_rotation_acg(double (&Rc)[4][4], float dispersion, float* rec) {
   double Lc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -101,7 +115,7 @@ PNP_FN void fit_rotation_acg(double (&Rc)[4][4], float dispersion, float* rec) {
 
 // proposal #0 from the Laplace approximation at the LM solution
 template <int DOF>
-PNP_FN void initial_fit(const float* pose_opt, const float* cov, float eps, float dispersion, float* rec) {
+PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, float dispersion, float* rec) {
   rec[0] = pose_opt[0]; rec[1] = pose_opt[1]; rec[2] = pose_opt[2];
   double Ct[3][3];
 #pragma unroll
@@ -196,7 +210,7 @@ PNP_FN float vm_sample_bounded(float loc, float kappa, const float* u /* kVmTrie
 // forward
 // ================================================================================================================
 template <int DOF, int PPL, bool BOUNDS, int MAXW>
-__global__ __launch_bounds__(MAXW * 64) void amis_forward_kernel(Problem p, AmisParams a,
+__global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis_forward_kernel(Problem p, AmisParams a,
                                                                    const float* __restrict__ pose_opt,
                                                                    const float* __restrict__ pose_cov,
                                                                    const float* __restrict__ noise,
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(MAXW * 64) void amis_forward_kernel(Problem p, Amis
 // backward
 // ================================================================================================================
 template <int DOF, int PPL, bool BOUNDS, int MAXW>
-__global__ __launch_bounds__(MAXW * 64) void amis_backward_kernel(Problem p, const float* __restrict__ pose_samples,
+__global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_BWD_OCC : 1)) void amis_backward_kernel(Problem p, const float* __restrict__ pose_samples,
                                                                     const float* __restrict__ g_logw, int S,
                                                                     const float* __restrict__ pose_init,
                                                                     const float* __restrict__ g_init,
@@ -628,6 +642,10 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
     WP *= 2;
     ppl /= 2;
   }
+  int ov[3];   // WS, WP, PPL
+  if (env_ints("EPROPNP_FWD_SHAPE", ov, 3) && 64 * ov[1] * ov[2] >= d.N && ov[0] * ov[1] <= 16) {
+    WS = ov[0]; WP = ov[1]; ppl = ov[2];
+  }
   AmisParams k;
   k.S = S; k.K = K; k.WP = WP; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset;
@@ -658,7 +676,9 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
     return fail(EPROPNP_EINVAL, "amis_backward: num_pts %d exceeds the register-resident limit %d", prob->num_pts,
                 kMaxResidentPoints);
   const Problem d = to_device_problem(prob);
-  const Shape s = choose_shape(d.B, d.N, /*max_ppl=*/4, /*want_waves_total=*/8192);
+  Shape s = choose_shape(d.B, d.N, /*max_ppl=*/4, /*want_waves_total=*/8192);
+  int ov[2];
+  if (env_ints("EPROPNP_BWD_SHAPE", ov, 2) && 64 * ov[0] * ov[1] >= d.N) { s.waves = ov[0]; s.ppl = ov[1]; }
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((amis_backward_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),

@@ -187,7 +187,9 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
   k.min_diag = lm->min_lm_diagonal; k.max_diag = lm->max_lm_diagonal;
   k.min_rel_decrease = lm->min_relative_decrease; k.radius0 = lm->initial_trust_region_radius;
   k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps;
-  const Shape s = choose_shape(d.B, d.N);
+  Shape s = choose_shape(d.B, d.N);
+  int ov[2];
+  if (env_ints("EPROPNP_LM_SHAPE", ov, 2) && 64 * ov[0] * ov[1] >= d.N) { s.waves = ov[0]; s.ppl = ov[1]; }
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),

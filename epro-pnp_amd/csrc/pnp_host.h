@@ -3,6 +3,7 @@
 #pragma once
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/epropnp_hip.h"
 #include "pnp_sweep.h"
@@ -62,6 +63,19 @@ inline Shape choose_shape(int B, int N, int max_ppl = 8, int want_waves_total = 
   while (64 * w * ppl < N) ppl *= 2;
   s.ppl = ppl;
   return s;
+}
+
+// Tuning knob: EPROPNP_<NAME>="a,b,c" overrides a launcher's automatic workgroup shape.
+inline bool env_ints(const char* name, int* out, int n) {
+  const char* v = getenv(name);
+  if (!v || !*v) return false;
+  for (int i = 0; i < n; ++i) {
+    char* end = nullptr;
+    out[i] = (int)strtol(v, &end, 10);
+    if (end == v) return false;
+    v = (*end == ',') ? end + 1 : end;
+  }
+  return true;
 }
 
 // launchers (one per .hip translation unit)

@@ -19,7 +19,14 @@ namespace pnp {
 constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
-__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+// wave index as a wave-uniform (scalar-register) value: lets the compiler keep everything derived from it in SGPRs
+__device__ __forceinline__ int wave_id() {
+#ifndef EPROPNP_EMU
+  return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+  return (int)(threadIdx.x >> 6);
+#endif
+}
 
 #ifndef EPROPNP_EMU
 

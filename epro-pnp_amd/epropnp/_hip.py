@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libepropnp_hip.so')
+# EPROPNP_LIB: alternative build of the SAME HIP library (kernel-tuning variants, tools/tune.py)
+LIB_PATH = os.environ.get('EPROPNP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libepropnp_hip.so')
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)

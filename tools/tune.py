@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""Kernel-level timing of the C2 workload under shape / build variants (run on the GPU box).
+
+    python tools/tune.py                 # driver: loops over VARIANTS in subprocesses, prints one line each
+    python tools/tune.py --worker        # times lm / amis_fwd / amis_bwd once under the current env
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'epro-pnp_amd'))
+sys.path.insert(0, ROOT)
+
+
+def worker(B, N, S, K, L, reps=8):
+    import torch
+    import bench
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    dev = torch.device('cuda:0')
+    prob = bench.synth_problem(B, N, dev, seed=1000)
+    cam = PerspectiveCamera(cam_mats=prob['cam_mats'])
+    cf = AdaptiveHuberPnPCost(relative_delta=0.5)
+    cf.set_param(prob['x2d'], prob['w2d'])
+    hp = F.PnPProblem(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf, 6)
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2], out
+    t_lm, (pose_opt, cov, _) = timeit(lambda: F.lm_solve(hp, prob['pose_init'], L, with_pose_cov=True, with_cost=True))
+    t_fw, (smp, logw) = timeit(lambda: F.amis_forward(hp, pose_opt, cov, S, K, seed=1))
+    g = -torch.softmax(logw, 0) / B
+    gi = torch.full((B,), 1.0 / B, device=dev)
+    t_bw, _ = timeit(lambda: F.amis_backward(hp, smp, g, prob['pose_init'], gi))
+    lse = torch.logsumexp(logw, 0).mean().item()
+    print(json.dumps(dict(lm_ms=round(t_lm, 4), fwd_ms=round(t_fw, 4), bwd_ms=round(t_bw, 4), lse=round(lse, 4))))
+
+
+VARIANTS = [
+    ('default', {}),
+    ('fwd WS2 WP1 PPL8', {'EPROPNP_FWD_SHAPE': '2,1,8'}),
+    ('fwd WS1 WP1 PPL8', {'EPROPNP_FWD_SHAPE': '1,1,8'}),
+    ('fwd WS2 WP2 PPL4', {'EPROPNP_FWD_SHAPE': '2,2,4'}),
+    ('fwd WS1 WP2 PPL4', {'EPROPNP_FWD_SHAPE': '1,2,4'}),
+    ('fwd WS2 WP4 PPL2', {'EPROPNP_FWD_SHAPE': '2,4,2'}),
+    ('fwd WS1 WP4 PPL2', {'EPROPNP_FWD_SHAPE': '1,4,2'}),
+    ('bwd W1 PPL8', {'EPROPNP_BWD_SHAPE': '1,8'}),
+    ('bwd W2 PPL4', {'EPROPNP_BWD_SHAPE': '2,4'}),
+    ('bwd W4 PPL2', {'EPROPNP_BWD_SHAPE': '4,2'}),
+    ('bwd W8 PPL1', {'EPROPNP_BWD_SHAPE': '8,1'}),
+    ('lm W1 PPL8', {'EPROPNP_LM_SHAPE': '1,8'}),
+    ('lm W2 PPL4', {'EPROPNP_LM_SHAPE': '2,4'}),
+    ('lm W4 PPL2', {'EPROPNP_LM_SHAPE': '4,2'}),
+]
+
+
+def main():
+    if '--worker' in sys.argv:
+        B, N, S, K, L = (int(os.environ.get(k, d)) for k, d in (('TUNE_B', 4096), ('TUNE_N', 512), ('TUNE_S', 512),
+                                                                 ('TUNE_K', 4), ('TUNE_L', 3)))
+        worker(B, N, S, K, L)
+        return
+    libs = [('', None)]
+    vdir = os.path.join(ROOT, 'epro-pnp_amd', 'lib', 'variants')
+    if os.path.isdir(vdir):
+        libs += [(t, os.path.join(vdir, t, 'libepropnp_hip.so')) for t in sorted(os.listdir(vdir))]
+    for tag, lib in libs:
+        for name, env in VARIANTS:
+            e = dict(os.environ)
+            e.update(env)
+            if lib:
+                e['EPROPNP_LIB'] = lib
+            r = subprocess.run([sys.executable, __file__, '--worker'], env=e, capture_output=True, text=True)
+            line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else 'FAILED ' + r.stderr.strip()[-300:]
+            print(f'{tag or "base":16s} {name:22s} {line}', flush=True)
+
+
+if __name__ == '__main__':
+    main()
