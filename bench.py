@@ -87,25 +87,35 @@ class KernelTimer:
 
 def cpu_baseline(N, S, K, L, sample_objects, budget_s=25.0):
     """The oracle (oracle/epropnp_oracle.py) timed on the host cores on `sample_objects` objects of the same
-    workload: monte_carlo_forward + MC loss + backward.  Test/baseline infrastructure -- never the product path."""
+    workload: monte_carlo_forward + MC loss + backward.  Test/baseline infrastructure -- never the product path.
+    torch-CPU oversubscribes badly on many-core hosts (256 threads on small tensors is ~100x slower than 16),
+    so a few thread counts are tried and the best is reported together with the thread count actually used."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import epropnp_oracle as orc
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    host_cores = os.cpu_count() or 1
     prob = synth_problem(sample_objects, N, torch.device('cpu'), seed=0)
     noise = orc.make_noise(sample_objects, S, K, 6, seed=1)
-    times = []
+    best, best_threads, tried = None, None, []
     t_start = time.perf_counter()
-    for it in range(4):
-        t0 = time.perf_counter()
-        orc.run_mc(prob, noise, 6, S, K, L)
-        times.append(time.perf_counter() - t0)
+    for threads in sorted({min(host_cores, t) for t in (8, 16, 32)}):
+        torch.set_num_threads(threads)
+        times = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            orc.run_mc(prob, noise, 6, S, K, L)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget_s:
+                break
+        t = min(times[1:]) if len(times) > 1 else times[0]
+        tried.append((threads, round(sample_objects / t, 1)))
+        if best is None or t < best:
+            best, best_threads = t, threads
         if time.perf_counter() - t_start > budget_s:
             break
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return dict(value=round(sample_objects / best, 2), unit='instances/s', cores=cores, kind='port',
-                sample=f'{sample_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd), best of {max(1, len(times) - 1)} '
-                       f'after 1 warm-up, torch-CPU {torch.get_num_threads()} threads')
+    return dict(value=round(sample_objects / best, 2), unit='instances/s', cores=best_threads, kind='port',
+                host_cores=host_cores, tried_threads_inst_per_s=tried,
+                sample=f'{sample_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd, oracle = PyTorch-CPU restatement '
+                       f'with the reference op structure), best of 2 after 1 warm-up per thread count')
 
 
 def main():
@@ -119,7 +129,7 @@ def main():
     ap.add_argument('--amis-iters', type=int, default=4)
     ap.add_argument('--lm-iters', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=96)
+    ap.add_argument('--cpu-sample', type=int, default=64)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -176,7 +186,7 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

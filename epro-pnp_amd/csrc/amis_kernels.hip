@@ -17,12 +17,8 @@
 
 namespace pnp {
 
-// minimum waves per SIMD requested from the register allocator for the <= 256-thread instantiations
-#ifndef PNP_FWD_OCC
-#define PNP_FWD_OCC 3
-#endif
-#ifndef PNP_BWD_OCC
-#define PNP_BWD_OCC 4
+#ifndef PNP_SWEEP_PIPELINE
+#define PNP_SWEEP_PIPELINE 0
 #endif
 
 constexpr int kPropStride = 40;   // floats per fitted proposal (layout below)
@@ -30,6 +26,8 @@ constexpr int kPropStride = 40;   // floats per fitted proposal (layout below)
 //   6-DoF: [16..25] L_r (lower 4x4 packed) | [26..35] L_r^-1 | [36] sum log diag L_r
 //   4-DoF: [16] yaw mode | [17] kappa | [18] log I0(kappa)
 constexpr int kVmTries = 16;
+constexpr int kRedStride = 68;                      // 64 lanes + 4 floats of padding per parked sample
+constexpr int kWaveRed = 16 * kRedStride + 64;     // per-wave LDS scratch of the transposed cost reduction
 
 struct AmisParams {
   int S, K;            // total samples, iterations
@@ -38,6 +36,7 @@ struct AmisParams {
   int mle_iter;
   float dispersion;
   unsigned long long seed, offset;
+  int ablate;          // tuning builds only (-DPNP_TUNING): bit0 skip sweep, bit1 skip proposal refit, bit2 skip densities
 };
 
 // The fp64 proposal fits run on one lane a handful of times per object; keeping them out of line stops their
@@ -53,26 +52,29 @@ __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) 
 
 // pack Cholesky factor / its inverse / log-normaliser of a 3x3 translation covariance into rec[3..15]
 PNP_FIT_FN void fit_translation(double (&C)[3][3], const float* fallback_diag, float* rec) {
-  const bool ok = cholesky<3, double>(C);
+  double invd[3];
+  const bool ok = cholesky<3, double>(C, invd);
   if (!ok) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) C[i][j] = (i == j) ? (double)fallback_diag[i] : 0.0;
+      invd[i] = 1.0 / (double)fallback_diag[i];
+    }
   }
   double Li[3][3];
-  tri_inverse<3, double>(C, Li);
-  double sl = 0.0;
+  tri_inverse<3, double>(C, invd, Li);
+  float sl = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    sl += log(C[i][i]);
+    sl += logf((float)C[i][i]);
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
       rec[3 + tri(i, j)] = (float)C[i][j];
       rec[9 + tri(i, j)] = (float)Li[i][j];
     }
   }
-  rec[15] = student_t3_log_norm((float)sl);
+  rec[15] = student_t3_log_norm(sl);
 }
 
 // rot_cov (4x4 SPD, trace ~ 1) -> + det^(1/4) * dispersion * I -> Cholesky -> rec[16..36]   (epropnp.py:301-302,341-342)
@@ -82,35 +84,36 @@ PNP_FIT_FN void fit_rotation_acg(double (&Rc)[4][4], float dispersion, float* re
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) Lc[i][j] = Rc[i][j];
-  bool ok = cholesky<4, double>(Lc);
-  double det = 1.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) det *= Lc[i][i] * Lc[i][i];
-  // reference: torch.det on a possibly indefinite matrix; for the non-SPD case any value leads to the
-  // Cholesky fallback below, so the SPD determinant is all that matters
-  const double add = ok ? sqrt(sqrt(det)) * (double)dispersion : 0.0;
+  double invd[4];
+  bool ok = cholesky<4, double>(Lc, invd);
+  // det^(1/4) = sqrt(prod of the Cholesky pivots).  reference: torch.det on a possibly indefinite matrix; in the
+  // non-SPD case any value leads to the Cholesky fallback below, so the SPD determinant is all that matters
+  const float pivots = (float)(Lc[0][0] * Lc[1][1] * Lc[2][2] * Lc[3][3]);
+  const double add = ok ? (double)(sqrtf(pivots) * dispersion) : 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) Rc[i][i] += add;
-  ok = cholesky<4, double>(Rc) && ok;
+  ok = cholesky<4, double>(Rc, invd) && ok;
   if (!ok) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) Rc[i][j] = (i == j) ? 1.0 : 0.0;
+      invd[i] = 1.0;
+    }
   }
   double Li[4][4];
-  tri_inverse<4, double>(Rc, Li);
-  double sl = 0.0;
+  tri_inverse<4, double>(Rc, invd, Li);
+  float sl = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    sl += log(Rc[i][i]);
+    sl += logf((float)Rc[i][i]);
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
       rec[16 + tri(i, j)] = (float)Rc[i][j];
       rec[26 + tri(i, j)] = (float)Li[i][j];
     }
   }
-  rec[36] = (float)sl;
+  rec[36] = sl;
 }
 
 // proposal #0 from the Laplace approximation at the LM solution
@@ -137,7 +140,8 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) Cr[i][j] = (double)cov[(3 + i) * 6 + 3 + j];
-    spd_inverse<3, double>(Cr, Ci);
+    double invd3[3], invd4[4];
+    spd_inverse<3, double>(Cr, invd3, Ci);
     const double w = pose_opt[3], qi = pose_opt[4], qj = pose_opt[5], qk = pose_opt[6];
     const double T[4][3] = {{qi, qj, qk}, {-w, -qk, qj}, {qk, -w, -qi}, {-qj, qi, -w}};   // camera.py:158-165
     double TC[4][3], A[4][4], Ai[4][4];
@@ -150,12 +154,12 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         A[i][j] = TC[i][0] * T[j][0] + TC[i][1] * T[j][1] + TC[i][2] * T[j][2] + ((i == j) ? 1.0 : 0.0);
-    spd_inverse<4, double>(A, Ai);
-    const double tr = Ai[0][0] + Ai[1][1] + Ai[2][2] + Ai[3][3];
+    spd_inverse<4, double>(A, invd4, Ai);
+    const double itr = 1.0 / (Ai[0][0] + Ai[1][1] + Ai[2][2] + Ai[3][3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Ai[i][j] /= tr;
+      for (int j = 0; j < 4; ++j) Ai[i][j] *= itr;
     fit_rotation_acg(Ai, dispersion, rec);
   }
 }
@@ -210,7 +214,7 @@ PNP_FN float vm_sample_bounded(float loc, float kappa, const float* u /* kVmTrie
 // forward
 // ================================================================================================================
 template <int DOF, int PPL, bool BOUNDS, int MAXW>
-__global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis_forward_kernel(Problem p, AmisParams a,
+__global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) void amis_forward_kernel(Problem p, AmisParams a,
                                                                    const float* __restrict__ pose_opt,
                                                                    const float* __restrict__ pose_cov,
                                                                    const float* __restrict__ noise,
@@ -226,7 +230,9 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis
   const int wp = wv % WP, ws = wv / WP;
 
   PNP_DYN_SMEM(float, smem);
-  float* smp = smem;                  // [PL][S]
+  float* ptab = smem;                 // [s][12] K R | K t of the current iteration's samples (16-B aligned rows)
+  float* wred = ptab + 12 * s;        // [waves][kWaveRed] transposed cost reduction (float4 views: 16-B aligned)
+  float* smp = wred + (T >> 6) * kWaveRed;   // [PL][S]
   float* cst = smp + PL * S;          // [S]   cost of each sample
   float* mixl = cst + S;              // [S]   log sum_j q_j(sample)
   float* lgw = mixl + S;              // [S]   log weight
@@ -236,11 +242,14 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis
 
   float Kc[9], delta;
   Bounds bd;
-  load_camera(p, b, Kc, bd, delta);
-  // this wave's slice of the points: lane = point
-  Point pts[PPL];
+  load_camera<BOUNDS>(p, b, Kc, bd, delta);
+  // this wave's slice of the points: lane = point; kept in the pre-multiplied form the sweep consumes
+  SweepPoint pts[PPL];
 #pragma unroll
-  for (int k = 0; k < PPL; ++k) pts[k] = load_point(p, b, wp * 64 + lane + k * 64 * WP);
+  for (int k = 0; k < PPL; ++k) pts[k] = to_sweep_point(load_point(p, b, wp * 64 + lane + k * 64 * WP));
+  // wave-uniform operands of the sweep live in VGPRs: an SGPR source halves the VALU issue rate on gfx950
+  // (profiles/r01_ubench_valu_rates.txt: v_fma_f32 1.05 ns vs 1.84 ns per wave-instruction with an SGPR operand)
+  const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
 
   if (tid == 0) initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop);
   __syncthreads();
@@ -311,37 +320,87 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis
         smp[i * S + m] = ps[i];
         pose_samples[((size_t)m * p.B + b) * PL + i] = ps[i];
       }
+      {   // project_b operands of this sample -> LDS row (read back as broadcast by every lane of the sweep)
+        float R[9], KR[9], Kt[3];
+        pose_to_rot<DOF>(ps, R);
+        compose_kr_kt(Kc, R, ps, KR, Kt);
+        float4* row = reinterpret_cast<float4*>(ptab + 12 * n);
+        row[0] = make_float4(KR[0], KR[1], KR[2], KR[3]);
+        row[1] = make_float4(KR[4], KR[5], KR[6], KR[7]);
+        row[2] = make_float4(KR[8], Kt[0], Kt[1], Kt[2]);
+      }
     }
     __syncthreads();
 
     // ---------------- 2. cost sweep: s poses x this wave's points (lane = point) ----------------
     const int ntile = (s + 63) >> 6;
+#ifdef PNP_TUNING
+    if (a.ablate & 1) {
+      for (int n = tid; n < s; n += T) cpart[n] = 1.0f;
+    } else
+#endif
     for (int t = ws; t < ntile; t += WS) {
-      const int n_l = t * 64 + lane;            // this lane's sample within the iteration
-      float KR[9], Kt[3];
-      {
-        float ps[PL], R[9];
-        const int m = it * s + min(n_l, s - 1);
-#pragma unroll
-        for (int i = 0; i < PL; ++i) ps[i] = smp[i * S + m];
-        pose_to_rot<DOF>(ps, R);
-        compose_kr_kt(Kc, R, ps, KR, Kt);
-      }
-      const int cnt = min(64, s - t * 64);
+      const int base = t * 64;
+      const int cnt = min(64, s - base);
       float mine = 0.f;
-      for (int j = 0; j < cnt; ++j) {
-        float kr[9], kt[3];
+#if PNP_SWEEP_PIPELINE
+      // two samples per trip (their DPP reduction chains interleave); the next trip's first pose row is fetched
+      // from LDS before the current pair is evaluated, so the ds_read latency hides behind ~400 VALU instructions
+      const float4* row = reinterpret_cast<const float4*>(ptab + 12 * base);   // uniform address: LDS broadcast
+      float4 n0 = row[0], n1 = row[1], n2 = row[2];
+      for (int j = 0; j < cnt; j += 2) {
+        const float4 a0 = n0, a1 = n1, a2 = n2;
+        const float4* rb = reinterpret_cast<const float4*>(ptab + 12 * (base + min(j + 1, cnt - 1)));
+        const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2];
+        const float4* rn = reinterpret_cast<const float4*>(ptab + 12 * (base + min(j + 2, cnt - 1)));
+        n0 = rn[0]; n1 = rn[1]; n2 = rn[2];
+        const float krA[9] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x};
+        const float ktA[3] = {a2.y, a2.z, a2.w};
+        const float krB[9] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x};
+        const float ktB[3] = {b2.y, b2.z, b2.w};
+        float cA = 0.f, cB = 0.f;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) kr[i] = wave_bcast(KR[i], j);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) kt[i] = wave_bcast(Kt[i], j);
-        float c = 0.f;
-#pragma unroll
-        for (int k = 0; k < PPL; ++k) c += point_cost<BOUNDS, true>(pts[k], kr, kt, p.z_min, delta, bd);
-        c = wave_sum(c);
-        mine = (lane == j) ? c : mine;
+        for (int k = 0; k < PPL; ++k) {
+          cA += sweep_cost<BOUNDS>(pts[k], krA, ktA, zmin_v, delta_v, bd);
+          cB += sweep_cost<BOUNDS>(pts[k], krB, ktB, zmin_v, delta_v, bd);
+        }
+        cA = wave_sum(cA);
+        cB = wave_sum(cB);
+        mine = (lane == j) ? cA : mine;
+        mine = (lane == j + 1) ? cB : mine;     // j + 1 == cnt (odd tail) only ever matches a lane >= cnt: unused
       }
-      if (n_l < s) cpart[wp * s + n_l] = mine;
+#else
+      // Per-lane partial costs of 16 samples are parked in LDS (one ds_write each, no dependent chain in the hot
+      // loop) and summed "transposed": lane l adds the 16 partials of sample (l & 15) held by lanes 16q..16q+15
+      // (q = l >> 4), then the four quarter sums are combined through a second 64-float exchange.
+      float* rt = wred + wv * kWaveRed;
+      float* rq = rt + 16 * kRedStride;
+      for (int j0 = 0; j0 < cnt; j0 += 16) {
+        const int g = min(16, cnt - j0);
+        for (int jj = 0; jj < g; ++jj) {
+          const float4* row = reinterpret_cast<const float4*>(ptab + 12 * (base + j0 + jj));   // uniform: LDS broadcast
+          const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+          const float kr[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+          const float kt[3] = {r2.y, r2.z, r2.w};
+          float c = 0.f;
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) c += sweep_cost<BOUNDS>(pts[k], kr, kt, zmin_v, delta_v, bd);
+          rt[jj * kRedStride + lane] = c;
+        }
+        wave_lds_fence();
+        const float4* col = reinterpret_cast<const float4*>(rt + (lane & 15) * kRedStride + 16 * (lane >> 4));
+        const float4 v0 = col[0], v1 = col[1], v2 = col[2], v3 = col[3];
+        const float quarter = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)) +
+                              (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
+        rq[(lane & 15) * 4 + (lane >> 4)] = quarter;
+        wave_lds_fence();
+        const float4 q4 = *reinterpret_cast<const float4*>(rq + (lane & 15) * 4);
+        const float total = (q4.x + q4.y) + (q4.z + q4.w);
+        mine = ((lane >> 4) == (j0 >> 4)) ? total : mine;   // lanes j0..j0+15 own samples j0..j0+15 of the tile
+        wave_lds_fence();                                   // rt / rq are rewritten by the next group
+      }
+#endif
+      if (base + lane < s) cpart[wp * s + base + lane] = mine;
     }
     __syncthreads();
 
@@ -357,9 +416,18 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis
         float c = cpart[m - it * s];
         for (int q = 1; q < WP; ++q) c += cpart[q * s + (m - it * s)];
         cst[m] = c;
+#ifdef PNP_TUNING
+        if (a.ablate & 4) mix = 0.f; else {
+#endif
         mix = proposal_logprob<DOF>(prop, ps);
         for (int j = 1; j <= it; ++j) mix = log_add_exp(mix, proposal_logprob<DOF>(prop + j * kPropStride, ps));
+#ifdef PNP_TUNING
+        }
+#endif
       } else {             // old sample: add the new proposal's density
+#ifdef PNP_TUNING
+        if (a.ablate & 4) mix = 0.f; else
+#endif
         mix = log_add_exp(mixl[m], proposal_logprob<DOF>(rec, ps));
       }
       mixl[m] = mix;
@@ -370,6 +438,13 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis
 
     // ---------------- 5. fit proposal it+1 to the weighted samples (epropnp.py:238-260 / :317-342) ---------
     float* nrec = prop + (it + 1) * kPropStride;
+#ifdef PNP_TUNING
+    if (a.ablate & 2) {
+      for (int i = tid; i < kPropStride; i += T) nrec[i] = rec[i];
+      __syncthreads();
+      continue;
+    }
+#endif
     float mx = -INFINITY;
     for (int m = tid; m < M; m += T) mx = fmaxf(mx, lgw[m]);
     mx = block_max(mx, red);
@@ -415,16 +490,17 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis
         block_sum<11>(acc, red);
         if (r + 1 < a.mle_iter) {   // need Sigma^-1 for the next fixed-point step
           if (tid == 0) {
-            double Sg[4][4], Sgi[4][4];
+            double Sg[4][4], Sgi[4][4], invd[4];
+            const double inorm = 1.0 / (double)acc[10];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
               for (int j = 0; j <= i; ++j) {
-                const double v = (double)acc[tri(i, j)] / (double)acc[10] + ((i == j) ? (double)a.eps : 0.0);
+                const double v = (double)acc[tri(i, j)] * inorm + ((i == j) ? (double)a.eps : 0.0);
                 Sg[i][j] = v;
                 Sg[j][i] = v;
               }
-            spd_inverse<4, double>(Sg, Sgi);
+            spd_inverse<4, double>(Sg, invd, Sgi);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -449,11 +525,12 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis
         const float dflt[3] = {1.f, 1.f, 1.f};
         fit_translation(Ct, dflt, nrec);
         double Sg[4][4];
+        const double inorm = (a.mle_iter > 0) ? 1.0 / (double)acc[10] : 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j <= i; ++j) {
-            double v = (a.mle_iter > 0) ? (double)acc[tri(i, j)] / (double)acc[10] + ((i == j) ? (double)a.eps : 0.0)
+            double v = (a.mle_iter > 0) ? (double)acc[tri(i, j)] * inorm + ((i == j) ? (double)a.eps : 0.0)
                                         : ((i == j) ? 1.0 : 0.0);
             Sg[i][j] = v;
             Sg[j][i] = v;
@@ -504,21 +581,24 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_FWD_OCC : 1)) void amis
 // backward
 // ================================================================================================================
 template <int DOF, int PPL, bool BOUNDS, int MAXW>
-__global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_BWD_OCC : 1)) void amis_backward_kernel(Problem p, const float* __restrict__ pose_samples,
+__global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ? 3 : 4)) : 1)) void amis_backward_kernel(Problem p, const float* __restrict__ pose_samples,
                                                                     const float* __restrict__ g_logw, int S,
                                                                     const float* __restrict__ pose_init,
                                                                     const float* __restrict__ g_init,
                                                                     float* __restrict__ gx3d, float* __restrict__ gx2d,
                                                                     float* __restrict__ gw2d, float* __restrict__ gdelta) {
   constexpr int PL = PoseLen<DOF>::value;
+  // pose tiles: 64 poses x {K R (9) | K t (3) | weight | pad} as 4 float4 rows, double buffered
+  __shared__ __attribute__((aligned(16))) float tab[2][64][16];
   __shared__ float red[16];
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
-  const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id();
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x;
 
   float Kc[9], delta;
   Bounds bd;
-  load_camera(p, b, Kc, bd, delta);
+  load_camera<BOUNDS>(p, b, Kc, bd, delta);
+  const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
   Point pts[PPL];
   float gX[PPL], gY[PPL], gZ[PPL], gu[PPL], gv[PPL], gwu[PPL], gwv[PPL];
 #pragma unroll
@@ -531,36 +611,64 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_BWD_OCC : 1)) void amis
   const bool with_init = (pose_init != nullptr) && (g_init != nullptr);
   const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
   const int ntile = (P + 63) >> 6;
-  for (int t = 0; t < ntile; ++t) {
-    // lane = pose: fetch pose, build K R / K t and the pose weight
-    float KR[9], Kt[3], aw;
-    {
-      const int m = min(t * 64 + lane, P - 1);
-      float ps[PL], R[9];
+
+  // lanes 0..63 of the workgroup fetch one pose each of tile t (global loads issued early, consumed late)
+  float nps[PL], naw = 0.f;
+  auto fetch = [&](int t) {
+    if (tid < 64) {
+      const int m = min(t * 64 + tid, P - 1);
       const float* src = (m < S) ? pose_samples + ((size_t)m * p.B + b) * PL : pose_init + (size_t)b * PL;
 #pragma unroll
-      for (int i = 0; i < PL; ++i) ps[i] = src[i];
-      aw = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init[b];     // logw = -cost - const
-      pose_to_rot<DOF>(ps, R);
-      compose_kr_kt(Kc, R, ps, KR, Kt);
+      for (int i = 0; i < PL; ++i) nps[i] = src[i];
+      naw = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init[b];     // logw = -cost - const
     }
+  };
+  auto publish = [&](int buf) {
+    if (tid < 64) {
+      float R[9], KR[9], Kt[3];
+      pose_to_rot<DOF>(nps, R);
+      compose_kr_kt(Kc, R, nps, KR, Kt);
+      float4* row = reinterpret_cast<float4*>(&tab[buf][tid][0]);
+      row[0] = make_float4(KR[0], KR[1], KR[2], KR[3]);
+      row[1] = make_float4(KR[4], KR[5], KR[6], KR[7]);
+      row[2] = make_float4(KR[8], Kt[0], Kt[1], Kt[2]);
+      row[3] = make_float4(naw, 0.f, 0.f, 0.f);
+    }
+  };
+
+  if (ntile > 0) {
+    fetch(0);
+    publish(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const bool more = (t + 1 < ntile);
+    if (more) fetch(t + 1);
     const int cnt = min(64, P - t * 64);
+    const int buf = t & 1;
+    const float4* row0 = reinterpret_cast<const float4*>(&tab[buf][0][0]);   // uniform address: LDS broadcast
+    float4 n0 = row0[0], n1 = row0[1], n2 = row0[2], n3 = row0[3];
     for (int j = 0; j < cnt; ++j) {
-      const float a = wave_bcast(aw, j);
-      if (a == 0.f) continue;   // wave-uniform
-      float kr[9], kt[3];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) kr[i] = wave_bcast(KR[i], j);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) kt[i] = wave_bcast(Kt[i], j);
+      const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+      {   // fetch the next pose row now; it is consumed one trip later
+        const float4* rn = reinterpret_cast<const float4*>(&tab[buf][min(j + 1, cnt - 1)][0]);
+        n0 = rn[0]; n1 = rn[1]; n2 = rn[2]; n3 = rn[3];
+      }
+      const float a = r3.x;
+#ifndef EPROPNP_EMU
+      if (__builtin_amdgcn_readfirstlane(__float_as_int(a)) == 0) continue;   // exact zero weight (wave-uniform)
+#else
+      if (a == 0.f) continue;
+#endif
+      const float kr[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+      const float kt[3] = {r2.y, r2.z, r2.w};
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         const Point& q = pts[k];
         const float hx = fmaf(kr[0], q.X, fmaf(kr[1], q.Y, fmaf(kr[2], q.Z, kt[0])));
         const float hy = fmaf(kr[3], q.X, fmaf(kr[4], q.Y, fmaf(kr[5], q.Z, kt[1])));
         const float hz = fmaf(kr[6], q.X, fmaf(kr[7], q.Y, fmaf(kr[8], q.Z, kt[2])));
-        const float z = fmaxf(hz, p.z_min);
-        const float rz = fast_rcp(z);
+        const float rz = fast_rcp(fmaxf(hz, zmin_v));
         const float ppx = hx * rz, ppy = hy * rz;          // un-clamped projection
         float px = ppx, py = ppy;
         if (BOUNDS) {
@@ -572,7 +680,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_BWD_OCC : 1)) void amis
         const float s2 = fmaf(rx, rx, ry * ry);
         const float rs = fast_rsqrt(fmaxf(s2, 1e-30f));
         const float rho = s2 * rs;
-        const float mm = fminf(rho, delta);
+        const float mm = fminf(rho, delta_v);
         const float coef = a * mm * rs;                      // a * min(1, delta / rho)
         gd = fmaf(a, rho - mm, gd);                          // d huber / d delta = max(rho - delta, 0)
         const float crx = coef * rx, cry = coef * ry;
@@ -587,12 +695,14 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? PNP_BWD_OCC : 1)) void amis
         }
         const float ghx = gpx * rz, ghy = gpy * rz;
         float ghz = -(gpx * ppx + gpy * ppy) * rz;
-        ghz = (hz >= p.z_min) ? ghz : 0.f;
+        ghz = (hz >= zmin_v) ? ghz : 0.f;
         gX[k] = fmaf(kr[0], ghx, fmaf(kr[3], ghy, fmaf(kr[6], ghz, gX[k])));
         gY[k] = fmaf(kr[1], ghx, fmaf(kr[4], ghy, fmaf(kr[7], ghz, gY[k])));
         gZ[k] = fmaf(kr[2], ghx, fmaf(kr[5], ghy, fmaf(kr[8], ghz, gZ[k])));
       }
     }
+    if (more) publish((t + 1) & 1);
+    __syncthreads();
   }
 
 #pragma unroll
@@ -649,7 +759,11 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   AmisParams k;
   k.S = S; k.K = K; k.WP = WP; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset;
-  const size_t smem = sizeof(float) * ((size_t)PL * S + 3 * (size_t)S + (size_t)WP * s + (size_t)K * kPropStride + 256);
+  k.ablate = 0;
+  { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
+  // the float4-viewed arrays (ptab rows, wred) come first so that they are 16-B aligned for any S
+  const size_t smem = sizeof(float) * (12 * (size_t)s + (size_t)PL * S + 3 * (size_t)S + (size_t)WP * s +
+                                       (size_t)K * kPropStride + 256 + (size_t)WS * WP * kWaveRed);
   if (smem > 160 * 1024) return fail(EPROPNP_EINVAL, "amis_forward: mc_samples %d needs %zu B of LDS (> 160 KiB)", S, smem);
   const dim3 grid(padded_object_grid(d.B)), block(64 * WS * WP);
   dispatch_shape(prob->dof, ppl, has_bounds(prob), WS * WP, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
@@ -676,7 +790,8 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
     return fail(EPROPNP_EINVAL, "amis_backward: num_pts %d exceeds the register-resident limit %d", prob->num_pts,
                 kMaxResidentPoints);
   const Problem d = to_device_problem(prob);
-  Shape s = choose_shape(d.B, d.N, /*max_ppl=*/4, /*want_waves_total=*/8192);
+  // measured on MI355X (profiles/): fewest waves per object wins (per-pose overhead amortised over 8 points/lane)
+  Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/4096);
   int ov[2];
   if (env_ints("EPROPNP_BWD_SHAPE", ov, 2) && 64 * ov[0] * ov[1] >= d.N) { s.waves = ov[0]; s.ppl = ov[1]; }
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);

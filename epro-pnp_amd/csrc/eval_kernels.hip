@@ -24,7 +24,7 @@ __global__ __launch_bounds__(1024) void normal_equations_kernel(Problem p, const
   if (b >= p.B) return;
   float K[9], R[9], ps[PL], delta;
   Bounds bd;
-  load_camera(p, b, K, bd, delta);
+  load_camera<BOUNDS>(p, b, K, bd, delta);
 #pragma unroll
   for (int i = 0; i < PL; ++i) ps[i] = pose[(size_t)b * PL + i];
   pose_to_rot<DOF>(ps, R);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(MAXW * 64) void evaluate_cost_kernel(Problem p, con
   if (b >= p.B) return;
   float K[9], delta;
   Bounds bd;
-  load_camera(p, b, K, bd, delta);
+  load_camera<BOUNDS>(p, b, K, bd, delta);
   Point pts[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; ++k) pts[k] = load_point(p, b, (int)threadIdx.x + k * (int)blockDim.x);

@@ -4,8 +4,8 @@
 // (:192-241) and pose_add (:255-265).  The reference launches ~40 ATen kernels per iteration and keeps two
 // (B,2N,d) Jacobians in memory; here one workgroup owns one object, its N correspondences are read from HBM
 // once and stay in registers for all 1+L sweeps, J^T J / J^T r / cost are wave-reduced with DPP, and the
-// d x d damped system is solved in registers (fp64 Cholesky: the matrix is SPD by construction; the
-// reference's LU with pivoting gives the same solution up to rounding).
+// d x d damped system is solved in registers by a Jacobi-scaled fp32 Cholesky (the matrix is SPD by construction;
+// the reference's unscaled LU with pivoting gives the same solution up to its own, larger, rounding error).
 #include "dispatch.h"
 #include "pnp_host.h"
 
@@ -16,21 +16,16 @@ struct LmParams {
   float min_diag, max_diag, min_rel_decrease, radius0, radius_max, eps;
 };
 
-template <int DOF, int PPL, bool BOUNDS>
-struct LmState {
-  static constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
-};
-
-// acc (upper-tri JtJ | Jtr | cost)  ->  dense symmetric fp64 matrix
+// acc (upper-tri JtJ | Jtr | cost)  ->  dense symmetric matrix
 template <int DOF>
-PNP_FN void unpack_h(const float (&acc)[NormalEq<DOF>::NV], double (&H)[DOF][DOF]) {
+PNP_FN void unpack_h(const float (&acc)[NormalEq<DOF>::NV], float (&H)[DOF][DOF]) {
   int idx = 0;
 #pragma unroll
   for (int i = 0; i < DOF; ++i)
 #pragma unroll
     for (int j = i; j < DOF; ++j) {
-      H[i][j] = (double)acc[idx];
-      H[j][i] = (double)acc[idx];
+      H[i][j] = acc[idx];
+      H[j][i] = acc[idx];
       ++idx;
     }
 }
@@ -47,7 +42,12 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
 
   float K[9], delta;
   Bounds bd;
-  load_camera(p, b, K, bd, delta);
+  load_camera<BOUNDS>(p, b, K, bd, delta);
+  // wave-uniform sweep operands go to VGPRs (an SGPR source operand halves the VALU issue rate on gfx950)
+#pragma unroll
+  for (int i = 0; i < 9; ++i) K[i] = to_vgpr(K[i]);
+  delta = to_vgpr(delta);
+  const float z_min = to_vgpr(p.z_min);
   Point pts[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; ++k) pts[k] = load_point(p, b, (int)threadIdx.x + k * (int)blockDim.x);
@@ -58,36 +58,40 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
 
   // one sweep: normal equations + cost of all points at pose `ps`
   auto sweep = [&](const float* ps, bool clip, float (&acc)[NV]) {
-    float R[9];
+    float R[9], t[3];
     pose_to_rot<DOF>(ps, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = to_vgpr(R[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = to_vgpr(ps[i]);
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, ps, p.z_min, delta, bd, clip, acc);
+    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, z_min, delta, bd, clip, acc);
     block_sum<NV>(acc, scratch);
   };
 
   float cur[NV];
   int accepted_bits = 0;
-  const double eps = (double)lm.eps;
 
   if (lm.fast_mode) {
     // Gauss-Newton (levenberg_marquardt.py:136-152): J^T J + eps I, no clip_jac; pose_cov / cost come from the
     // last EVALUATED (pre-update) point.
     for (int it = 0; it < lm.num_iter; ++it) {
       sweep(pose, false, cur);
-      double H[DOF][DOF], g[DOF];
+      float H[DOF][DOF], g[DOF];
+      ScaledFactor<DOF> f;
       unpack_h<DOF>(cur, H);
 #pragma unroll
       for (int i = 0; i < DOF; ++i) {
-        H[i][i] += eps;
-        g[i] = (double)cur[NH + i];
+        H[i][i] += lm.eps;
+        g[i] = cur[NH + i];
       }
-      cholesky<DOF, double>(H);
-      cholesky_solve<DOF, double>(H, g);
+      scaled_cholesky<DOF>(H, f);
+      scaled_solve<DOF>(f, g);
       float step[DOF], nxt[PL];
 #pragma unroll
-      for (int i = 0; i < DOF; ++i) step[i] = (float)(-g[i]);
+      for (int i = 0; i < DOF; ++i) step[i] = -g[i];
       pose_add<DOF>(pose, step, nxt);
 #pragma unroll
       for (int i = 0; i < PL; ++i) pose[i] = nxt[i];
@@ -98,39 +102,39 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
     sweep(pose, true, cur);
     float radius = lm.radius0, decrease = 2.0f;
     for (int it = 0; it < lm.num_iter; ++it) {
-      double H[DOF][DOF], Hlm[DOF][DOF], g[DOF], st[DOF];
+      float H[DOF][DOF], Hlm[DOF][DOF], g[DOF], st[DOF];
+      ScaledFactor<DOF> f;
       unpack_h<DOF>(cur, H);
 #pragma unroll
       for (int i = 0; i < DOF; ++i) {
 #pragma unroll
         for (int j = 0; j < DOF; ++j) Hlm[i][j] = H[i][j];
-        // diagonal += clamp(diagonal, min, max) / radius + eps   (fp32 like the reference, :210-211)
-        const float d = cur[/*diag index*/ i * DOF - i * (i - 1) / 2];
-        const float add = fminf(fmaxf(d, lm.min_diag), lm.max_diag) / radius + lm.eps;
-        Hlm[i][i] = (double)(d + add);
-        g[i] = (double)cur[NH + i];
+        // diagonal += clamp(diagonal, min, max) / radius + eps   (:210-211)
+        const float d = H[i][i];
+        Hlm[i][i] = d + (fminf(fmaxf(d, lm.min_diag), lm.max_diag) / radius + lm.eps);
+        g[i] = cur[NH + i];
         st[i] = g[i];
       }
-      cholesky<DOF, double>(Hlm);
-      cholesky_solve<DOF, double>(Hlm, st);   // st = Hlm^-1 g ; step = -st
+      scaled_cholesky<DOF>(Hlm, f);
+      scaled_solve<DOF>(f, st);   // st = Hlm^-1 g ; step = -st
       float step[DOF], pose_new[PL];
 #pragma unroll
-      for (int i = 0; i < DOF; ++i) step[i] = (float)(-st[i]);
+      for (int i = 0; i < DOF; ++i) step[i] = -st[i];
       pose_add<DOF>(pose, step, pose_new);
 
       float nxt[NV];
       sweep(pose_new, true, nxt);
 
-      // model_cost_change = -step^T (H step / 2 + g)     (:225), in fp32 step like the reference
-      double mcc = 0.0;
+      // model_cost_change = -step^T (H step / 2 + g)     (:225)
+      float mcc = 0.f;
 #pragma unroll
       for (int i = 0; i < DOF; ++i) {
-        double hs = 0.0;
+        float hs = 0.f;
 #pragma unroll
-        for (int j = 0; j < DOF; ++j) hs += H[i][j] * (double)step[j];
-        mcc -= (double)step[i] * (0.5 * hs + g[i]);
+        for (int j = 0; j < DOF; ++j) hs = fmaf(H[i][j], step[j], hs);
+        mcc -= step[i] * (0.5f * hs + g[i]);
       }
-      const float model_change = (float)mcc;
+      const float model_change = mcc;
       const float rel = (cur[NV - 1] - nxt[NV - 1]) / model_change;
       const bool ok = (rel >= lm.min_rel_decrease) && (model_change > 0.0f);
       if (ok) {   // wave-uniform
@@ -157,16 +161,20 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
     for (int i = 0; i < PL; ++i) pose_opt[(size_t)b * PL + i] = pose[i];
     if (cost_out) cost_out[b] = cur[NV - 1];
     if (accept_out) accept_out[b] = accepted_bits;
-    if (pose_cov) {   // inverse(J^T J + eps I) at the final accepted point (:170-181)
-      double H[DOF][DOF], Hi[DOF][DOF];
-      unpack_h<DOF>(cur, H);
+  }
+  if (pose_cov) {   // inverse(J^T J + eps I) at the final accepted point (:170-181)
+    float H[DOF][DOF], Hi[DOF][DOF];
+    ScaledFactor<DOF> f;
+    unpack_h<DOF>(cur, H);
 #pragma unroll
-      for (int i = 0; i < DOF; ++i) H[i][i] = (double)(cur[i * DOF - i * (i - 1) / 2] + lm.eps);
-      spd_inverse<DOF, double>(H, Hi);
+    for (int i = 0; i < DOF; ++i) H[i][i] += lm.eps;
+    scaled_cholesky<DOF>(H, f);
+    scaled_inverse<DOF>(f, Hi);
+    if (threadIdx.x == 0) {
 #pragma unroll
       for (int i = 0; i < DOF; ++i)
 #pragma unroll
-        for (int j = 0; j < DOF; ++j) pose_cov[(size_t)b * DOF * DOF + i * DOF + j] = (float)Hi[i][j];
+        for (int j = 0; j < DOF; ++j) pose_cov[(size_t)b * DOF * DOF + i * DOF + j] = Hi[i][j];
     }
   }
 }

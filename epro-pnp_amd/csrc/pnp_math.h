@@ -156,6 +156,47 @@ PNP_FN float point_cost(const Point& p, const float (&KR)[9], const float (&Kt)[
   return m * fmaf(-0.5f, m, rho);
 }
 
+// Force a (possibly wave-uniform, SGPR-resident) value into a vector register.
+PNP_FN float to_vgpr(float x) {
+#ifndef EPROPNP_EMU
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+
+// Correspondence in the form the AMIS cost sweep consumes: the residual is one FMA,
+//   r = (p - u) * w  ==  fma(p, w, -u*w).
+struct SweepPoint {
+  float X, Y, Z, wu, wv, cu, cv;
+};
+PNP_FN SweepPoint to_sweep_point(const Point& p) {
+  SweepPoint q;
+  q.X = p.X; q.Y = p.Y; q.Z = p.Z; q.wu = p.wu; q.wv = p.wv;
+  q.cu = -p.u * p.wu;
+  q.cv = -p.v * p.wv;
+  return q;
+}
+
+// Huber cost of one point under pose (KR, Kt), all operands in VGPRs: 17 plain VALU + max + min + rcp + sqrt.
+template <bool BOUNDS>
+PNP_FN float sweep_cost(const SweepPoint& p, const float (&KR)[9], const float (&Kt)[3], float z_min, float delta,
+                        const Bounds& bd) {
+  const float hx = fmaf(KR[0], p.X, fmaf(KR[1], p.Y, fmaf(KR[2], p.Z, Kt[0])));
+  const float hy = fmaf(KR[3], p.X, fmaf(KR[4], p.Y, fmaf(KR[5], p.Z, Kt[1])));
+  const float hz = fmaf(KR[6], p.X, fmaf(KR[7], p.Y, fmaf(KR[8], p.Z, Kt[2])));
+  const float rz = fast_rcp(fmaxf(hz, z_min));
+  float px = hx * rz, py = hy * rz;
+  if (BOUNDS) {
+    px = fminf(fmaxf(px, bd.lbx), bd.ubx);
+    py = fminf(fmaxf(py, bd.lby), bd.uby);
+  }
+  const float rx = fmaf(px, p.wu, p.cu);
+  const float ry = fmaf(py, p.wv, p.cv);
+  const float rho = fast_sqrt(fmaf(rx, rx, ry * ry));
+  const float m = fminf(rho, delta);          // huber = m * (rho - m/2)
+  return m * fmaf(-0.5f, m, rho);
+}
+
 // Exact-form Huber (same expression as cost_fun.py:8-12) for the non-fast paths.
 PNP_FN float huber_exact(float rho, float delta) {
   return (rho <= delta) ? 0.5f * rho * rho : delta * rho - 0.5f * delta * delta;
@@ -164,52 +205,68 @@ PNP_FN float huber_exact(float rho, float delta) {
 // ---------------------------------------------------------------------------------------------------
 // tiny dense linear algebra, fully unrolled
 // ---------------------------------------------------------------------------------------------------
-// Cholesky A = L L^T in place on the lower triangle; returns false when a pivot is not positive/finite.
+// 1/sqrt(d) without the long IEEE sqrt/divide sequences: hardware rsq (fp32, 1 ulp) + Newton steps in the
+// working precision (one step: ~full fp32 accuracy; two steps from an fp32 seed: ~1e-14 relative in fp64).
+PNP_FN float rsqrt_newton(float d) {
+  const float r = fast_rsqrt(d);
+  return r * fmaf(-0.5f * d * r, r, 1.5f);
+}
+PNP_FN double rsqrt_newton(double d) {
+  double r = (double)fast_rsqrt((float)d);
+  r = r * (1.5 - 0.5 * d * r * r);
+  r = r * (1.5 - 0.5 * d * r * r);
+  return r;
+}
+
+// Cholesky A = L L^T in place on the lower triangle; invd[j] = 1 / L[j][j].
+// Returns false when a pivot is not positive/finite (that pivot is then replaced by 1).
 template <int D, typename T>
-PNP_FN bool cholesky(T (&A)[D][D]) {
+PNP_FN bool cholesky(T (&A)[D][D], T (&invd)[D]) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     T d = A[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
-    ok = ok && (d > T(0)) && (d < T(1e300));
-    const T l = sqrt(d > T(0) ? d : T(1));
-    A[j][j] = l;
-    const T inv = T(1) / l;
+    const bool good = (d > T(1e-37)) && (d < T(1e37));
+    ok = ok && good;
+    d = good ? d : T(1);
+    const T r = rsqrt_newton(d);
+    A[j][j] = d * r;
+    invd[j] = r;
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
       T s = A[i][j];
 #pragma unroll
       for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
-      A[i][j] = s * inv;
+      A[i][j] = s * r;
     }
   }
   return ok;
 }
 
-// solve L L^T x = b in place (L lower)
+// solve L L^T x = b in place (L lower, invd = 1/diag L)
 template <int D, typename T>
-PNP_FN void cholesky_solve(const T (&L)[D][D], T (&b)[D]) {
+PNP_FN void cholesky_solve(const T (&L)[D][D], const T (&invd)[D], T (&b)[D]) {
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     T s = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s -= L[i][k] * b[k];
-    b[i] = s / L[i][i];
+    b[i] = s * invd[i];
   }
 #pragma unroll
   for (int i = D - 1; i >= 0; --i) {
     T s = b[i];
 #pragma unroll
     for (int k = i + 1; k < D; ++k) s -= L[k][i] * b[k];
-    b[i] = s / L[i][i];
+    b[i] = s * invd[i];
   }
 }
 
 // inverse of a lower-triangular matrix (result lower-triangular, upper part zeroed)
 template <int D, typename T>
-PNP_FN void tri_inverse(const T (&L)[D][D], T (&Li)[D][D]) {
+PNP_FN void tri_inverse(const T (&L)[D][D], const T (&invd)[D], T (&Li)[D][D]) {
 #pragma unroll
   for (int j = 0; j < D; ++j) {
 #pragma unroll
@@ -217,24 +274,24 @@ PNP_FN void tri_inverse(const T (&L)[D][D], T (&Li)[D][D]) {
       if (i < j) {
         Li[i][j] = T(0);
       } else if (i == j) {
-        Li[i][j] = T(1) / L[i][i];
+        Li[i][j] = invd[i];
       } else {
         T s = T(0);
 #pragma unroll
         for (int k = j; k < i; ++k) s -= L[i][k] * Li[k][j];
-        Li[i][j] = s / L[i][i];
+        Li[i][j] = s * invd[i];
       }
     }
   }
 }
 
-// SPD inverse through Cholesky: A^-1 = L^-T L^-1.  A is overwritten by its Cholesky factor.
+// SPD inverse through Cholesky: A^-1 = L^-T L^-1.  A is overwritten by its Cholesky factor, invd = 1/diag L.
 // Returns false when A is not positive definite (result then undefined).
 template <int D, typename T>
-PNP_FN bool spd_inverse(T (&A)[D][D], T (&Ainv)[D][D]) {
-  const bool ok = cholesky<D, T>(A);
+PNP_FN bool spd_inverse(T (&A)[D][D], T (&invd)[D], T (&Ainv)[D][D]) {
+  const bool ok = cholesky<D, T>(A, invd);
   T Li[D][D];
-  tri_inverse<D, T>(A, Li);
+  tri_inverse<D, T>(A, invd, Li);
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -246,6 +303,55 @@ PNP_FN bool spd_inverse(T (&A)[D][D], T (&Ainv)[D][D]) {
       Ainv[j][i] = s;
     }
   return ok;
+}
+
+// Jacobi-scaled Cholesky of a symmetric positive definite matrix H (fp32): with s_i = 1/sqrt(H_ii),
+// A = diag(s) H diag(s) has unit diagonal and a condition number that no longer carries the metres-vs-radians
+// scale gap of the pose parameterisation, so single precision suffices.  L L^T = A on return (lower).
+template <int D>
+struct ScaledFactor {
+  float L[D][D];     // Cholesky factor of diag(s) H diag(s)
+  float invd[D];     // 1 / diag L
+  float s[D];        // 1 / sqrt(diag H)
+};
+
+template <int D>
+PNP_FN bool scaled_cholesky(const float (&H)[D][D], ScaledFactor<D>& f) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) f.s[i] = rsqrt_newton(fmaxf(H[i][i], 1e-30f));
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) f.L[i][j] = H[i][j] * (f.s[i] * f.s[j]);
+  return cholesky<D, float>(f.L, f.invd);
+}
+
+// x = H^-1 b through the scaled factor:  x = s .* (A^-1 (s .* b))
+template <int D>
+PNP_FN void scaled_solve(const ScaledFactor<D>& f, float (&b)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) b[i] *= f.s[i];
+  cholesky_solve<D, float>(f.L, f.invd, b);
+#pragma unroll
+  for (int i = 0; i < D; ++i) b[i] *= f.s[i];
+}
+
+// H^-1 = diag(s) A^-1 diag(s)
+template <int D>
+PNP_FN void scaled_inverse(const ScaledFactor<D>& f, float (&Hinv)[D][D]) {
+  float Li[D][D];
+  tri_inverse<D, float>(f.L, f.invd, Li);
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = i; k < D; ++k) acc += Li[k][i] * Li[k][j];
+      acc *= f.s[i] * f.s[j];
+      Hinv[i][j] = acc;
+      Hinv[j][i] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -45,10 +45,11 @@ __device__ __forceinline__ Point load_point(const Problem& p, int b, int n) {
   return q;
 }
 
+template <bool BOUNDS>
 __device__ __forceinline__ void load_camera(const Problem& p, int b, float (&K)[9], Bounds& bd, float& delta) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) K[i] = p.cam[(size_t)b * 9 + i];
-  if (p.lb != nullptr && p.ub != nullptr) {
+  if (BOUNDS) {
     bd.lbx = p.lb[(size_t)b * 2]; bd.lby = p.lb[(size_t)b * 2 + 1];
     bd.ubx = p.ub[(size_t)b * 2]; bd.uby = p.ub[(size_t)b * 2 + 1];
   } else {
@@ -66,7 +67,8 @@ struct NormalEq {
 
 // One point's contribution to (J^T J, J^T r, cost) at pose (R, t): the Jacobian path
 // project_a -> clamp -> Jacobian -> clip -> Huber rescale  (camera.py:10-18,81-143; cost_fun.py:45-84).
-// IEEE division / sqrt throughout: this path feeds the trust-region accept test.
+// IEEE reciprocal / sqrt (no fast-math approximations): this path feeds the trust-region accept test.
+// One correctly rounded 1/z replaces the reference's eight divisions by z (<= 1 ulp apart per term).
 template <int DOF, bool BOUNDS>
 PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R)[9], const float* t, float z_min,
                             float delta, const Bounds& bd, bool clip, float (&acc)[NormalEq<DOF>::NV]) {
@@ -78,14 +80,15 @@ PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R
   const float hy = c0 * K[3] + c1 * K[4] + c2 * K[5];
   const float hz = c0 * K[6] + c1 * K[7] + c2 * K[8];
   const float z = fmaxf(hz, z_min);
-  float px = hx / z, py = hy / z;
+  const float rz = 1.0f / z;
+  float px = hx * rz, py = hy * rz;
   if (BOUNDS) {
     px = fminf(fmaxf(px, bd.lbx), bd.ubx);
     py = fminf(fmaxf(py, bd.lby), bd.uby);
   }
   float J0[DOF], J1[DOF];
-  J0[0] = K[0] / z; J0[1] = K[1] / z; J0[2] = (K[2] - px) / z;
-  J1[0] = K[3] / z; J1[1] = K[4] / z; J1[2] = (K[5] - py) / z;
+  J0[0] = K[0] * rz; J0[1] = K[1] * rz; J0[2] = (K[2] - px) * rz;
+  J1[0] = K[3] * rz; J1[1] = K[4] * rz; J1[2] = (K[5] - py) * rz;
   if (DOF == 6) {
     const float ax = 2.f * xr0, ay = 2.f * xr1, az = 2.f * xr2;
     J0[3] = J0[1] * az - J0[2] * ay;

@@ -76,6 +76,17 @@ __device__ __forceinline__ float wave_max(float x) {
 
 #endif
 
+// Orders this wave's earlier LDS writes before its later LDS reads of OTHER lanes' data.  The hardware executes a
+// wave's DS instructions in order, so no s_barrier is needed; this only stops the compiler from reordering.
+__device__ __forceinline__ void wave_lds_fence() {
+#ifndef EPROPNP_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#else
+  emu::wave_sync();
+#endif
+}
+
 // Sum NV per-thread values over the whole workgroup; every thread receives the totals.
 // `scratch` must hold NV * (blockDim.x / 64) floats of LDS.  Two barriers (none for a single-wave group).
 template <int NV>

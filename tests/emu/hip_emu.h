@@ -196,3 +196,7 @@ struct float2 {
   float x, y;
 };
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct float4 {
+  float x, y, z, w;
+};
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }

@@ -45,7 +45,13 @@ def test_monte_carlo_forward_backward_matches_reference(backend, name):
     # how far the reference's own fp32 arithmetic is from fp64 on this input (the AMIS proposal fit inverts
     # 4x4 matrices of condition ~1e5 in fp32): a second correct implementation cannot be closer than that
     drift = (ref['loss_obj'] - o64['loss_obj']).abs().max().item()
-    assert (r['pose_opt'] - ref['pose_opt']).abs().max().item() <= 1e-4 + 2 * (ref['pose_opt'] - o64['pose_opt']).abs().max().item()
+    # pose: 1e-4, except where a marginal trust-region step flipped at convergence (see tests/test_lm_solver.py):
+    # there the two LM runs must have reached the same cost
+    pose_err = (r['pose_opt'] - ref['pose_opt']).abs().max(-1).values
+    pose_drift = (ref['pose_opt'] - o64['pose_opt']).abs().max(-1).values
+    same_cost = (r['cost'] - ref['cost']).abs() <= 1e-5 * ref['cost'].abs().clamp(min=1.0)
+    assert bool(((pose_err <= 1e-4 + 2 * pose_drift) | same_cost).all()), (pose_err, r['cost'], ref['cost'])
+    assert bool((pose_err <= 2e-3).all())
     torch.testing.assert_close(r['cost_init'], ref['cost_init'], rtol=2e-5, atol=1e-5)
     # KL / Monte-Carlo loss: per object and batch mean
     assert (r['loss_obj'] - ref['loss_obj']).abs().max().item() <= KL_TOL + 2 * drift
@@ -58,12 +64,13 @@ def test_monte_carlo_forward_backward_matches_reference(backend, name):
     assert (r['pose_samples'] - ref['pose_samples']).abs().max().item() <= 2e-2
 
 
-@pytest.mark.parametrize('dof', [6, 4])
-def test_logweights_consistent_with_own_samples(backend, dof):
+@pytest.mark.parametrize('dof,S,K,N', [(6, 64, 4, 96), (4, 64, 4, 96), (6, 60, 3, 70), (6, 200, 2, 130), (4, 100, 1, 33),
+                                       (6, 320, 2, 600)])
+def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
     """Tight check that does not depend on the (ill-conditioned) proposal fit: recompute cost and proposal mixture
     density with the oracle AT THE KERNEL'S OWN samples and fitted proposals; log-weights must agree to 1e-4."""
     from epropnp import functional as F
-    B, N, S, K = 3, 96, 64, 4
+    B = 3
     prob = orc.make_problem(B, N, dof, seed=7)
     noise = orc.make_noise(B, S, K, dof, seed=8)
     p, cam, cf = make_layer_objects(prob, backend)

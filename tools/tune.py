@@ -49,19 +49,13 @@ def worker(B, N, S, K, L, reps=8):
 
 VARIANTS = [
     ('default', {}),
-    ('fwd WS2 WP1 PPL8', {'EPROPNP_FWD_SHAPE': '2,1,8'}),
-    ('fwd WS1 WP1 PPL8', {'EPROPNP_FWD_SHAPE': '1,1,8'}),
+    ('ablate: no sweep', {'EPROPNP_ABLATE': '1'}),
+    ('ablate: no refit', {'EPROPNP_ABLATE': '2'}),
+    ('ablate: no sweep/refit/dens', {'EPROPNP_ABLATE': '7'}),
     ('fwd WS2 WP2 PPL4', {'EPROPNP_FWD_SHAPE': '2,2,4'}),
-    ('fwd WS1 WP2 PPL4', {'EPROPNP_FWD_SHAPE': '1,2,4'}),
-    ('fwd WS2 WP4 PPL2', {'EPROPNP_FWD_SHAPE': '2,4,2'}),
-    ('fwd WS1 WP4 PPL2', {'EPROPNP_FWD_SHAPE': '1,4,2'}),
+    ('fwd WS1 WP1 PPL8', {'EPROPNP_FWD_SHAPE': '1,1,8'}),
     ('bwd W1 PPL8', {'EPROPNP_BWD_SHAPE': '1,8'}),
     ('bwd W2 PPL4', {'EPROPNP_BWD_SHAPE': '2,4'}),
-    ('bwd W4 PPL2', {'EPROPNP_BWD_SHAPE': '4,2'}),
-    ('bwd W8 PPL1', {'EPROPNP_BWD_SHAPE': '8,1'}),
-    ('lm W1 PPL8', {'EPROPNP_LM_SHAPE': '1,8'}),
-    ('lm W2 PPL4', {'EPROPNP_LM_SHAPE': '2,4'}),
-    ('lm W4 PPL2', {'EPROPNP_LM_SHAPE': '4,2'}),
 ]
 
 
