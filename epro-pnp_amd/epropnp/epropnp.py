@@ -50,6 +50,9 @@ class EProPnPBase(torch.nn.Module):
         self.iter_samples = mc_samples // num_iter
         self.eps = eps
         self.normalize = normalize
+        if isinstance(solver, dict):     # EPro-PnP-Det style config: solver=dict(type='LMSolver', ...)
+            from .builder import build_pnp
+            solver = build_pnp(dict(solver), dof=self.dof)
         self.solver = solver
         self.seed = seed
         self._calls = 0

@@ -1,0 +1,185 @@
+"""The Python boundary: same names, signatures, return arity and error behaviour as the reference's `epropnp` package
+(SURVEY.md section 8b), exercised through the same fixtures the reference produced."""
+import inspect
+
+import pytest
+import torch
+
+import epropnp_oracle as orc
+from helpers import load_golden, make_layer_objects, pack_noise
+
+
+def test_public_names_and_signatures():
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.common import evaluate_pnp, pnp_denormalize, pnp_normalize  # noqa: F401
+    from epropnp.cost_fun import AdaptiveHuberPnPCost, HuberPnPCost
+    from epropnp.distributions import AngularCentralGaussian, VonMisesUniformMix  # noqa: F401
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF, cholesky_wrapper  # noqa: F401
+    from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+
+    def params(f):
+        return list(inspect.signature(f).parameters)
+    assert params(LMSolver.__init__)[1:] == ['dof', 'num_iter', 'min_lm_diagonal', 'max_lm_diagonal',
+                                            'min_relative_decrease', 'initial_trust_region_radius',
+                                            'max_trust_region_radius', 'eps', 'normalize', 'init_solver']
+    assert params(LMSolver.solve)[1:] == ['x3d', 'x2d', 'w2d', 'camera', 'cost_fun', 'pose_init', 'cost_init',
+                                         'with_pose_cov', 'with_cost', 'force_init_solve', 'fast_mode']
+    assert params(LMSolver.forward)[1:9] == ['x3d', 'x2d', 'w2d', 'camera', 'cost_fun', 'with_pose_opt_plus',
+                                            'pose_init', 'normalize_override']
+    assert params(RSLMSolver.__init__)[1:4] == ['num_points', 'num_proposals', 'num_iter']
+    assert params(EProPnP6DoF.monte_carlo_forward)[1:8] == ['x3d', 'x2d', 'w2d', 'camera', 'cost_fun', 'pose_init',
+                                                           'force_init_solve']
+    assert params(PerspectiveCamera.__init__)[1:] == ['cam_mats', 'z_min', 'img_shape', 'allowed_border', 'lb', 'ub']
+    assert params(AdaptiveHuberPnPCost.__init__)[1:] == ['delta', 'relative_delta', 'eps']
+    assert params(HuberPnPCost.__init__)[1:] == ['delta', 'eps']
+    layer = EProPnP6DoF(mc_samples=512, num_iter=4, solver=LMSolver(dof=6, num_iter=10))
+    assert len(list(layer.parameters())) == 0 and len(list(layer.buffers())) == 0
+    layer.solver.num_iter = 5          # Det overrides this at test time via rsetattr
+    with pytest.raises(AssertionError):
+        EProPnP4DoF(mc_samples=10, num_iter=4)
+
+
+@pytest.mark.parametrize('name', ['eval6', 'eval6_clip', 'eval4_clip'])
+def test_evaluate_pnp_composite_matches_reference(name):
+    """The framework-level (PyTorch) evaluate_pnp / camera / cost objects reproduce the reference's outputs."""
+    from epropnp.common import evaluate_pnp
+    g = load_golden(name)
+    p, cam, cf = make_layer_objects(g['prob'], 'cpu')
+    res, cost, jac = evaluate_pnp(p['x3d'], p['x2d'], p['w2d'], g['pose'], cam, cf, out_jacobian=True, out_residual=True,
+                                  out_cost=True)
+    torch.testing.assert_close(res, g['res'], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(cost, g['cost'], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(jac, g['jac'], rtol=1e-5, atol=1e-5)
+    buf_j, buf_r, buf_c = torch.empty_like(g['jac']), torch.empty_like(g['res']), torch.empty_like(g['cost'])
+    with torch.no_grad():
+        evaluate_pnp(p['x3d'], p['x2d'], p['w2d'], g['pose'], cam, cf, out_jacobian=buf_j, out_residual=buf_r, out_cost=buf_c)
+    torch.testing.assert_close(buf_j, g['jac'], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(buf_r, g['res'], rtol=1e-6, atol=1e-7)
+    costs = evaluate_pnp(p['x3d'], p['x2d'], p['w2d'], g['poses'], cam, cf, out_cost=True)[1]
+    torch.testing.assert_close(costs, g['costs'], rtol=1e-5, atol=1e-6)
+
+
+def _demo_layer(g, dof, draws, normalize=False):
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+    n_pts, n_prop, n_it = g['rslm_cfg'].tolist()
+    init = RSLMSolver(dof=dof, num_points=n_pts, num_proposals=n_prop, num_iter=n_it)
+    init.draw = lambda w2d: (draws['inds'].to(w2d.device), draws['rot'].to(w2d.device))     # injected randomness
+    cls = EProPnP6DoF if dof == 6 else EProPnP4DoF
+    return cls(mc_samples=int(g['S']), num_iter=int(g['K']), normalize=normalize,
+               solver=LMSolver(dof=dof, num_iter=int(g['lm_iter']), init_solver=init))
+
+
+@pytest.mark.parametrize('name', ['mc6_demo', 'mc4_rslm'])
+def test_demo_config_with_rslm_and_pose_opt_plus(backend, name):
+    """BASELINE config[0] (demo/fit_identity.ipynb shape): RSLM initialisation + LM + AMIS + derivative-regularisation
+    output, force_init_solve=True, against the reference's outputs and input gradients."""
+    g = load_golden(name)
+    dof = int(g['dof'])
+    p, cam, cf = make_layer_objects(g['prob'], backend, relative_delta=0.5)
+    x3d, x2d, w2d = (p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+    cf.set_param(x2d.detach(), w2d)
+    layer = _demo_layer(g, dof, g['rslm'], normalize=bool(g['normalize']))
+    out = layer.monte_carlo_forward(x3d, x2d, w2d, cam, cf, pose_init=p['pose_init'], force_init_solve=True,
+                                    with_pose_opt_plus=True, with_cost=True,
+                                    noise=pack_noise(g['noise'], dof).to(backend))
+    pose_opt, cost, pose_opt_plus, samples, logw, cost_init = out
+    assert pose_opt_plus.requires_grad and logw.requires_grad and cost_init.requires_grad and not samples.requires_grad
+    loss_obj = cost_init + torch.logsumexp(logw, dim=0)
+    total = loss_obj.mean() + 0.1 * (pose_opt_plus * torch.linspace(0.5, 1.5, pose_opt_plus.shape[-1],
+                                                                    device=backend)).sum(-1).mean()
+    total.backward()
+    r, o64 = g['ref'], g['o64']
+    pose_err = (pose_opt.detach().cpu() - r['pose_opt']).abs().max(-1).values
+    same_cost = (cost.cpu() - r['cost']).abs() <= 1e-5 * r['cost'].abs().clamp(min=1.0)
+    drift = (r['pose_opt'] - o64['pose_opt']).abs().max(-1).values
+    assert bool(((pose_err <= 1e-4 + 2 * drift) | same_cost).all()), (pose_err, drift)
+    ok = pose_err <= 1e-4 + 2 * drift
+    if bool(ok.all()):
+        assert (pose_opt_plus.detach().cpu() - r['pose_opt_plus']).abs().max() <= 2e-4 + \
+            2 * (r['pose_opt_plus'] - o64['pose_opt_plus']).abs().max()
+    ldrift = (r['loss_obj'] - o64['loss_obj']).abs().max().item()
+    assert (loss_obj.detach().cpu() - r['loss_obj']).abs().max().item() <= 1e-3 + 2 * ldrift
+    for k, t in (('gx3d', x3d), ('gx2d', x2d), ('gw2d', w2d)):
+        ref_g, o64_g = r[k], o64[k]
+        gd = ((ref_g - o64_g).abs().max() / ref_g.abs().max()).item()
+        err = ((t.grad.cpu() - ref_g).abs().max() / ref_g.abs().max()).item()
+        assert err <= 5e-3 + 3 * gd, (k, err, gd)
+
+
+def test_inference_forward_and_empty_batch(backend):
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    from epropnp.epropnp import EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver
+    prob = orc.make_problem(5, 80, 6, seed=3)
+    p, cam, _ = make_layer_objects(prob, backend)
+    cf = AdaptiveHuberPnPCost(relative_delta=0.5)
+    cf.set_param(p['x2d'], p['w2d'])
+    layer = EProPnP6DoF(mc_samples=64, num_iter=4, solver=LMSolver(dof=6, num_iter=4))
+    # non-contiguous inputs + an expanded single camera matrix, as the reference's callers pass them
+    x3d_t = p['x3d'].transpose(0, 1).contiguous().transpose(0, 1)
+    cam1 = PerspectiveCamera(cam_mats=p['cam_mats'][:1].expand(5, 3, 3))
+    pose_opt, pose_cov, cost, plus = layer(x3d_t, p['x2d'], p['w2d'], cam1, cf, pose_init=p['pose_init'], fast_mode=True)
+    assert pose_opt.shape == (5, 7) and pose_cov is None and cost is None and plus is None
+    assert (pose_opt.cpu()[:, :3] - prob['pose_gt'][:, :3]).norm(dim=-1).max() < 0.2
+    with pytest.raises(NotImplementedError):
+        layer.solver(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], with_pose_cov=True,
+                     normalize_override=True)
+    with pytest.raises(AssertionError):   # no init_solver but pose_init missing
+        layer.solver.solve(p['x3d'], p['x2d'], p['w2d'], cam, cf)
+    # B = 0 keeps the graph (DDP callers rely on it)
+    e3, e2 = (torch.zeros(0, 16, c, device=backend, requires_grad=True) for c in (3, 2))
+    ew = torch.zeros(0, 16, 2, device=backend, requires_grad=True)
+    cam0 = PerspectiveCamera(cam_mats=torch.zeros(0, 3, 3, device=backend))
+    out = layer.monte_carlo_forward(e3, e2, ew, cam0, cf, pose_init=torch.zeros(0, 7, device=backend),
+                                    force_init_solve=False)
+    assert out[3].shape == (64, 0, 7) and out[4].shape == (64, 0) and out[4].requires_grad
+    (out[4].sum() + out[5].sum()).backward()
+    assert e3.grad is not None and e3.grad.shape == e3.shape
+
+
+def test_img_shape_bounds_and_scalar_lb(backend):
+    """camera.set_param(img_shape) gives a python-float lb and a tensor ub (camera.py:57-59)."""
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import HuberPnPCost
+    prob = orc.make_problem(4, 64, 4, seed=12)
+    p = {k: v.to(backend) for k, v in prob.items()}
+    img = torch.tensor([[480., 640.]], device=backend).expand(4, 2)
+    cam = PerspectiveCamera(z_min=0.1, allowed_border=20)
+    cam.set_param(p['cam_mats'], img_shape=img)
+    assert isinstance(cam.lb, float) and isinstance(cam.ub, torch.Tensor)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, HuberPnPCost(delta=p['delta']), 4)
+    cost = F.evaluate_cost(hp, p['pose_init'])
+    ocam = orc.Cam.from_img_shape(prob['cam_mats'], img.cpu(), 0.1, 20)
+    ref = orc.evaluate(prob['x3d'], prob['x2d'], prob['w2d'], prob['pose_init'], ocam, prob['delta'], want_cost=True)[1]
+    torch.testing.assert_close(cost.cpu(), ref, rtol=2e-5, atol=1e-6)
+
+
+def test_distributions_and_loss_modules():
+    from epropnp.distributions import AngularCentralGaussian, VonMisesUniformMix
+    from epropnp.epropnp import cholesky_wrapper
+    from epropnp.losses import MonteCarloPoseLoss
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(5, 4, 4, generator=g)
+    L = torch.linalg.cholesky(A @ A.transpose(-1, -2) + 0.1 * torch.eye(4))
+    acg = AngularCentralGaussian(L)
+    x = acg.rsample((7,))
+    assert x.shape == (7, 5, 4) and (x.norm(dim=-1) - 1).abs().max() < 1e-5
+    torch.testing.assert_close(acg.log_prob(x), orc.acg_logprob(x, L), rtol=1e-5, atol=1e-5)
+    vm = VonMisesUniformMix(torch.tensor([[0.3], [-2.0]]), torch.tensor([[2.0], [9.0]]))
+    xs = vm.sample((8,))
+    assert xs.shape == (8, 2, 1)
+    torch.testing.assert_close(vm.log_prob(xs), orc.vm_mix_logprob(xs, vm.loc, vm.concentration), rtol=1e-5, atol=1e-5)
+    bad = torch.eye(3).repeat(2, 1, 1)
+    bad[1, 0, 0] = -1.0
+    tril = cholesky_wrapper(bad, [1.0, 1.0, 4.0])
+    torch.testing.assert_close(tril[1], torch.diag(torch.tensor([1.0, 1.0, 4.0])))
+    loss = MonteCarloPoseLoss(init_norm_factor=2.0, momentum=0.1)
+    logw, ct = torch.randn(16, 3, generator=g), torch.rand(3, generator=g)
+    v = loss(logw, ct, torch.tensor(4.0))
+    torch.testing.assert_close(loss.norm_factor, torch.tensor(2.2))
+    torch.testing.assert_close(v, orc.mc_pose_loss(logw, ct, 2.2), rtol=1e-6, atol=1e-6)
+    v2 = loss(logw, ct, 4.0, weight=torch.tensor([1.0, 0.0, 2.0]), avg_factor=3.0)
+    assert v2.dim() == 0

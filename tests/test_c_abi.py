@@ -1,0 +1,65 @@
+"""The C-ABI shared library exists after build(), exports every symbol include/*.h declares, and refuses to compute on
+the host (no CPU fallback).  No GPU needed: nothing is launched."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'epro-pnp_amd', 'lib', 'libepropnp_hip.so')
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'epropnp_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(epropnp_[a-z_]+)\s*\(', txt)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(LIB):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('epropnp_build', os.path.join(ROOT, 'epro-pnp_amd', 'build.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    return ctypes.CDLL(LIB)
+
+
+def test_exports_match_header(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 8
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in include/epropnp_hip.h but not exported'
+    from epropnp import _hip
+    assert sorted(_hip.EXPORTS) == syms
+
+
+def test_abi_version_and_noise_stride(lib):
+    assert lib.epropnp_abi_version() == 1
+    assert lib.epropnp_noise_stride(6) == 8 and lib.epropnp_noise_stride(4) == 52 and lib.epropnp_noise_stride(5) == -1
+
+
+def test_argument_validation_without_launch(lib):
+    from epropnp import _hip
+    lib.epropnp_last_error.restype = ctypes.c_char_p
+    prob = _hip.Problem(None, None, None, None, None, None, None, 0.1, 4, 16, 5)
+    rc = lib.epropnp_evaluate_cost(ctypes.byref(prob), None, 1, None, None)
+    assert rc == -1 and b'dof' in lib.epropnp_last_error()
+    prob = _hip.Problem(None, None, None, None, None, None, None, 0.1, 4, 16, 6)
+    rc = lib.epropnp_evaluate_cost(ctypes.byref(prob), None, 1, None, None)
+    assert rc == -1 and b'NULL' in lib.epropnp_last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    from epropnp import _hip
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import HuberPnPCost
+    from epropnp.levenberg_marquardt import LMSolver
+    _hip._use_emulation_library(None)
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match='HIP device'):
+        LMSolver(dof=6, num_iter=1).solve(z(2, 8, 3), z(2, 8, 2), z(2, 8, 2), PerspectiveCamera(cam_mats=torch.eye(3).expand(2, 3, 3)),
+                                          HuberPnPCost(), pose_init=z(2, 7))
