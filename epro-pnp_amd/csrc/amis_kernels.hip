@@ -746,9 +746,9 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   while (64 * WP * ppl < d.N) ppl *= 2;
   const int ntile = (s + 63) / 64;
   int WS = 1;
-  while (WS * 2 <= ntile && WS * 2 * WP <= 16) WS *= 2;
-  // few objects: trade points-per-lane for more point-waves to fill the machine
-  while ((long)d.B * WS * WP < 2048 && ppl > 1 && WS * WP * 2 <= 16) {
+  while (WS * 2 <= ntile && WS * 2 * WP <= 8) WS *= 2;
+  // few objects: trade points-per-lane for more point-waves to fill the machine (<= 8 waves: no register spills)
+  while ((long)d.B * WS * WP < 2048 && ppl > 1 && WS * WP * 2 <= 8) {
     WP *= 2;
     ppl /= 2;
   }

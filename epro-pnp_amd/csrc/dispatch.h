@@ -11,7 +11,10 @@ using ic = std::integral_constant<int, V>;
 template <class F>
 inline int dispatch_shape(int dof, int ppl, bool bnd, int waves, F&& f) {
   auto d3 = [&](auto DOF, auto PPL, auto BND) -> int {
-    return (waves <= 4) ? f(DOF, PPL, BND, ic<4>{}) : f(DOF, PPL, BND, ic<16>{});
+    // block-size class: the register budget per lane is 512 / (waves per SIMD) -> 512 / 256 / 128 VGPRs
+    if (waves <= 4) return f(DOF, PPL, BND, ic<4>{});
+    if (waves <= 8) return f(DOF, PPL, BND, ic<8>{});
+    return f(DOF, PPL, BND, ic<16>{});
   };
   auto d2 = [&](auto DOF, auto PPL) -> int {
     return bnd ? d3(DOF, PPL, std::true_type{}) : d3(DOF, PPL, std::false_type{});

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
                                                                float* __restrict__ cost_out, int* __restrict__ accept_out) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
-  __shared__ float scratch[NV * 16];
+  // dynamic LDS: transposed reduction scratch (waves * kSumTStride<NV>) for <= 4 waves, NV * 16 for the DPP fallback
+  PNP_DYN_SMEM(float, scratch);
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
 
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, z_min, delta, bd, clip, acc);
-    block_sum<NV>(acc, scratch);
+    if (MAXW <= 4) block_sum_t<NV>(acc, scratch); else block_sum<NV>(acc, scratch);
   };
 
   float cur[NV];
@@ -201,7 +202,10 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),
-               grid, block, 0, st, d, k, pose_init, pose_opt, pose_cov, cost, accept_mask);
+               grid, block,
+               sizeof(float) * (decltype(MAXW)::value <= 4 ? s.waves * kSumTStride<NormalEq<decltype(DOF)::value>::NV>
+                                                           : NormalEq<decltype(DOF)::value>::NV * 16),
+               st, d, k, pose_init, pose_opt, pose_cov, cost, accept_mask);
     return 0;
   });
   return check_launch("lm_solve_kernel");

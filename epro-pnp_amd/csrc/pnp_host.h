@@ -54,8 +54,10 @@ inline Shape choose_shape(int B, int N, int max_ppl = 8, int want_waves_total = 
   Shape s;
   int wmin = 1;
   while (64 * wmin * max_ppl < N && wmin < 16) wmin *= 2;
+  // 16-wave (1024-thread) groups are limited to 128 VGPRs per lane and spill: only used when N demands it
   int wmax = 1;
-  while (64 * wmax < N && wmax < 16) wmax *= 2;
+  while (64 * wmax < N && wmax < 8) wmax *= 2;
+  if (wmax < wmin) wmax = wmin;
   int w = wmin;
   while (w < wmax && (long)B * w < want_waves_total) w *= 2;
   s.waves = w;

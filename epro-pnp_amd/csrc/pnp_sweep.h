@@ -67,8 +67,9 @@ struct NormalEq {
 
 // One point's contribution to (J^T J, J^T r, cost) at pose (R, t): the Jacobian path
 // project_a -> clamp -> Jacobian -> clip -> Huber rescale  (camera.py:10-18,81-143; cost_fun.py:45-84).
-// IEEE reciprocal / sqrt (no fast-math approximations): this path feeds the trust-region accept test.
-// One correctly rounded 1/z replaces the reference's eight divisions by z (<= 1 ulp apart per term).
+// 1/z, |r| and the Huber rescaling come from the hardware rcp / rsq seeds plus one Newton step each (<= 1 ulp, no
+// IEEE divide/sqrt expansions: those were a quarter of this loop's instructions).  One reciprocal replaces the
+// reference's eight divisions by z; gamma = sqrt(min(delta / rho, 1)) reuses 1/rho from the norm.
 template <int DOF, bool BOUNDS>
 PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R)[9], const float* t, float z_min,
                             float delta, const Bounds& bd, bool clip, float (&acc)[NormalEq<DOF>::NV]) {
@@ -80,7 +81,8 @@ PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R
   const float hy = c0 * K[3] + c1 * K[4] + c2 * K[5];
   const float hz = c0 * K[6] + c1 * K[7] + c2 * K[8];
   const float z = fmaxf(hz, z_min);
-  const float rz = 1.0f / z;
+  float rz = fast_rcp(z);
+  rz = rz * fmaf(-z, rz, 2.0f);
   float px = hx * rz, py = hy * rz;
   if (BOUNDS) {
     px = fminf(fmaxf(px, bd.lbx), bd.ubx);
@@ -103,8 +105,14 @@ PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R
   }
   const float rx = (px - p.u) * p.wu;
   const float ry = (py - p.v) * p.wv;
-  const float rho = sqrtf(rx * rx + ry * ry);
-  const float gam = sqrtf(fminf(delta / fmaxf(rho, 1e-10f), 1.0f));
+  const float s2 = rx * rx + ry * ry;
+  const float ir = fast_rsqrt(fmaxf(s2, 1e-36f));             // ~ 1 / rho
+  float rho = s2 * ir;
+  rho = fmaf(0.5f * ir, fmaf(-rho, rho, s2), rho);            // Newton step on sqrt
+  const float q = fminf(delta * ir, 1.0f);                    // min(delta / max(rho, eps), 1); eps = 1e-10 never binds first
+  const float iq = fast_rsqrt(fmaxf(q, 1e-36f));
+  float gam = q * iq;
+  gam = fmaf(0.5f * iq, fmaf(-gam, gam, q), gam);
   float s0 = p.wu * gam, s1 = p.wv * gam;
   if (clip) {
     const bool zc = (z == z_min);

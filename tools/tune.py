@@ -49,13 +49,8 @@ def worker(B, N, S, K, L, reps=8):
 
 VARIANTS = [
     ('default', {}),
-    ('ablate: no sweep', {'EPROPNP_ABLATE': '1'}),
-    ('ablate: no refit', {'EPROPNP_ABLATE': '2'}),
-    ('ablate: no sweep/refit/dens', {'EPROPNP_ABLATE': '7'}),
-    ('fwd WS2 WP2 PPL4', {'EPROPNP_FWD_SHAPE': '2,2,4'}),
-    ('fwd WS1 WP1 PPL8', {'EPROPNP_FWD_SHAPE': '1,1,8'}),
-    ('bwd W1 PPL8', {'EPROPNP_BWD_SHAPE': '1,8'}),
-    ('bwd W2 PPL4', {'EPROPNP_BWD_SHAPE': '2,4'}),
+    ('lm W1 PPL8', {'EPROPNP_LM_SHAPE': '1,8'}),
+    ('lm W2 PPL4', {'EPROPNP_LM_SHAPE': '2,4'}),
 ]
 
 
