@@ -176,7 +176,9 @@ PNP_FN float proposal_logprob(const float* rec, const float* smp /*PL*/) {
 
 // Best & Fisher (1979) von Mises draw with at most kVmTries attempts; u = 3 uniforms per attempt.
 // Same bounded procedure as oracle/epropnp_oracle.py:vm_sample_bounded.
-PNP_FN float vm_sample_bounded(float loc, float kappa, const float* u /* kVmTries*3 */) {
+// `next(a, u1, u2, u3)` supplies the three uniforms of attempt a (from injected noise or Philox): no per-lane array.
+template <class Uniforms>
+PNP_FN float vm_sample_bounded(float loc, float kappa, Uniforms next) {
   const double k = fmax((double)kappa, 1e-12);
   const double tau = 1.0 + sqrt(1.0 + 4.0 * k * k);
   const double rho = (tau - sqrt(2.0 * tau)) / (2.0 * k);
@@ -184,7 +186,9 @@ PNP_FN float vm_sample_bounded(float loc, float kappa, const float* u /* kVmTrie
   double x = 0.0;
   bool done = false;
   for (int a = 0; a < kVmTries; ++a) {
-    const double u1 = u[a * 3], u2 = u[a * 3 + 1], u3 = u[a * 3 + 2];
+    float f1, f2, f3;
+    next(a, f1, f2, f3);
+    const double u1 = f1, u2 = f2, u3 = f3;
     const double zc = cos(3.141592653589793 * u1);
     const double f = (1.0 + r * zc) / (r + zc);
     const double c = k * (r - f);
@@ -224,15 +228,12 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
   const float* rec = cx.prop + it * kPropStride;
   for (int n = tid; n < s; n += T) {
     const int m = it * s + n;
-    float z[3], chi2, g[4], uvm[3 * kVmTries];
+    float z[3], chi2, g[4];
     if (noise != nullptr) {
       const float* nz = noise + (((size_t)b * K + it) * s + n) * NZ;
       z[0] = nz[0]; z[1] = nz[1]; z[2] = nz[2]; chi2 = nz[3];
       if (DOF == 6) {
         g[0] = nz[4]; g[1] = nz[5]; g[2] = nz[6]; g[3] = nz[7];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3 * kVmTries; ++i) uvm[i] = nz[4 + i];
       }
     } else {
       const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
@@ -248,13 +249,6 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
       chi2 = nrm[3] * nrm[3] + nrm[4] * nrm[4] + nrm[5] * nrm[5];   // Chi2(3)
       if (DOF == 6) {
         g[0] = nrm[6]; g[1] = nrm[7]; g[2] = nrm[8]; g[3] = nrm[9];
-      } else {
-#pragma unroll
-        for (int q = 0; q < (3 * kVmTries) / 4; ++q) {
-          const Philox4 r = philox4x32_10((uint32_t)b, (uint32_t)m, c2, c3base + 8 + q, k0, k1);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) uvm[q * 4 + e] = (float)(r.v[e] >> 8) * (1.0f / 16777216.0f);
-        }
       }
     }
     float ps[PL];
@@ -277,8 +271,27 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
       }
     } else {          // first round(0.25 s) samples uniform, the rest von Mises  (distributions.py:65-71)
       const int n_u = (int)rintf(0.25f * (float)s);
-      if (n < n_u) ps[3] = (uvm[0] * 2.0f - 1.0f) * 3.14159265358979f;
-      else ps[3] = vm_sample_bounded(rec[16], rec[17], uvm);
+      // uniforms of attempt `att`: injected (row layout [z, chi2, 16 x (u1,u2,u3)]) or one Philox block per attempt
+      auto uniforms = [&](int att, float& u1, float& u2, float& u3) {
+        if (noise != nullptr) {
+          const float* nz = noise + (((size_t)b * K + it) * s + n) * NZ + 4 + 3 * att;
+          u1 = nz[0]; u2 = nz[1]; u3 = nz[2];
+        } else {
+          const Philox4 r = philox4x32_10((uint32_t)b, (uint32_t)m, (uint32_t)a.offset,
+                                          (uint32_t)(a.offset >> 32) * 64u + 8u + (uint32_t)att, (uint32_t)a.seed,
+                                          (uint32_t)(a.seed >> 32));
+          u1 = (float)(r.v[0] >> 8) * (1.0f / 16777216.0f);
+          u2 = (float)(r.v[1] >> 8) * (1.0f / 16777216.0f);
+          u3 = (float)(r.v[2] >> 8) * (1.0f / 16777216.0f);
+        }
+      };
+      if (n < n_u) {
+        float u1, u2, u3;
+        uniforms(0, u1, u2, u3);
+        ps[3] = (u1 * 2.0f - 1.0f) * 3.14159265358979f;
+      } else {
+        ps[3] = vm_sample_bounded(rec[16], rec[17], uniforms);
+      }
     }
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
@@ -353,42 +366,75 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     return;
   }
 #endif
+  // One pass over the samples gathers every first/second moment that does not depend on a matrix inverse:
+  // Z = sum e, sum e d, sum e d d^T with d = t - (previous mode) as pivot (keeps the E[dd^T] - dd^T cancellation
+  // benign), and -- since the ACG fixed point starts from Sigma = I -- the first maximum-likelihood step as well.
   float mx = -INFINITY;
   for (int m = tid; m < M; m += T) mx = fmaxf(mx, lgw[m]);
   mx = block_max(mx, red);
-  float s4[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int m = tid; m < M; m += T) {
-    const float e = expf(lgw[m] - mx);
-    s4[0] += e;
-    s4[1] += e * smp[0 * S + m];
-    s4[2] += e * smp[1 * S + m];
-    s4[3] += e * smp[2 * S + m];
-  }
-  block_sum<4>(s4, red);
-  const float invZ = 1.0f / s4[0];
-  const float mu0 = s4[1] * invZ, mu1 = s4[2] * invZ, mu2 = s4[3] * invZ;
+  const float p0 = rec[0], p1 = rec[1], p2 = rec[2];
   if (DOF == 6) {
-    float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mom[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) mom[i] = 0.f;
     for (int m = tid; m < M; m += T) {
-      const float w = expf(lgw[m] - mx) * invZ;
-      const float d0 = smp[m] - mu0, d1 = smp[S + m] - mu1, d2 = smp[2 * S + m] - mu2;
-      c6[0] += w * d0 * d0; c6[1] += w * d1 * d0; c6[2] += w * d1 * d1;
-      c6[3] += w * d2 * d0; c6[4] += w * d2 * d1; c6[5] += w * d2 * d2;
+      const float e = expf(lgw[m] - mx);
+      const float d0 = smp[m] - p0, d1 = smp[S + m] - p1, d2 = smp[2 * S + m] - p2;
+      mom[0] += e;
+      mom[1] += e * d0; mom[2] += e * d1; mom[3] += e * d2;
+      mom[4] += e * d0 * d0; mom[5] += e * d1 * d0; mom[6] += e * d1 * d1;
+      mom[7] += e * d2 * d0; mom[8] += e * d2 * d1; mom[9] += e * d2 * d2;
+      const float q0 = smp[3 * S + m], q1 = smp[4 * S + m], q2 = smp[5 * S + m], q3 = smp[6 * S + m];
+      const float iw = e / fmaxf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3, a.eps);    // M = q^T I q
+      mom[10] += iw * q0 * q0;
+      mom[11] += iw * q1 * q0; mom[12] += iw * q1 * q1;
+      mom[13] += iw * q2 * q0; mom[14] += iw * q2 * q1; mom[15] += iw * q2 * q2;
+      mom[16] += iw * q3 * q0; mom[17] += iw * q3 * q1; mom[18] += iw * q3 * q2; mom[19] += iw * q3 * q3;
+      mom[20] += iw;
     }
-    block_sum<6>(c6, red);
-    // ACG maximum-likelihood fixed point, Sigma_0 = I
-    float Si[10] = {1.f, 0.f, 1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};   // packed lower of Sigma^-1
+    block_sum<21>(mom, red);
+    const float invZ = 1.0f / mom[0];
+    const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
+    const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;
+    float c6[6];
+    c6[0] = mom[4] * invZ - dl0 * dl0; c6[1] = mom[5] * invZ - dl1 * dl0; c6[2] = mom[6] * invZ - dl1 * dl1;
+    c6[3] = mom[7] * invZ - dl2 * dl0; c6[4] = mom[8] * invZ - dl2 * dl1; c6[5] = mom[9] * invZ - dl2 * dl2;
     float acc[11];
-    for (int r = 0; r < a.mle_iter; ++r) {
+#pragma unroll
+    for (int i = 0; i < 11; ++i) acc[i] = mom[10 + i];
+    float Si[10];
+    for (int r = 1; r < a.mle_iter; ++r) {
+      // Sigma^-1 of the previous fixed-point iterate (one lane, fp64), broadcast through LDS
+      if (tid == 0) {
+        double Sg[4][4], Sgi[4][4], invd[4];
+        const double inorm = 1.0 / (double)acc[10];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            const double v = (double)acc[tri(i, j)] * inorm + ((i == j) ? (double)a.eps : 0.0);
+            Sg[i][j] = v;
+            Sg[j][i] = v;
+          }
+        spd_inverse<4, double>(Sg, invd, Sgi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) red[tri(i, j)] = (float)Sgi[i][j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 10; ++i) Si[i] = red[i];
+      __syncthreads();
 #pragma unroll
       for (int i = 0; i < 11; ++i) acc[i] = 0.f;
       for (int m = tid; m < M; m += T) {
-        const float w = expf(lgw[m] - mx) * invZ;
+        const float e = expf(lgw[m] - mx);
         const float q0 = smp[3 * S + m], q1 = smp[4 * S + m], q2 = smp[5 * S + m], q3 = smp[6 * S + m];
         const float Mq = Si[0] * q0 * q0 + Si[2] * q1 * q1 + Si[5] * q2 * q2 + Si[9] * q3 * q3 +
                          2.f * (Si[1] * q1 * q0 + Si[3] * q2 * q0 + Si[4] * q2 * q1 + Si[6] * q3 * q0 + Si[7] * q3 * q1 +
                                 Si[8] * q3 * q2);
-        const float iw = w / fmaxf(Mq, a.eps);
+        const float iw = e / fmaxf(Mq, a.eps);     // the reference normalises w first; the ratio below is scale-free
         acc[10] += iw;
         acc[0] += iw * q0 * q0;
         acc[1] += iw * q1 * q0; acc[2] += iw * q1 * q1;
@@ -396,29 +442,6 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
         acc[6] += iw * q3 * q0; acc[7] += iw * q3 * q1; acc[8] += iw * q3 * q2; acc[9] += iw * q3 * q3;
       }
       block_sum<11>(acc, red);
-      if (r + 1 < a.mle_iter) {   // need Sigma^-1 for the next fixed-point step
-        if (tid == 0) {
-          double Sg[4][4], Sgi[4][4], invd[4];
-          const double inorm = 1.0 / (double)acc[10];
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-              const double v = (double)acc[tri(i, j)] * inorm + ((i == j) ? (double)a.eps : 0.0);
-              Sg[i][j] = v;
-              Sg[j][i] = v;
-            }
-          spd_inverse<4, double>(Sg, invd, Sgi);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) red[tri(i, j)] = (float)Sgi[i][j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 10; ++i) Si[i] = red[i];
-        __syncthreads();
-      }
     }
     if (tid == 0) {
       nrec[0] = mu0; nrec[1] = mu1; nrec[2] = mu2;
@@ -446,17 +469,29 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       fit_rotation_acg(Sg, a.dispersion, nrec);
     }
   } else {
-    float c8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mom[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) mom[i] = 0.f;
     for (int m = tid; m < M; m += T) {
-      const float w = expf(lgw[m] - mx) * invZ;
-      const float d0 = smp[m] - mu0, d1 = smp[S + m] - mu1, d2 = smp[2 * S + m] - mu2;
-      c8[0] += w * d0 * d0; c8[1] += w * d1 * d0; c8[2] += w * d1 * d1;
-      c8[3] += w * d2 * d0; c8[4] += w * d2 * d1; c8[5] += w * d2 * d2;
+      const float e = expf(lgw[m] - mx);
+      const float d0 = smp[m] - p0, d1 = smp[S + m] - p1, d2 = smp[2 * S + m] - p2;
+      mom[0] += e;
+      mom[1] += e * d0; mom[2] += e * d1; mom[3] += e * d2;
+      mom[4] += e * d0 * d0; mom[5] += e * d1 * d0; mom[6] += e * d1 * d1;
+      mom[7] += e * d2 * d0; mom[8] += e * d2 * d1; mom[9] += e * d2 * d2;
       const float yaw = smp[3 * S + m];
-      c8[6] += w * sinf(yaw);
-      c8[7] += w * cosf(yaw);
+      mom[10] += e * sinf(yaw);
+      mom[11] += e * cosf(yaw);
     }
-    block_sum<8>(c8, red);
+    block_sum<12>(mom, red);
+    const float invZ = 1.0f / mom[0];
+    const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
+    const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;
+    float c8[8];
+    c8[0] = mom[4] * invZ - dl0 * dl0; c8[1] = mom[5] * invZ - dl1 * dl0; c8[2] = mom[6] * invZ - dl1 * dl1;
+    c8[3] = mom[7] * invZ - dl2 * dl0; c8[4] = mom[8] * invZ - dl2 * dl1; c8[5] = mom[9] * invZ - dl2 * dl2;
+    c8[6] = mom[10] * invZ;
+    c8[7] = mom[11] * invZ;
     if (tid == 0) {
       nrec[0] = mu0; nrec[1] = mu1; nrec[2] = mu2;
       double Ct[3][3];

@@ -1,0 +1,218 @@
+// amis_forward_mfma.hip -- AMIS forward with the pose x point projection on the matrix cores.
+//
+// Same algorithm and LDS-resident sampler state as amis_forward_kernel (amis_kernels.hip); only the cost sweep
+// differs.  The projection h = (K R | K t) (X,Y,Z,1)^T of 16 poses x 16 points is ONE v_mfma_f32_16x16x4_f32 per
+// image row (x, y, z): exact f32 (a k-ordered fmaf chain), issued on the matrix pipe, which runs concurrently with
+// the VALU.  That removes the 9 FMAs of the ~21 VALU instructions per point-pose; what stays on the VALU is the
+// perspective divide, the weighted residual and the Huber kernel (2 transcendentals + ~12 simple ops).
+//   A operand (16 poses x 4): lane l holds row[pose l&15][k = l>>4]       <- LDS pose table, x | y | z rows
+//   B operand (4 x 16 points): lane l holds (X,Y,Z,1)[k = l>>4] of point l&15 <- LDS point table
+//   D (16 x 16): lane l holds poses 4*(l>>4)+r, r = 0..3, at point l&15   -> 4 point-poses per lane per tile
+// Points are no longer register-resident (no N limit; chunks of <= kChunk points stream through LDS), waves split
+// the pose tiles, and a pose's cost is the DPP row-sum over the 16 lanes that hold its 16 points.
+#include "amis_common.h"
+#include "dispatch.h"
+
+namespace pnp {
+
+#ifndef EPROPNP_EMU
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#else
+typedef floatx4_emu floatx4;
+#endif
+
+__device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
+#ifndef EPROPNP_EMU
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#else
+  return emu::mfma_16x16x4(a, b, c);
+#endif
+}
+
+// sum over the 16 lanes of a DPP row (every lane of the row receives it)
+__device__ __forceinline__ float row_sum16(float x) {
+#ifndef EPROPNP_EMU
+  x += dpp_mov<0x128>(x);
+  x += dpp_mov<0x124>(x);
+  x += dpp_mov<0x122>(x);
+  x += dpp_mov<0x121>(x);
+  return x;
+#else
+  for (int m : {8, 4, 2, 1}) {
+    const int l = lane_id();
+    x += emu::shfl(x, (l & ~15) | ((l + m) & 15));
+  }
+  return x;
+#endif
+}
+
+constexpr int kChunk = 1024;   // points per LDS chunk (32 KiB of point tables)
+
+struct MfmaShape {
+  int chunk;     // points per chunk, multiple of 16
+  int s16;       // samples per iteration rounded up to 16
+};
+
+template <int DOF, bool BOUNDS>
+__global__ __launch_bounds__(512) void amis_forward_mfma_kernel(Problem p, AmisParams a, MfmaShape sh,
+                                                                  const float* __restrict__ pose_opt,
+                                                                  const float* __restrict__ pose_cov,
+                                                                  const float* __restrict__ noise,
+                                                                  float* __restrict__ pose_samples,
+                                                                  float* __restrict__ logweights,
+                                                                  float* __restrict__ proposals) {
+  constexpr int PL = PoseLen<DOF>::value;
+  const int b = object_of_block(p.B);
+  if (b >= p.B) return;
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), W = T >> 6;
+  const int S = a.S, K = a.K, s = S / K, s16 = sh.s16, NC = sh.chunk;
+
+  PNP_DYN_SMEM(float, smem);
+  float* ptab = smem;                 // [s16][12]   x | y | z rows of (K R | K t)          (16-B aligned)
+  float* pB = ptab + 12 * s16;        // [NC][4]     (X, Y, Z, 1)                            (16-B aligned)
+  float* pW = pB + 4 * NC;            // [NC][4]     (wu, wv, -u wu, -v wv)                  (16-B aligned)
+  float* smp = pW + 4 * NC;           // [PL][S]
+  float* cst = smp + PL * S;          // [S]
+  float* mixl = cst + S;              // [S]
+  float* lgw = mixl + S;              // [S]
+  float* cpart = lgw + S;             // [s16]
+  float* prop = cpart + s16;          // [K][kPropStride]
+  float* red = prop + K * kPropStride;   // [256]
+
+  float Kc[9], delta;
+  Bounds bd;
+  load_camera<BOUNDS>(p, b, Kc, bd, delta);
+  const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
+
+  for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last tile
+  if (tid == 0) initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop);
+  const int nchunk = (p.N + NC - 1) / NC;
+  auto load_chunk = [&](int c0) {
+    const int cnt = min(NC, ((p.N - c0 + 15) >> 4) << 4);
+    for (int n = tid; n < cnt; n += T) {
+      const Point q = load_point(p, b, c0 + n);          // zero weight beyond N
+      reinterpret_cast<float4*>(pB)[n] = make_float4(q.X, q.Y, q.Z, 1.0f);
+      reinterpret_cast<float4*>(pW)[n] = make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
+    }
+  };
+  if (nchunk == 1) load_chunk(0);
+  __syncthreads();
+
+  AmisCtx cx;
+  cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
+  cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b;
+
+  const int g4 = (lane >> 4) * 4, col = lane & 15, kk = lane >> 4;
+  for (int it = 0; it < K; ++it) {
+    amis_draw<DOF>(cx, p, a, it, Kc, noise, pose_samples);
+    __syncthreads();
+
+    // ---------------- cost sweep: 16 x 16 (pose, point) tiles on the matrix pipe ----------------
+#ifdef PNP_TUNING
+    if (a.ablate & 1) {
+      for (int n = tid; n < s; n += T) cpart[n] = 1.0f;
+    } else
+#endif
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int c0 = ch * NC;
+      if (nchunk > 1) {
+        if (ch > 0 || it > 0) __syncthreads();    // everyone is done with the previous chunk
+        load_chunk(c0);
+        __syncthreads();
+      }
+      const int npt = (min(NC, p.N - c0) + 15) >> 4;
+      for (int t = wv; t < (s16 >> 4); t += W) {
+        const float* arow = ptab + 12 * (t * 16 + col) + kk;
+        const float ax = arow[0], ay = arow[4], az = arow[8];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+        // software pipeline: tile q+1's operands are fetched and its three MFMAs issued before tile q's VALU work,
+        // so the matrix pipe (32 cycles per MFMA) runs underneath the ~55 VALU instructions of the previous tile
+        float bq = pB[4 * col + kk];
+        float4 w4 = reinterpret_cast<const float4*>(pW)[col];
+        floatx4 hx = mfma_16x16x4(ax, bq, zero), hy = mfma_16x16x4(ay, bq, zero), hz = mfma_16x16x4(az, bq, zero);
+        for (int q = 0; q < npt; ++q) {
+          const int qn = min(q + 1, npt - 1);
+          const float bn = pB[4 * (qn * 16 + col) + kk];
+          const float4 wn = reinterpret_cast<const float4*>(pW)[qn * 16 + col];
+          const floatx4 hxn = mfma_16x16x4(ax, bn, zero);
+          const floatx4 hyn = mfma_16x16x4(ay, bn, zero);
+          const floatx4 hzn = mfma_16x16x4(az, bn, zero);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // compare+select instead of fmaxf: v_max_f32 issues at half rate and needs a canonicalising
+            // v_max(x, x) on an MFMA result first (IEEE mode); a NaN depth maps to z_min either way
+            const float zc = (hz[r] > zmin_v) ? hz[r] : zmin_v;
+            const float rz = fast_rcp(zc);
+            float px = hx[r] * rz, py = hy[r] * rz;
+            if (BOUNDS) {
+              px = fminf(fmaxf(px, bd.lbx), bd.ubx);
+              py = fminf(fmaxf(py, bd.lby), bd.uby);
+            }
+            const float rx = fmaf(px, w4.x, w4.z);
+            const float ry = fmaf(py, w4.y, w4.w);
+            const float rho = fast_sqrt(fmaf(rx, rx, ry * ry));
+            const float m = fminf(rho, delta_v);
+            acc[r] = fmaf(m, fmaf(-0.5f, m, rho), acc[r]);
+          }
+          hx = hxn; hy = hyn; hz = hzn; w4 = wn;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
+        if (col == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pose = t * 16 + g4 + r;
+            cpart[pose] = (ch == 0) ? acc[r] : cpart[pose] + acc[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    amis_weights<DOF>(cx, a, it, 1);
+    __syncthreads();
+    if (it == K - 1) break;
+    amis_refit<DOF>(cx, a, it);
+  }
+
+  for (int m = tid; m < S; m += T) logweights[(size_t)m * p.B + b] = lgw[m];
+  if (proposals != nullptr)
+    for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
+}
+
+int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_params* am, const float* pose_opt,
+                             const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
+                             float* proposals, hipStream_t st) {
+  const Problem d = to_device_problem(prob);
+  const int S = am->mc_samples, K = am->num_iter, s = S / K;
+  const int PL = prob->dof == 6 ? 7 : 4;
+  MfmaShape sh;
+  sh.s16 = ((s + 15) / 16) * 16;
+  sh.chunk = ((d.N + 15) / 16) * 16;
+  if (sh.chunk > kChunk) sh.chunk = kChunk;
+  const int tiles = sh.s16 / 16;
+  int waves = 4;                       // pose tiles are dealt round-robin to the waves
+  { int ov[1]; if (env_ints("EPROPNP_FWD_WAVES", ov, 1) && ov[0] >= 1 && ov[0] <= 8) waves = ov[0]; }
+  while (waves > 1 && waves > tiles) waves /= 2;
+  AmisParams k;
+  k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
+  k.seed = am->seed; k.offset = am->offset; k.ablate = 0;
+  { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
+  const size_t smem = sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (size_t)PL * S + 3 * (size_t)S +
+                                       (size_t)sh.s16 + (size_t)K * kPropStride + 256);
+  if (smem > 160 * 1024) return fail(EPROPNP_EINVAL, "amis_forward: mc_samples %d needs %zu B of LDS (> 160 KiB)", S, smem);
+  const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
+  dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+    auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value>;
+#ifndef EPROPNP_EMU
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+    PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals);
+    return 0;
+  });
+  return check_launch("amis_forward_mfma_kernel");
+}
+
+}  // namespace pnp

@@ -309,6 +309,11 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
                 am->mc_samples, am->num_iter);
   if (prob->num_obj == 0) return EPROPNP_OK;
   if (!pose_opt || !pose_cov || !pose_samples || !logweights) return fail(EPROPNP_EINVAL, "amis_forward: NULL pointer");
+  {   // default: projection on the matrix cores (amis_forward_mfma.hip); EPROPNP_FWD_IMPL=valu keeps the VALU sweep
+    const char* impl = getenv("EPROPNP_FWD_IMPL");
+    if (!(impl && impl[0] == 'v'))
+      return launch_amis_forward_mfma(prob, am, pose_opt, pose_cov, noise, pose_samples, logweights, proposals, st);
+  }
   if (prob->num_pts > kMaxResidentPoints)
     return fail(EPROPNP_EINVAL, "amis_forward: num_pts %d exceeds the register-resident limit %d", prob->num_pts,
                 kMaxResidentPoints);

@@ -89,6 +89,9 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
 int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
                         const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
                         float* proposals, hipStream_t st);
+int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
+                             const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
+                             float* proposals, hipStream_t st);
 int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
                          int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
                          float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);

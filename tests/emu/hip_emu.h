@@ -200,3 +200,38 @@ struct float4 {
   float x, y, z, w;
 };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+// v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) B(4x16) + C.  Lane l holds A[l&15][l>>4], B[l>>4][l&15] and
+// D[4*(l>>4)+r][l&15], r = 0..3.  k-ordered fmaf chain, like the hardware.
+typedef float floatx4_emu __attribute__((vector_size(16)));
+namespace emu {
+inline floatx4_emu mfma_16x16x4(float a, float b, floatx4_emu c) {
+  Block& blk_ = blk();
+  unsigned t = blk_.fibers[blk_.cur].tid.x;
+  int w = t / 64, lane = t % 64;
+  float av[4][4], bv[4];
+  uint64_t bits = 0;
+  std::memcpy(&bits, &a, 4);
+  blk_.w_buf[w][lane] = bits;
+  wave_sync();
+  for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 4; ++k) {
+      uint64_t g = blk_.w_buf[w][k * 16 + 4 * (lane >> 4) + r];
+      std::memcpy(&av[r][k], &g, 4);
+    }
+  wave_sync();
+  bits = 0;
+  std::memcpy(&bits, &b, 4);
+  blk_.w_buf[w][lane] = bits;
+  wave_sync();
+  for (int k = 0; k < 4; ++k) {
+    uint64_t g = blk_.w_buf[w][k * 16 + (lane & 15)];
+    std::memcpy(&bv[k], &g, 4);
+  }
+  wave_sync();
+  floatx4_emu d = c;
+  for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 4; ++k) d[r] = fmaf(av[r][k], bv[k], d[r]);
+  return d;
+}
+}  // namespace emu

@@ -65,7 +65,7 @@ def test_monte_carlo_forward_backward_matches_reference(backend, name):
 
 
 @pytest.mark.parametrize('dof,S,K,N', [(6, 64, 4, 96), (4, 64, 4, 96), (6, 60, 3, 70), (6, 200, 2, 130), (4, 100, 1, 33),
-                                       (6, 320, 2, 600)])
+                                       (6, 320, 2, 600), (6, 48, 2, 1300)])
 def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
     """Tight check that does not depend on the (ill-conditioned) proposal fit: recompute cost and proposal mixture
     density with the oracle AT THE KERNEL'S OWN samples and fitted proposals; log-weights must agree to 1e-4."""
@@ -156,3 +156,20 @@ def test_philox_sampler_statistics(backend):
     # seed-to-seed std of the per-object estimate is ~0.05-0.1 at S=256
     assert (lse - ref_lse).abs().max().item() < 0.6
     assert (lse.mean(1) - ref_lse.mean()).abs().max().item() < 0.25
+
+
+def test_valu_sweep_variant_matches_mfma_variant(backend, monkeypatch):
+    """EPROPNP_FWD_IMPL=valu selects the register-resident VALU sweep kernel; same samples, same weights."""
+    from epropnp import functional as F
+    B, N, S, K, dof = 3, 200, 64, 4, 6
+    prob = orc.make_problem(B, N, dof, seed=17)
+    noise = pack_noise(orc.make_noise(B, S, K, dof, seed=18), dof).to(backend)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
+    monkeypatch.delenv('EPROPNP_FWD_IMPL', raising=False)
+    s1, w1 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+    monkeypatch.setenv('EPROPNP_FWD_IMPL', 'valu')
+    s2, w2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+    assert (s1 - s2).abs().max().item() < 5e-4
+    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3

@@ -48,9 +48,12 @@ def worker(B, N, S, K, L, reps=8):
 
 
 VARIANTS = [
-    ('default', {}),
-    ('lm W1 PPL8', {'EPROPNP_LM_SHAPE': '1,8'}),
-    ('lm W2 PPL4', {'EPROPNP_LM_SHAPE': '2,4'}),
+    ('default (mfma, 4 waves)', {}),
+    ('mfma: no sweep', {'EPROPNP_ABLATE': '1'}),
+    ('mfma: no refit', {'EPROPNP_ABLATE': '2'}),
+    ('mfma: no sweep/refit/dens', {'EPROPNP_ABLATE': '7'}),
+    ('valu sweep', {'EPROPNP_FWD_IMPL': 'valu'}),
+    ('valu: no sweep', {'EPROPNP_FWD_IMPL': 'valu', 'EPROPNP_ABLATE': '1'}),
 ]
 
 
