@@ -150,6 +150,7 @@ def main():
     from epropnp.cost_fun import AdaptiveHuberPnPCost
     from epropnp.epropnp import EProPnP6DoF
     from epropnp.levenberg_marquardt import LMSolver
+    from epropnp.losses import monte_carlo_pose_loss
 
     B, N, S, K, L = args.objects, args.points, args.samples, args.amis_iters, args.lm_iters
     prob = synth_problem(B, N, dev, seed=1000 + rank)      # every rank owns its own shard of objects
@@ -159,6 +160,7 @@ def main():
     layer = EProPnP6DoF(mc_samples=S, num_iter=K, solver=LMSolver(dof=6, num_iter=L), seed=1 + rank)
 
     timers = {n: KernelTimer(F, n) for n in ('lm_solve', 'amis_forward', 'amis_backward', 'evaluate_cost')}
+    # (the adaptive-delta and Monte-Carlo-loss kernels are part of the step as well, untimed individually)
 
     def step():
         for t in (x3d, x2d, w2d):
@@ -166,7 +168,7 @@ def main():
         cost_fun.set_param(x2d.detach(), w2d)
         _, _, _, _, logw, cost_init = layer.monte_carlo_forward(x3d, x2d, w2d, camera, cost_fun,
                                                                 pose_init=prob['pose_init'], force_init_solve=False)
-        loss = (cost_init + torch.logsumexp(logw, dim=0)).mean()       # Monte-Carlo pose (KL) loss
+        loss = monte_carlo_pose_loss(logw, cost_init).mean()           # Monte-Carlo pose (KL) loss, NaN -> 0
         loss.backward()
         return loss
 

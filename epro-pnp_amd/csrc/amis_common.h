@@ -215,6 +215,7 @@ struct AmisCtx {
   float* prop;    // [K][kPropStride] fitted proposals
   float* red;     // [256]        block-reduction scratch
   int S, K, s, T, tid, b;
+  int cstride;    // row stride of cpart (s, or s rounded up to 16 for the MFMA kernel)
 };
 
 // ---------------- 1. draw s samples from proposal `it` (lane = sample) ----------------
@@ -328,7 +329,7 @@ PNP_FN void amis_weights(const AmisCtx& cx, const AmisParams& a, int it, int WP)
     float mix;
     if (m >= it * s) {   // new sample: every proposal so far
       float c = cpart[m - it * s];
-      for (int q = 1; q < WP; ++q) c += cpart[q * s + (m - it * s)];
+      for (int q = 1; q < WP; ++q) c += cpart[q * cx.cstride + (m - it * s)];
       cst[m] = c;
 #ifdef PNP_TUNING
       if (a.ablate & 4) mix = 0.f; else {
@@ -353,12 +354,18 @@ PNP_FN void amis_weights(const AmisCtx& cx, const AmisParams& a, int it, int WP)
 // ---------------- 5. fit proposal it+1 to the weighted samples (epropnp.py:238-260 / :317-342) ---------
 template <int DOF>
 PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
+  // Runs on wave 0 only: with <= a few hundred samples the moment passes are short, and a single wave needs no
+  // workgroup barriers and a quarter of the cross-lane reduction instructions (the other waves wait at the end).
   float* smp = cx.smp; float* lgw = cx.lgw; float* prop = cx.prop; float* red = cx.red;
-  const int S = cx.S, s = cx.s, T = cx.T, tid = cx.tid;
+  const int S = cx.S, s = cx.s;
   const float* rec = prop + it * kPropStride;
   const int M = (it + 1) * s;
-  (void)rec;
   float* nrec = prop + (it + 1) * kPropStride;
+  if (wave_id() != 0) {
+    __syncthreads();
+    return;
+  }
+  const int T = 64, tid = lane_id();
 #ifdef PNP_TUNING
   if (a.ablate & 2) {
     for (int i = tid; i < kPropStride; i += T) nrec[i] = rec[i];
@@ -371,7 +378,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
   // benign), and -- since the ACG fixed point starts from Sigma = I -- the first maximum-likelihood step as well.
   float mx = -INFINITY;
   for (int m = tid; m < M; m += T) mx = fmaxf(mx, lgw[m]);
-  mx = block_max(mx, red);
+  mx = wave_max(mx);
   const float p0 = rec[0], p1 = rec[1], p2 = rec[2];
   if (DOF == 6) {
     float mom[21];
@@ -392,7 +399,8 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       mom[16] += iw * q3 * q0; mom[17] += iw * q3 * q1; mom[18] += iw * q3 * q2; mom[19] += iw * q3 * q3;
       mom[20] += iw;
     }
-    block_sum<21>(mom, red);
+#pragma unroll
+    for (int i = 0; i < 21; ++i) mom[i] = wave_sum(mom[i]);
     const float invZ = 1.0f / mom[0];
     const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
     const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;
@@ -422,10 +430,10 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
 #pragma unroll
           for (int j = 0; j <= i; ++j) red[tri(i, j)] = (float)Sgi[i][j];
       }
-      __syncthreads();
+      wave_lds_fence();
 #pragma unroll
       for (int i = 0; i < 10; ++i) Si[i] = red[i];
-      __syncthreads();
+      wave_lds_fence();
 #pragma unroll
       for (int i = 0; i < 11; ++i) acc[i] = 0.f;
       for (int m = tid; m < M; m += T) {
@@ -441,7 +449,8 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
         acc[3] += iw * q2 * q0; acc[4] += iw * q2 * q1; acc[5] += iw * q2 * q2;
         acc[6] += iw * q3 * q0; acc[7] += iw * q3 * q1; acc[8] += iw * q3 * q2; acc[9] += iw * q3 * q3;
       }
-      block_sum<11>(acc, red);
+#pragma unroll
+      for (int i = 0; i < 11; ++i) acc[i] = wave_sum(acc[i]);
     }
     if (tid == 0) {
       nrec[0] = mu0; nrec[1] = mu1; nrec[2] = mu2;
@@ -483,7 +492,8 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       mom[10] += e * sinf(yaw);
       mom[11] += e * cosf(yaw);
     }
-    block_sum<12>(mom, red);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) mom[i] = wave_sum(mom[i]);
     const float invZ = 1.0f / mom[0];
     const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
     const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;

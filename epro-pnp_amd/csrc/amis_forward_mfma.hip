@@ -53,8 +53,11 @@ struct MfmaShape {
   int s16;       // samples per iteration rounded up to 16
 };
 
-template <int DOF, bool BOUNDS>
-__global__ __launch_bounds__(512) void amis_forward_mfma_kernel(Problem p, AmisParams a, MfmaShape sh,
+// NPT > 0: the workgroup's waves split the POINTS, each wave keeps its NPT point tiles (B operand + residual
+// constants, 5 VGPRs per tile) in registers for the whole kernel and sweeps every pose tile; per-wave partial costs
+// meet in LDS.  NPT == 0: waves split the pose tiles and points stream through LDS in chunks (any N).
+template <int DOF, bool BOUNDS, int NPT>
+__global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_kernel(Problem p, AmisParams a, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
                                                                   const float* __restrict__ noise,
@@ -68,15 +71,17 @@ __global__ __launch_bounds__(512) void amis_forward_mfma_kernel(Problem p, AmisP
   const int S = a.S, K = a.K, s = S / K, s16 = sh.s16, NC = sh.chunk;
 
   PNP_DYN_SMEM(float, smem);
+  constexpr bool kRegs = NPT > 0;
+  const int WPs = kRegs ? W : 1;      // point slices whose partial costs are summed in amis_weights
   float* ptab = smem;                 // [s16][12]   x | y | z rows of (K R | K t)          (16-B aligned)
-  float* pB = ptab + 12 * s16;        // [NC][4]     (X, Y, Z, 1)                            (16-B aligned)
-  float* pW = pB + 4 * NC;            // [NC][4]     (wu, wv, -u wu, -v wv)                  (16-B aligned)
+  float* pB = ptab + 12 * s16;        // [NC][4]     (X, Y, Z, 1)        (NC = 0 in register mode)
+  float* pW = pB + 4 * NC;            // [NC][4]     (wu, wv, -u wu, -v wv)
   float* smp = pW + 4 * NC;           // [PL][S]
   float* cst = smp + PL * S;          // [S]
   float* mixl = cst + S;              // [S]
   float* lgw = mixl + S;              // [S]
-  float* cpart = lgw + S;             // [s16]
-  float* prop = cpart + s16;          // [K][kPropStride]
+  float* cpart = lgw + S;             // [WPs][s16]
+  float* prop = cpart + WPs * s16;    // [K][kPropStride]
   float* red = prop + K * kPropStride;   // [256]
 
   float Kc[9], delta;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(512) void amis_forward_mfma_kernel(Problem p, AmisP
 
   for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last tile
   if (tid == 0) initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop);
-  const int nchunk = (p.N + NC - 1) / NC;
+  const int nchunk = kRegs ? 1 : (p.N + NC - 1) / NC;
   auto load_chunk = [&](int c0) {
     const int cnt = min(NC, ((p.N - c0 + 15) >> 4) << 4);
     for (int n = tid; n < cnt; n += T) {
@@ -95,12 +100,25 @@ __global__ __launch_bounds__(512) void amis_forward_mfma_kernel(Problem p, AmisP
       reinterpret_cast<float4*>(pW)[n] = make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
     }
   };
-  if (nchunk == 1) load_chunk(0);
+  // register mode: this wave's point tiles q = wv + W * i, lane = (point column, k)
+  float rB[kRegs ? NPT : 1];
+  float4 rW[kRegs ? NPT : 1];
+  if (kRegs) {
+#pragma unroll
+    for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
+      const Point q = load_point(p, b, (wv + W * i) * 16 + (lane & 15));      // zero weight beyond N
+      const int k4 = lane >> 4;
+      rB[i] = (k4 == 0) ? q.X : (k4 == 1) ? q.Y : (k4 == 2) ? q.Z : 1.0f;
+      rW[i] = make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
+    }
+  } else if (nchunk == 1) {
+    load_chunk(0);
+  }
   __syncthreads();
 
   AmisCtx cx;
   cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
-  cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b;
+  cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s16;
 
   const int g4 = (lane >> 4) * 4, col = lane & 15, kk = lane >> 4;
   for (int it = 0; it < K; ++it) {
@@ -113,6 +131,42 @@ __global__ __launch_bounds__(512) void amis_forward_mfma_kernel(Problem p, AmisP
       for (int n = tid; n < s; n += T) cpart[n] = 1.0f;
     } else
 #endif
+    if (kRegs) {
+      const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < (s16 >> 4); ++t) {
+        const float* arow = ptab + 12 * (t * 16 + col) + kk;
+        const float ax = arow[0], ay = arow[4], az = arow[8];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
+          const floatx4 hx = mfma_16x16x4(ax, rB[i], zero);
+          const floatx4 hy = mfma_16x16x4(ay, rB[i], zero);
+          const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
+          const float4 w4 = rW[i];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float zc = (hz[r] > zmin_v) ? hz[r] : zmin_v;
+            const float rz = fast_rcp(zc);
+            float px = hx[r] * rz, py = hy[r] * rz;
+            if (BOUNDS) {
+              px = fminf(fmaxf(px, bd.lbx), bd.ubx);
+              py = fminf(fmaxf(py, bd.lby), bd.uby);
+            }
+            const float rx = fmaf(px, w4.x, w4.z);
+            const float ry = fmaf(py, w4.y, w4.w);
+            const float rho = fast_sqrt(fmaf(rx, rx, ry * ry));
+            const float m = fminf(rho, delta_v);
+            acc[r] = fmaf(m, fmaf(-0.5f, m, rho), acc[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
+        if (col == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cpart[wv * s16 + t * 16 + g4 + r] = acc[r];
+        }
+      }
+    } else
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * NC;
       if (nchunk > 1) {
@@ -170,7 +224,7 @@ __global__ __launch_bounds__(512) void amis_forward_mfma_kernel(Problem p, AmisP
     }
     __syncthreads();
 
-    amis_weights<DOF>(cx, a, it, 1);
+    amis_weights<DOF>(cx, a, it, WPs);
     __syncthreads();
     if (it == K - 1) break;
     amis_refit<DOF>(cx, a, it);
@@ -181,6 +235,19 @@ __global__ __launch_bounds__(512) void amis_forward_mfma_kernel(Problem p, AmisP
     for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
 }
 
+template <class F>
+static int dispatch_npt(int npt, F&& f) {
+  switch (npt) {
+    case 0: return f(ic<0>{});
+    case 1: return f(ic<1>{});
+    case 2: return f(ic<2>{});
+    case 4: return f(ic<4>{});
+    case 8: return f(ic<8>{});
+    case 12: return f(ic<12>{});
+    default: return f(ic<16>{});
+  }
+}
+
 int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_params* am, const float* pose_opt,
                              const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
                              float* proposals, hipStream_t st) {
@@ -189,28 +256,44 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   const int PL = prob->dof == 6 ? 7 : 4;
   MfmaShape sh;
   sh.s16 = ((s + 15) / 16) * 16;
-  sh.chunk = ((d.N + 15) / 16) * 16;
-  if (sh.chunk > kChunk) sh.chunk = kChunk;
-  const int tiles = sh.s16 / 16;
-  int waves = 4;                       // pose tiles are dealt round-robin to the waves
-  { int ov[1]; if (env_ints("EPROPNP_FWD_WAVES", ov, 1) && ov[0] >= 1 && ov[0] <= 8) waves = ov[0]; }
-  while (waves > 1 && waves > tiles) waves /= 2;
+  // register mode: W waves x NPT point tiles of 16 cover N with the least padding (ties: prefer 4 waves)
+  const int ptiles = (d.N + 15) / 16;
+  const int npt_opts[6] = {1, 2, 4, 8, 12, 16};
+  int waves = 4, npt = 0, best = 1 << 30;
+  for (int w : {4, 8, 2, 1}) {
+    for (int o : npt_opts) {
+      if (w * o >= ptiles && w * o < best) { best = w * o; waves = w; npt = o; }
+      if (w * o >= ptiles) break;
+    }
+  }
+  { int ov[2]; if (env_ints("EPROPNP_FWD_MFMA", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 0 || ov[0] * ov[1] >= ptiles)) { waves = ov[0]; npt = ov[1]; } }
+  if (npt == 0) {       // points stream through LDS in chunks; waves split the pose tiles
+    sh.chunk = ((d.N + 15) / 16) * 16;
+    if (sh.chunk > kChunk) sh.chunk = kChunk;
+    if (best == (1 << 30)) waves = 4;
+    const int tiles = sh.s16 / 16;
+    while (waves > 1 && waves > tiles) waves /= 2;
+  } else {
+    sh.chunk = 0;
+  }
   AmisParams k;
   k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.ablate = 0;
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
   const size_t smem = sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (size_t)PL * S + 3 * (size_t)S +
-                                       (size_t)sh.s16 + (size_t)K * kPropStride + 256);
+                                       (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256);
   if (smem > 160 * 1024) return fail(EPROPNP_EINVAL, "amis_forward: mc_samples %d needs %zu B of LDS (> 160 KiB)", S, smem);
   const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
-    auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value>;
+    return dispatch_npt(npt, [&](auto NPT) -> int {
+      auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
 #ifndef EPROPNP_EMU
-    if (smem > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-    PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals);
-    return 0;
+      PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals);
+      return 0;
+    });
   });
   return check_launch("amis_forward_mfma_kernel");
 }

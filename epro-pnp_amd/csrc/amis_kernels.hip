@@ -63,7 +63,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) vo
 
   AmisCtx cx;
   cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
-  cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b;
+  cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s;
 
   for (int it = 0; it < K; ++it) {
     amis_draw<DOF>(cx, p, a, it, Kc, noise, pose_samples);
@@ -188,6 +188,15 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
   const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
   const int ntile = (P + 63) >> 6;
 
+  // Poses whose weight is below 2^-30 of the object's largest |weight| are dropped: with S <= 2^13 samples their
+  // combined contribution is < 2^-17 of ONE term of the largest kind, i.e. under the fp32 rounding error that the
+  // S-term sums carry anyway.  After softmax normalisation this is ~10-15 % of the AMIS samples (the Student-t tails).
+  constexpr float kSkipRel = 9.313225746154785e-10f;   // 2^-30
+  float amax = 0.f;
+  for (int m = tid; m < S; m += T) amax = fmaxf(amax, fabsf(g_logw[(size_t)m * p.B + b]));
+  amax = block_max(amax, red);
+  const float askip = amax * kSkipRel;
+
   // lanes 0..63 of the workgroup fetch one pose each of tile t (global loads issued early, consumed late)
   float nps[PL], naw = 0.f;
   auto fetch = [&](int t) {
@@ -197,6 +206,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
 #pragma unroll
       for (int i = 0; i < PL; ++i) nps[i] = src[i];
       naw = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init[b];     // logw = -cost - const
+      if (m < S && fabsf(naw) <= askip) naw = 0.f;
     }
   };
   auto publish = [&](int buf) {

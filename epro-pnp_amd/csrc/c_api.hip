@@ -44,4 +44,20 @@ int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples
                                    grad_x2d, grad_w2d, grad_delta, (hipStream_t)stream);
 }
 
+int epropnp_adaptive_delta(const float* x2d, const float* w2d, int32_t num_obj, int32_t num_pts, float relative_delta,
+                           float* delta, float* stats, void* stream) {
+  return pnp::launch_adaptive_delta(x2d, w2d, num_obj, num_pts, relative_delta, delta, stats, (hipStream_t)stream);
+}
+
+int epropnp_mc_loss_forward(const float* logweights, const float* cost_target, int32_t mc_samples, int32_t num_obj,
+                            float* loss, float* lse, void* stream) {
+  return pnp::launch_mc_loss_forward(logweights, cost_target, mc_samples, num_obj, loss, lse, (hipStream_t)stream);
+}
+
+int epropnp_mc_loss_backward(const float* logweights, const float* lse, const float* loss, const float* grad_loss,
+                             int32_t mc_samples, int32_t num_obj, float* grad_logweights, void* stream) {
+  return pnp::launch_mc_loss_backward(logweights, lse, loss, grad_loss, mc_samples, num_obj, grad_logweights,
+                                      (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -107,6 +107,129 @@ __global__ __launch_bounds__(MAXW * 64) void evaluate_cost_kernel(Problem p, con
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// Glue of the training step that the reference leaves to ~25 small ATen launches: adaptive Huber threshold and the
+// Monte-Carlo pose loss.  Both are single HBM-bound passes.
+__global__ __launch_bounds__(256) void adaptive_delta_kernel(const float* __restrict__ x2d, const float* __restrict__ w2d,
+                                                              int B, int N, float rel, float* __restrict__ delta,
+                                                              float* __restrict__ stats) {
+  __shared__ float red[5 * 16];
+  const int b = object_of_block(B);
+  if (b >= B) return;
+  const float2* x = reinterpret_cast<const float2*>(x2d) + (size_t)b * N;
+  const float2* w = reinterpret_cast<const float2*>(w2d) + (size_t)b * N;
+  // shifted one-pass moments (pivot = first point) -> no E[x^2] - E[x]^2 cancellation at pixel magnitudes
+  const float2 piv = x[0];
+  float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int n = (int)threadIdx.x; n < N; n += (int)blockDim.x) {
+    const float2 xi = x[n], wi = w[n];
+    const float dx = xi.x - piv.x, dy = xi.y - piv.y;
+    v[0] += wi.x + wi.y;
+    v[1] += dx; v[2] += dy;
+    v[3] += dx * dx; v[4] += dy * dy;
+  }
+  block_sum<5>(v, red);
+  if (threadIdx.x == 0) {
+    const float n = (float)N;
+    const float var = ((v[3] - v[1] * v[1] / n) + (v[4] - v[2] * v[2] / n)) / (n - 1.0f);
+    const float sd = sqrtf(fmaxf(var, 0.f));
+    const float mw = v[0] / (2.0f * n);
+    delta[b] = mw * sd * rel;
+    stats[(size_t)b * 4 + 0] = mw;
+    stats[(size_t)b * 4 + 1] = sd;
+    stats[(size_t)b * 4 + 2] = piv.x + v[1] / n;
+    stats[(size_t)b * 4 + 3] = piv.y + v[2] / n;
+  }
+}
+
+// (S,B) log-weights: a 512-thread block owns 32 adjacent objects (columns) and splits the S rows over 16 row groups;
+// each thread keeps an online (max, sum) pair, the 16 partials of a column are merged through LDS.
+__global__ __launch_bounds__(512) void mc_loss_forward_kernel(const float* __restrict__ logw, const float* __restrict__ ct,
+                                                               int S, int B, float* __restrict__ loss,
+                                                               float* __restrict__ lse) {
+  __shared__ float smax[16][33], ssum[16][33];
+  const int c = (int)(threadIdx.x & 31u), rg = (int)(threadIdx.x >> 5);
+  const int b = (int)blockIdx.x * 32 + c;
+  float m = -INFINITY, acc = 0.f;
+  bool nan = false;
+  if (b < B) {
+    for (int j = rg; j < S; j += 16) {
+      const float v = logw[(size_t)j * B + b];
+      nan = nan || (v != v);
+      if (v > m) {
+        acc = acc * expf(m - v) + 1.0f;      // exp(-inf - v) = 0 on the first element
+        m = v;
+      } else if (v == v) {
+        acc += (v == -INFINITY) ? 0.f : expf(v - m);
+      }
+    }
+  }
+  smax[rg][c] = nan ? NAN : m;
+  ssum[rg][c] = acc;
+  __syncthreads();
+  if (rg == 0 && b < B) {
+    float M = -INFINITY;
+    bool bad = false;
+    for (int k = 0; k < 16; ++k) {
+      const float mk = smax[k][c];
+      bad = bad || (mk != mk);
+      M = fmaxf(M, mk);
+    }
+    float tot = 0.f;
+    for (int k = 0; k < 16; ++k) {
+      const float mk = smax[k][c];
+      if (mk == mk && mk > -INFINITY) tot += ssum[k][c] * expf(mk - M);
+    }
+    float l = (M == -INFINITY || M == INFINITY) ? M : M + logf(tot);
+    if (bad) l = NAN;
+    const float v = l + (ct ? ct[b] : 0.f);
+    lse[b] = (v != v) ? NAN : l;          // NaN marks "loss zeroed": the backward passes no gradient there
+    loss[b] = (v != v) ? 0.f : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void mc_loss_backward_kernel(const float* __restrict__ logw, const float* __restrict__ lse,
+                                                                const float* __restrict__ g, int S, int B,
+                                                                float* __restrict__ glogw) {
+  const size_t total = (size_t)S * B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % (size_t)B);
+    const float l = lse[b];
+    glogw[i] = (l != l) ? 0.f : g[b] * expf(logw[i] - l);
+  }
+}
+
+int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, float rel, float* delta, float* stats,
+                          hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!x2d || !w2d || !delta || !stats || N < 1) return fail(EPROPNP_EINVAL, "adaptive_delta: bad argument");
+  int threads = 64;
+  while (threads < 256 && threads * 4 < N) threads *= 2;
+  PNP_LAUNCH(adaptive_delta_kernel, dim3(padded_object_grid(B)), dim3(threads), 0, st, x2d, w2d, B, N, rel, delta, stats);
+  return check_launch("adaptive_delta_kernel");
+}
+
+int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, float* loss, float* lse, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!logw || !loss || !lse || S < 1) return fail(EPROPNP_EINVAL, "mc_loss_forward: bad argument");
+  PNP_LAUNCH(mc_loss_forward_kernel, dim3((B + 31) / 32), dim3(512), 0, st, logw, ct, S, B, loss, lse);
+  return check_launch("mc_loss_forward_kernel");
+}
+
+int launch_mc_loss_backward(const float* logw, const float* lse, const float* loss, const float* g, int S, int B,
+                            float* glogw, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!logw || !lse || !loss || !g || !glogw) return fail(EPROPNP_EINVAL, "mc_loss_backward: NULL pointer");
+  (void)loss;
+  {
+    const size_t total = (size_t)S * B;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    PNP_LAUNCH(mc_loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logw, lse, g, S, B, glogw);
+  }
+  return check_launch("mc_loss_backward_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------------
 int launch_normal_equations(const epropnp_problem* prob, const float* pose, int clip_jac, float* jtj, float* jtr,
                             float* cost, hipStream_t st) {
   if (int rc = check_problem(prob)) return rc;

@@ -441,11 +441,20 @@ PNP_FN Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 PNP_FN float u01(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
 
 // two independent N(0,1) from two uint32
+// Hardware v_log / v_sin / v_cos (the latter take their argument in revolutions, exactly what Box-Muller wants):
+// ~10 instructions instead of ~110 for the libm versions; absolute error ~1e-6, irrelevant for random draws.
 PNP_FN void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+#ifndef EPROPNP_EMU
+  const float r = fast_sqrt(-1.3862943611198906f * __builtin_amdgcn_logf(u01(a)));   // -2 ln u = -2 ln2 log2 u
+  const float rev = u01(b);
+  n0 = r * __builtin_amdgcn_cosf(rev);
+  n1 = r * __builtin_amdgcn_sinf(rev);
+#else
   const float r = sqrtf(-2.0f * logf(u01(a)));
   const float th = 6.283185307179586f * u01(b);
   n0 = r * cosf(th);
   n1 = r * sinf(th);
+#endif
 }
 
 }  // namespace pnp

@@ -50,13 +50,18 @@ def _declare(lib):
     lib.epropnp_lm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), vp, vp, vp, vp, vp, vp]
     lib.epropnp_amis_forward.argtypes = [C.POINTER(Problem), C.POINTER(AmisParams), vp, vp, vp, vp, vp, vp, vp]
     lib.epropnp_amis_backward.argtypes = [C.POINTER(Problem), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
-    for name in ('evaluate_cost', 'normal_equations', 'lm_solve', 'amis_forward', 'amis_backward'):
+    lib.epropnp_adaptive_delta.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp]
+    lib.epropnp_mc_loss_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.epropnp_mc_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    for name in ('evaluate_cost', 'normal_equations', 'lm_solve', 'amis_forward', 'amis_backward', 'adaptive_delta',
+                 'mc_loss_forward', 'mc_loss_backward'):
         getattr(lib, 'epropnp_' + name).restype = C.c_int
     return lib
 
 
 EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 'epropnp_evaluate_cost',
-           'epropnp_normal_equations', 'epropnp_lm_solve', 'epropnp_amis_forward', 'epropnp_amis_backward')
+           'epropnp_normal_equations', 'epropnp_lm_solve', 'epropnp_amis_forward', 'epropnp_amis_backward',
+           'epropnp_adaptive_delta', 'epropnp_mc_loss_forward', 'epropnp_mc_loss_backward')
 
 
 def lib():
@@ -93,6 +98,12 @@ def check_device(t, name):
         return
     if not t.is_cuda:
         raise RuntimeError(f'{name} must live on a HIP device (got {t.device}); the EPro-PnP HIP path has no CPU fallback')
+
+
+def on_hip_path(*tensors):
+    """True when the fused kernels can serve these tensors: fp32 on a HIP device (or the test-only emulation)."""
+    ok = all(t.dtype == torch.float32 for t in tensors)
+    return ok and (all(t.is_cuda for t in tensors) or (_emulated and not any(t.is_cuda for t in tensors)))
 
 
 def ptr(t):

@@ -77,5 +77,11 @@ class AdaptiveHuberPnPCost(HuberPnPCost):
         self.eps = eps
 
     def set_param(self, x2d, w2d):
+        from . import _hip
+        if x2d.dim() == 3 and x2d.shape == w2d.shape and x2d.size(0) > 0 and x2d.size(1) > 1 \
+                and _hip.on_hip_path(x2d, w2d):
+            from .functional import adaptive_delta        # one fused pass (fwd) instead of ~8 ATen launches
+            self.delta = adaptive_delta(x2d, w2d, self.relative_delta)
+            return
         spread = torch.var(x2d, dim=-2).sum(dim=-1).sqrt()
         self.delta = w2d.mean(dim=(-2, -1)) * spread * self.relative_delta

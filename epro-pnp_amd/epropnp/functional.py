@@ -172,3 +172,68 @@ class _MonteCarloCost(torch.autograd.Function):
 
 def monte_carlo_cost(x3d, x2d, w2d, delta, prob, pose_opt, pose_cov, pose_init, cost_init_value, cfg):
     return _MonteCarloCost.apply(x3d, x2d, w2d, delta, prob, pose_opt, pose_cov, pose_init, cost_init_value, cfg)
+
+
+class _AdaptiveDelta(torch.autograd.Function):
+    """delta_b = mean(w2d_b) * sqrt(sum_xy var_N(x2d_b)) * relative_delta in one pass over (x2d, w2d)
+    (reference: ~8 ATen launches, epropnp/cost_fun.py:123-126).  Backward: closed-form broadcasts."""
+
+    @staticmethod
+    def forward(ctx, x2d, w2d, relative_delta):
+        x, w = _f32c(x2d, 'x2d'), _f32c(w2d, 'w2d')
+        B, N, _ = x.shape
+        delta = torch.empty(B, dtype=torch.float32, device=x.device)
+        stats = torch.empty(B, 4, dtype=torch.float32, device=x.device)
+        _hip.call('epropnp_adaptive_delta', _hip.ptr(x), _hip.ptr(w), B, N, float(relative_delta), _hip.ptr(delta),
+                  _hip.ptr(stats), _hip.stream_of(x))
+        ctx.save_for_backward(x, stats)
+        ctx.rel, ctx.N = float(relative_delta), N
+        return delta
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats = ctx.saved_tensors
+        N, rel = ctx.N, ctx.rel
+        mw, sd = stats[:, 0], stats[:, 1]
+        gx = gw = None
+        if ctx.needs_input_grad[1]:      # d delta / d w = std * rel / (2N), the same for every element of the object
+            gw = (g * sd * (rel / (2 * N)))[:, None, None].expand(-1, N, 2)
+        if ctx.needs_input_grad[0]:      # d delta / d x = mean_w * rel * (x - mean) / ((N-1) std)
+            coef = g * mw * rel / ((N - 1) * sd.clamp(min=1e-30))
+            gx = coef[:, None, None] * (x - stats[:, None, 2:4])
+        return gx, gw, None
+
+
+def adaptive_delta(x2d, w2d, relative_delta):
+    return _AdaptiveDelta.apply(x2d, w2d, relative_delta)
+
+
+class _McPoseLoss(torch.autograd.Function):
+    """Per-object Monte-Carlo pose loss cost_target + logsumexp_S(logweights), NaN -> 0, as two kernels (fwd / bwd)."""
+
+    @staticmethod
+    def forward(ctx, logw, cost_target):
+        lw = _f32c(logw, 'pose_sample_logweights')
+        S, B = lw.shape
+        ct = None if cost_target is None else _f32c(cost_target, 'cost_target')
+        loss = torch.empty(B, dtype=torch.float32, device=lw.device)
+        lse = torch.empty_like(loss)
+        _hip.call('epropnp_mc_loss_forward', _hip.ptr(lw), _hip.ptr(ct), S, B, _hip.ptr(loss), _hip.ptr(lse),
+                  _hip.stream_of(lw))
+        ctx.save_for_backward(lw, lse, loss)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lw, lse, loss = ctx.saved_tensors
+        S, B = lw.shape
+        g = g.contiguous()
+        glw = torch.empty_like(lw)
+        _hip.call('epropnp_mc_loss_backward', _hip.ptr(lw), _hip.ptr(lse), _hip.ptr(loss), _hip.ptr(g), S, B,
+                  _hip.ptr(glw), _hip.stream_of(lw))
+        gct = torch.where(torch.isnan(lse), torch.zeros_like(g), g) if ctx.needs_input_grad[1] else None
+        return glw, gct
+
+
+def mc_pose_loss(logweights, cost_target):
+    return _McPoseLoss.apply(logweights, cost_target)

@@ -12,6 +12,11 @@ import torch.nn as nn
 
 def monte_carlo_pose_loss(pose_sample_logweights, cost_target):
     """(S,B), (B,) -> per-object loss (B,): cost_target + logsumexp_S(logweights); NaN -> 0."""
+    from . import _hip
+    if pose_sample_logweights.dim() == 2 and pose_sample_logweights.numel() > 0 \
+            and _hip.on_hip_path(pose_sample_logweights, cost_target):
+        from .functional import mc_pose_loss              # fused forward / backward kernels
+        return mc_pose_loss(pose_sample_logweights, cost_target)
     loss = cost_target + torch.logsumexp(pose_sample_logweights, dim=0)
     return torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)
 

@@ -117,6 +117,22 @@ int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples
                           int32_t mc_samples, const float* pose_init, const float* grad_cost_init,
                           float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream);
 
+/* AdaptiveHuberPnPCost.set_param (epropnp/cost_fun.py:123-126):
+ *   delta[b] = mean(w2d[b]) * sqrt(sum_xy var_N(x2d[b])) * relative_delta      (unbiased variance)
+ * x2d (B,N,2), w2d (B,N,2) -> delta (B,), stats (B,4) = [mean_w, x2d_std, mean_x, mean_y] (kept for the backward,
+ * which is three broadcast expressions evaluated by the caller). */
+int epropnp_adaptive_delta(const float* x2d, const float* w2d, int32_t num_obj, int32_t num_pts, float relative_delta,
+                           float* delta, float* stats, void* stream);
+
+/* Monte-Carlo pose loss per object (EPro-PnP-6DoF/lib/models/monte_carlo_pose_loss.py:28-32):
+ *   loss[b] = cost_target[b] + logsumexp_j logweights[j,b];  NaN -> 0.   lse (B,) is kept for the backward.
+ * logweights (S,B), cost_target (B,) or NULL. */
+int epropnp_mc_loss_forward(const float* logweights, const float* cost_target, int32_t mc_samples, int32_t num_obj,
+                            float* loss, float* lse, void* stream);
+/* grad_logweights[j,b] = grad_loss[b] * exp(logweights[j,b] - lse[b])   (0 where the loss was NaN) */
+int epropnp_mc_loss_backward(const float* logweights, const float* lse, const float* loss, const float* grad_loss,
+                             int32_t mc_samples, int32_t num_obj, float* grad_logweights, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,7 +65,7 @@ def test_monte_carlo_forward_backward_matches_reference(backend, name):
 
 
 @pytest.mark.parametrize('dof,S,K,N', [(6, 64, 4, 96), (4, 64, 4, 96), (6, 60, 3, 70), (6, 200, 2, 130), (4, 100, 1, 33),
-                                       (6, 320, 2, 600), (6, 48, 2, 1300)])
+                                       (6, 320, 2, 600), (6, 48, 2, 1300), (6, 32, 2, 2300)])
 def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
     """Tight check that does not depend on the (ill-conditioned) proposal fit: recompute cost and proposal mixture
     density with the oracle AT THE KERNEL'S OWN samples and fitted proposals; log-weights must agree to 1e-4."""
@@ -158,7 +158,7 @@ def test_philox_sampler_statistics(backend):
     assert (lse.mean(1) - ref_lse.mean()).abs().max().item() < 0.25
 
 
-def test_valu_sweep_variant_matches_mfma_variant(backend, monkeypatch):
+def test_forward_kernel_variants_agree(backend, monkeypatch):
     """EPROPNP_FWD_IMPL=valu selects the register-resident VALU sweep kernel; same samples, same weights."""
     from epropnp import functional as F
     B, N, S, K, dof = 3, 200, 64, 4, 6
@@ -173,3 +173,9 @@ def test_valu_sweep_variant_matches_mfma_variant(backend, monkeypatch):
     s2, w2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     assert (s1 - s2).abs().max().item() < 5e-4
     assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3
+    # MFMA kernel, LDS-chunk mode (used for N > 2048), forced on this small problem with 2 waves
+    monkeypatch.delenv('EPROPNP_FWD_IMPL')
+    monkeypatch.setenv('EPROPNP_FWD_MFMA', '2,0')
+    s3, w3 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+    assert (s1 - s3).abs().max().item() < 5e-4
+    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w3, 0)).abs().max().item() < 1e-3

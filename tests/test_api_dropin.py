@@ -183,3 +183,40 @@ def test_distributions_and_loss_modules():
     torch.testing.assert_close(v, orc.mc_pose_loss(logw, ct, 2.2), rtol=1e-6, atol=1e-6)
     v2 = loss(logw, ct, 4.0, weight=torch.tensor([1.0, 0.0, 2.0]), avg_factor=3.0)
     assert v2.dim() == 0
+
+
+def test_fused_delta_and_loss_match_torch(backend):
+    """The fused set_param / Monte-Carlo-loss kernels against their PyTorch definitions, values and gradients."""
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    from epropnp.losses import monte_carlo_pose_loss
+    g = torch.Generator().manual_seed(5)
+    B, N, S = 7, 50, 24
+    x = (torch.randn(B, N, 2, generator=g) * 80 + 300).to(backend).requires_grad_(True)
+    w = (torch.rand(B, N, 2, generator=g) * 0.01).to(backend).requires_grad_(True)
+    cf = AdaptiveHuberPnPCost(relative_delta=0.3)
+    cf.set_param(x, w)
+    up = torch.randn(B, generator=g).to(backend)
+    (cf.delta * up).sum().backward()
+    xr, wr = x.detach().cpu().double().requires_grad_(True), w.detach().cpu().double().requires_grad_(True)
+    dref = orc.adaptive_huber_delta(xr, wr, 0.3)
+    (dref * up.cpu().double()).sum().backward()
+    torch.testing.assert_close(cf.delta.detach().cpu().double(), dref.detach(), rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(x.grad.cpu().double(), xr.grad, rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(w.grad.cpu().double(), wr.grad, rtol=1e-4, atol=1e-9)
+    logw = torch.randn(S, B, generator=g).mul(3).to(backend).requires_grad_(True)
+    ct = torch.rand(B, generator=g).to(backend).requires_grad_(True)
+    with torch.no_grad():
+        logw[3, 2] = float('nan')        # NaN loss for object 2 -> 0, no gradient
+    loss = monte_carlo_pose_loss(logw, ct)
+    (loss * up).sum().backward()
+    lr, cr = logw.detach().cpu().clone().requires_grad_(True), ct.detach().cpu().clone().requires_grad_(True)
+    ref = cr + torch.logsumexp(lr, 0)
+    ref = torch.where(torch.isnan(ref), torch.zeros_like(ref), ref)
+    keep = torch.ones(B, dtype=torch.bool)
+    keep[2] = False
+    (ref * up.cpu())[keep].sum().backward()
+    torch.testing.assert_close(loss.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    assert loss[2].item() == 0.0
+    torch.testing.assert_close(logw.grad.cpu()[:, keep], lr.grad[:, keep], rtol=1e-4, atol=1e-6)
+    assert (logw.grad[:, 2] == 0).all() and ct.grad[2].item() == 0.0
+    torch.testing.assert_close(ct.grad.cpu()[keep], cr.grad[keep], rtol=1e-6, atol=1e-7)

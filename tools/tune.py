@@ -48,12 +48,13 @@ def worker(B, N, S, K, L, reps=8):
 
 
 VARIANTS = [
-    ('default (mfma, 4 waves)', {}),
+    ('default (mfma regs 4x8)', {}),
     ('mfma: no sweep', {'EPROPNP_ABLATE': '1'}),
     ('mfma: no refit', {'EPROPNP_ABLATE': '2'}),
-    ('mfma: no sweep/refit/dens', {'EPROPNP_ABLATE': '7'}),
+    ('mfma regs 8 waves x4', {'EPROPNP_FWD_MFMA': '8,4'}),
+    ('mfma regs 2 waves x16', {'EPROPNP_FWD_MFMA': '2,16'}),
+    ('mfma lds 4 waves', {'EPROPNP_FWD_MFMA': '4,0'}),
     ('valu sweep', {'EPROPNP_FWD_IMPL': 'valu'}),
-    ('valu: no sweep', {'EPROPNP_FWD_IMPL': 'valu', 'EPROPNP_ABLATE': '1'}),
 ]
 
 
