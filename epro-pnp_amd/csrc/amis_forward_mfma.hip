@@ -29,23 +29,6 @@ __device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
 #endif
 }
 
-// sum over the 16 lanes of a DPP row (every lane of the row receives it)
-__device__ __forceinline__ float row_sum16(float x) {
-#ifndef EPROPNP_EMU
-  x += dpp_mov<0x128>(x);
-  x += dpp_mov<0x124>(x);
-  x += dpp_mov<0x122>(x);
-  x += dpp_mov<0x121>(x);
-  return x;
-#else
-  for (int m : {8, 4, 2, 1}) {
-    const int l = lane_id();
-    x += emu::shfl(x, (l & ~15) | ((l + m) & 15));
-  }
-  return x;
-#endif
-}
-
 constexpr int kChunk = 1024;   // points per LDS chunk (32 KiB of point tables)
 
 struct MfmaShape {

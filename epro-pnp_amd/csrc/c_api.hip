@@ -60,4 +60,10 @@ int epropnp_mc_loss_backward(const float* logweights, const float* lse, const fl
                                       (hipStream_t)stream);
 }
 
+int epropnp_rslm_draw(const float* w2d, int32_t num_obj, int32_t num_pts, int32_t num_proposals, int32_t n_pts,
+                      uint64_t seed, uint64_t offset, int64_t* inds, void* stream) {
+  return pnp::launch_rslm_draw(w2d, num_obj, num_pts, num_proposals, n_pts, seed, offset, (long long*)inds,
+                               (hipStream_t)stream);
+}
+
 }  // extern "C"

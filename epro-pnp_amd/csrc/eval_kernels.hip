@@ -198,6 +198,49 @@ __global__ __launch_bounds__(256) void mc_loss_backward_kernel(const float* __re
   }
 }
 
+// One wave per (proposal, object) row.  Keys live in LDS; each of the n_pts rounds is a wave-wide argmin.
+__global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__ w2d, int B, int N, int P, int n_pts,
+                                                        unsigned long long seed, unsigned long long offset,
+                                                        long long* __restrict__ inds) {
+  PNP_DYN_SMEM(float, key);
+  const int row = (int)blockIdx.x;          // row = proposal * B + object
+  const int b = row % B;
+  const int lane = lane_id();
+  const float2* w = reinterpret_cast<const float2*>(w2d) + (size_t)b * N;
+  for (int n = lane; n < N; n += 64) {
+    const float2 wi = w[n];
+    const float wm = 0.5f * (wi.x + wi.y);
+    const Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)n, (uint32_t)offset, (uint32_t)(offset >> 32),
+                                    (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
+    key[n] = (wm > 0.f) ? -logf(u01(r.v[0])) / wm : INFINITY;
+  }
+  wave_lds_fence();
+  for (int k = 0; k < n_pts; ++k) {
+    float best = INFINITY, best_n = 1e9f;
+    for (int n = lane; n < N; n += 64) {
+      const float v = key[n];
+      if (v < best) { best = v; best_n = (float)n; }
+    }
+    const float m = -wave_max(-best);
+    const float cand = (best == m) ? best_n : 1e9f;
+    const float win = -wave_max(-cand);       // lowest index among ties
+    const int wi = (win < 1e8f) ? (int)win : (k % N);   // fewer positive weights than n_pts: fall back deterministically
+    if (lane == 0) inds[(size_t)row * n_pts + k] = (long long)wi;
+    if (lane == (wi & 63)) key[wi] = INFINITY;
+    wave_lds_fence();
+  }
+}
+
+int launch_rslm_draw(const float* w2d, int B, int N, int P, int n_pts, unsigned long long seed, unsigned long long offset,
+                     long long* inds, hipStream_t st) {
+  if (B <= 0 || P <= 0 || n_pts <= 0) return EPROPNP_OK;
+  if (!w2d || !inds || N < 1) return fail(EPROPNP_EINVAL, "rslm_draw: bad argument");
+  if ((size_t)N * 4 > 64 * 1024) return fail(EPROPNP_EINVAL, "rslm_draw: num_pts %d too large", N);
+  PNP_LAUNCH(rslm_draw_kernel, dim3((unsigned)(P * B)), dim3(64), sizeof(float) * (size_t)N, st, w2d, B, N, P, n_pts, seed,
+             offset, inds);
+  return check_launch("rslm_draw_kernel");
+}
+
 int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, float rel, float* delta, float* stats,
                           hipStream_t st) {
   if (B <= 0) return EPROPNP_OK;

@@ -30,16 +30,22 @@ PNP_FN void unpack_h(const float (&acc)[NormalEq<DOF>::NV], float (&H)[DOF][DOF]
     }
 }
 
+// MAXW == 0 selects the small-problem variant: N <= 16 points, one object per 16-lane DPP row (4 objects per wave,
+// reductions are row_ror adds only) -- the shape of the RSLM initialiser's 10^4..10^5 sub-problems.
 template <int DOF, int PPL, bool BOUNDS, int MAXW>
-__global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams lm, const float* __restrict__ pose_init,
+__global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(Problem p, LmParams lm, const float* __restrict__ pose_init,
                                                                float* __restrict__ pose_opt, float* __restrict__ pose_cov,
                                                                float* __restrict__ cost_out, int* __restrict__ accept_out) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
   // dynamic LDS: transposed reduction scratch (waves * kSumTStride<NV>) for <= 4 waves, NV * 16 for the DPP fallback
   PNP_DYN_SMEM(float, scratch);
-  const int b = object_of_block(p.B);
-  if (b >= p.B) return;
+  constexpr bool kRow = (MAXW == 0);
+  const int b_raw = kRow ? (int)(blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4)) : object_of_block(p.B);
+  if (!kRow && b_raw >= p.B) return;
+  const bool live = b_raw < p.B;          // row variant: padded rows compute on object B-1 and write nothing
+  const int b = live ? b_raw : p.B - 1;
+  const bool writer = kRow ? (live && (threadIdx.x & 15u) == 0) : (threadIdx.x == 0);
 
   float K[9], delta;
   Bounds bd;
@@ -51,7 +57,8 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
   const float z_min = to_vgpr(p.z_min);
   Point pts[PPL];
 #pragma unroll
-  for (int k = 0; k < PPL; ++k) pts[k] = load_point(p, b, (int)threadIdx.x + k * (int)blockDim.x);
+  for (int k = 0; k < PPL; ++k)
+    pts[k] = load_point(p, b, kRow ? (int)(threadIdx.x & 15u) : (int)threadIdx.x + k * (int)blockDim.x);
 
   float pose[PL];
 #pragma unroll
@@ -69,7 +76,14 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, z_min, delta, bd, clip, acc);
-    if (MAXW <= 4) block_sum_t<NV>(acc, scratch); else block_sum<NV>(acc, scratch);
+    if (kRow) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] = row_sum16(acc[i]);
+    } else if (MAXW <= 4) {
+      block_sum_t<NV>(acc, scratch);
+    } else {
+      block_sum<NV>(acc, scratch);
+    }
   };
 
   float cur[NV];
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
     }
   }
 
-  if (threadIdx.x == 0) {
+  if (writer) {
 #pragma unroll
     for (int i = 0; i < PL; ++i) pose_opt[(size_t)b * PL + i] = pose[i];
     if (cost_out) cost_out[b] = cur[NV - 1];
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(MAXW * 64) void lm_solve_kernel(Problem p, LmParams
     for (int i = 0; i < DOF; ++i) H[i][i] += lm.eps;
     scaled_cholesky<DOF>(H, f);
     scaled_inverse<DOF>(f, Hi);
-    if (threadIdx.x == 0) {
+    if (writer) {
 #pragma unroll
       for (int i = 0; i < DOF; ++i)
 #pragma unroll
@@ -196,6 +210,15 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
   k.min_diag = lm->min_lm_diagonal; k.max_diag = lm->max_lm_diagonal;
   k.min_rel_decrease = lm->min_relative_decrease; k.radius0 = lm->initial_trust_region_radius;
   k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps;
+  if (d.N <= 16 && !getenv("EPROPNP_LM_NO_ROWS")) {   // RSLM sub-problems: 16 objects per 256-thread block
+    const dim3 grid((d.B + 15) / 16), block(256);
+    dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+      PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 1, decltype(BND)::value, 0>), grid, block, 0, st, d, k, pose_init,
+                 pose_opt, pose_cov, cost, accept_mask);
+      return 0;
+    });
+    return check_launch("lm_solve_kernel (row variant)");
+  }
   Shape s = choose_shape(d.B, d.N);
   int ov[2];
   if (env_ints("EPROPNP_LM_SHAPE", ov, 2) && 64 * ov[0] * ov[1] >= d.N) { s.waves = ov[0]; s.ppl = ov[1]; }

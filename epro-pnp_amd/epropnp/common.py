@@ -48,16 +48,25 @@ def evaluate_pnp(x3d, x2d, w2d, pose, camera, cost_fun, out_jacobian=False, out_
                             out_jacobian=out_jacobian)
 
 
+def rotate_offset(pose, offset):
+    """R(pose) @ offset for broadcastable leading dims, written out element-wise: a batched 3x3 @ 3x1 `matmul` over
+    (S, B) poses dispatches a BLAS GEMM per call (measured ~1 ms for 128 x 600 poses on MI355X)."""
+    ox, oy, oz = offset.unbind(-1)
+    if pose.size(-1) == 4:
+        c, s = torch.cos(pose[..., 3]), torch.sin(pose[..., 3])
+        return torch.stack((c * ox + s * oz, oy.expand_as(c), c * oz - s * ox), dim=-1)
+    rot = quaternion_to_rot_mat(pose[..., 3:])
+    return (rot * offset.unsqueeze(-2)).sum(dim=-1)
+
+
 def pnp_normalize(x3d, pose=None, detach_transformation=True):
     """Centre x3d on its mean; shift the pose translation accordingly.  -> offset (*,3), x3d_norm, pose_norm|None."""
     offset = (x3d.detach() if detach_transformation else x3d).mean(dim=-2)
     x3d_norm = x3d - offset.unsqueeze(-2)
     if pose is None:
         return offset, x3d_norm, None
-    shift = torch.matmul(pose_rotation(pose), offset.unsqueeze(-1)).squeeze(-1)
-    return offset, x3d_norm, torch.cat((pose[..., :3] + shift, pose[..., 3:]), dim=-1)
+    return offset, x3d_norm, torch.cat((pose[..., :3] + rotate_offset(pose, offset), pose[..., 3:]), dim=-1)
 
 
 def pnp_denormalize(offset, pose_norm):
-    shift = torch.matmul(pose_rotation(pose_norm), offset.unsqueeze(-1)).squeeze(-1)
-    return torch.cat((pose_norm[..., :3] - shift, pose_norm[..., 3:]), dim=-1)
+    return torch.cat((pose_norm[..., :3] - rotate_offset(pose_norm, offset), pose_norm[..., 3:]), dim=-1)

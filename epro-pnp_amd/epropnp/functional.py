@@ -237,3 +237,13 @@ class _McPoseLoss(torch.autograd.Function):
 
 def mc_pose_loss(logweights, cost_target):
     return _McPoseLoss.apply(logweights, cost_target)
+
+
+def rslm_draw(w2d, num_proposals, num_points, seed, offset):
+    """(B,N,2) weights -> (P,B,n) int64 indices, weighted sampling without replacement per (proposal, object)."""
+    w = _f32c(w2d, 'w2d')
+    B, N, _ = w.shape
+    inds = torch.empty((num_proposals, B, num_points), dtype=torch.int64, device=w.device)
+    _hip.call('epropnp_rslm_draw', _hip.ptr(w), B, N, int(num_proposals), int(num_points), int(seed), int(offset),
+              _hip.ptr(inds), _hip.stream_of(w))
+    return inds

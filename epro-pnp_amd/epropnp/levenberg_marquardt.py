@@ -120,8 +120,10 @@ class RSLMSolver(LMSolver):
 
     def center_based_init(self, x2d, x3d, camera, eps=1e-6):
         """Translation guess from the centroid / spread of the back-projected 2D points."""
-        ones = torch.ones_like(x2d[..., :1])
-        rays = solve_wrapper(torch.cat((x2d, ones), dim=-1).transpose(-1, -2), camera.cam_mats).transpose(-1, -2)
+        # back-project through K^-1 (explicit 3x3 inverse applied element-wise: no batched LU / GEMM launches)
+        kinv = torch.linalg.inv(camera.cam_mats)
+        xh = torch.cat((x2d, torch.ones_like(x2d[..., :1])), dim=-1)
+        rays = (xh.unsqueeze(-2) * kinv.unsqueeze(-3)).sum(dim=-1)
         rays = rays[..., :2] / rays[..., 2:].clamp(min=eps)
         ray_std, ray_mean = torch.std_mean(rays, dim=-2)
         x3d_std = torch.std(x3d, dim=-2)
@@ -136,8 +138,16 @@ class RSLMSolver(LMSolver):
         initial rotations (P,B) yaw in [0, 2 pi) or (P,B,4) unit quaternions.  Overridable for reproducibility."""
         bs, pn, _ = w2d.shape
         P = self.num_proposals
-        mean_weight = w2d.mean(dim=-1).reshape(1, bs, pn).expand(P, -1, -1).reshape(-1, pn)
-        inds = torch.multinomial(mean_weight, self.num_points).reshape(P, bs, self.num_points)
+        from . import _hip
+        if _hip.on_hip_path(w2d) and pn * 4 <= 64 * 1024:
+            # one kernel (exponential-race keys + wave argmin) instead of torch.multinomial's top-k on (P*B, N)
+            if not hasattr(self, '_draw_seed'):
+                self._draw_seed, self._draw_calls = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
+            inds = hip.rslm_draw(w2d, P, self.num_points, self._draw_seed, self._draw_calls)
+            self._draw_calls += 1
+        else:
+            mean_weight = w2d.mean(dim=-1).reshape(1, bs, pn).expand(P, -1, -1).reshape(-1, pn)
+            inds = torch.multinomial(mean_weight, self.num_points).reshape(P, bs, self.num_points)
         if self.dof == 4:
             rot = torch.rand((P, bs), dtype=w2d.dtype, device=w2d.device) * (2 * math.pi)
         else:

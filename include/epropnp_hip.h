@@ -133,6 +133,13 @@ int epropnp_mc_loss_forward(const float* logweights, const float* cost_target, i
 int epropnp_mc_loss_backward(const float* logweights, const float* lse, const float* loss, const float* grad_loss,
                              int32_t mc_samples, int32_t num_obj, float* grad_logweights, void* stream);
 
+/* Sub-sample indices of the RSLM initialiser (epropnp/levenberg_marquardt.py:305-308): for each of the P x B
+ * (proposal, object) rows draw n_pts distinct point indices with probability proportional to mean(w2d[b,n,:]),
+ * sequentially without replacement (exponential-race keys -log(u)/w, the n_pts smallest win; same law as
+ * torch.multinomial(replacement=False)).   w2d (B,N,2) -> inds (P,B,n_pts) int64, Philox(seed, offset). */
+int epropnp_rslm_draw(const float* w2d, int32_t num_obj, int32_t num_pts, int32_t num_proposals, int32_t n_pts,
+                      uint64_t seed, uint64_t offset, int64_t* inds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,3 +220,24 @@ def test_fused_delta_and_loss_match_torch(backend):
     torch.testing.assert_close(logw.grad.cpu()[:, keep], lr.grad[:, keep], rtol=1e-4, atol=1e-6)
     assert (logw.grad[:, 2] == 0).all() and ct.grad[2].item() == 0.0
     torch.testing.assert_close(ct.grad.cpu()[keep], cr.grad[keep], rtol=1e-6, atol=1e-7)
+
+
+def test_rslm_draw_is_weighted_sampling_without_replacement(backend):
+    from epropnp import functional as F
+    g = torch.Generator().manual_seed(9)
+    B, N, P, n = 4, 40, 3000 if backend.type == 'cuda' else 300, 6
+    w = torch.rand(B, N, 2, generator=g)
+    w[:, :5] *= 8.0                       # five heavy points
+    w[0, 7] = 0.0                         # never selected
+    inds = F.rslm_draw(w.to(backend), P, n, seed=5, offset=0).cpu()
+    assert inds.shape == (P, B, n) and inds.min() >= 0 and inds.max() < N
+    srt = inds.sort(-1).values
+    assert (srt[..., 1:] != srt[..., :-1]).all()                      # distinct within a row
+    assert not (inds[:, 0] == 7).any()
+    first = inds[:, :, 0]                                             # first pick ~ categorical(mean weight)
+    pw = w.mean(-1)
+    pw = pw / pw.sum(-1, keepdim=True)
+    for b in range(B):
+        freq = torch.bincount(first[:, b], minlength=N).float() / P
+        assert (freq - pw[b]).abs().max() < 6 * (pw[b].max() / P) ** 0.5 + 2.0 / P
+    assert not torch.equal(inds, F.rslm_draw(w.to(backend), P, n, seed=5, offset=1).cpu())

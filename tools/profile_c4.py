@@ -1,0 +1,25 @@
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'epro-pnp_amd'))
+import bench
+from epropnp.camera import PerspectiveCamera
+from epropnp.cost_fun import AdaptiveHuberPnPCost
+from epropnp.epropnp import EProPnP4DoF
+from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+from epropnp.losses import monte_carlo_pose_loss
+dev = torch.device('cuda:0')
+B, N = 600, 128
+p = bench.synth_problem(B, N, dev, seed=5, dof=4)
+x3d, x2d, w2d = (p[k].requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+cam = PerspectiveCamera(z_min=0.1, allowed_border=200)
+cam.set_param(p['cam_mats'], img_shape=torch.tensor([[480., 640.]], device=dev).expand(B, 2))
+cf4 = AdaptiveHuberPnPCost(relative_delta=0.5)
+layer4 = EProPnP4DoF(mc_samples=128, num_iter=4, normalize=True,
+                     solver=LMSolver(dof=4, num_iter=5, init_solver=RSLMSolver(dof=4, num_points=16, num_proposals=64, num_iter=3)))
+for it in range(8):
+    for tt in (x3d, x2d, w2d):
+        tt.grad = None
+    cf4.set_param(x2d.detach(), w2d)
+    o = layer4.monte_carlo_forward(x3d, x2d, w2d, cam, cf4, pose_init=p['pose_init'], force_init_solve=True)
+    monte_carlo_pose_loss(o[4], o[5]).mean().backward()
+torch.cuda.synchronize()
