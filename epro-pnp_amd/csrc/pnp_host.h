@@ -84,6 +84,9 @@ inline bool env_ints(const char* name, int* out, int n) {
 int launch_evaluate_cost(const epropnp_problem* prob, const float* poses, int num_poses, float* cost, hipStream_t st);
 int launch_normal_equations(const epropnp_problem* prob, const float* pose, int clip_jac, float* jtj, float* jtr,
                             float* cost, hipStream_t st);
+int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, hipStream_t st);
+int launch_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
+                            float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);
 int launch_rslm_draw(const float* w2d, int B, int N, int P, int n_pts, unsigned long long seed, unsigned long long offset,
                      long long* inds, hipStream_t st);
 int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, float rel, float* delta, float* stats,

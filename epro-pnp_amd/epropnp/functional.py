@@ -247,3 +247,37 @@ def rslm_draw(w2d, num_proposals, num_points, seed, offset):
     _hip.call('epropnp_rslm_draw', _hip.ptr(w), B, N, int(num_proposals), int(num_points), int(seed), int(offset),
               _hip.ptr(inds), _hip.stream_of(w))
     return inds
+
+
+class _GnStep(torch.autograd.Function):
+    """step = -(J^T J + eps I)^-1 J^T r at `pose`, differentiable w.r.t. x3d, x2d, w2d, delta (one sweep forward,
+    two sweeps backward, nothing materialised; reference: levenberg_marquardt.py:243-253 + autograd)."""
+
+    @staticmethod
+    def forward(ctx, x3d, x2d, w2d, delta, prob, pose, eps):
+        ps = _f32c(pose, 'pose')
+        step = prob.new(prob.B, prob.dof)
+        _hip.call('epropnp_gn_step_forward', C.byref(prob.c), float(eps), _hip.ptr(ps), _hip.ptr(step), prob.stream)
+        ctx.prob, ctx.eps = prob, float(eps)
+        ctx.save_for_backward(ps)
+        ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
+        return step
+
+    @staticmethod
+    def backward(ctx, g):
+        (ps,) = ctx.saved_tensors
+        prob = ctx.prob
+        B, N = prob.B, prob.N
+        g = g.contiguous()
+        gx3d, gx2d, gw2d, gdel = prob.new(B, N, 3), prob.new(B, N, 2), prob.new(B, N, 2), prob.new(B)
+        _hip.call('epropnp_gn_step_backward', C.byref(prob.c), ctx.eps, _hip.ptr(ps), _hip.ptr(g), _hip.ptr(gx3d),
+                  _hip.ptr(gx2d), _hip.ptr(gw2d), _hip.ptr(gdel), prob.stream)
+        gdelta = None
+        if ctx.delta_shape is not None and ctx.needs_input_grad[3]:
+            gdelta = gdel.sum() if len(ctx.delta_shape) == 0 else gdel.reshape(ctx.delta_shape)
+        return (gx3d if ctx.needs_input_grad[0] else None, gx2d if ctx.needs_input_grad[1] else None,
+                gw2d if ctx.needs_input_grad[2] else None, gdelta, None, None, None)
+
+
+def gn_step(x3d, x2d, w2d, delta, prob, pose, eps):
+    return _GnStep.apply(x3d, x2d, w2d, delta, prob, pose, eps)

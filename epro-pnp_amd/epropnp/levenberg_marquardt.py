@@ -95,7 +95,13 @@ class LMSolver(nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def gn_step(self, x3d, x2d, w2d, pose, camera, cost_fun):
-        """One differentiable Gauss-Newton step at `pose` (used for the derivative-regularisation loss)."""
+        """One differentiable Gauss-Newton step at `pose` (used for the derivative-regularisation loss).
+        On HIP tensors: fused forward / backward kernels (csrc/gn_step_kernel.hip); otherwise the PyTorch composite."""
+        from . import _hip
+        if x2d.dim() == 3 and x2d.size(0) > 0 and not pose.requires_grad and _hip.on_hip_path(x3d, x2d, w2d, pose):
+            prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+            delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
+            return hip.gn_step(x3d, x2d, w2d, delta, prob, pose, self.eps)
         residual, _, jac = evaluate_pnp(x3d, x2d, w2d, pose, camera, cost_fun, out_jacobian=True, out_residual=True)
         jac_t = jac.transpose(-1, -2)
         jtj = jac_t @ jac + self.eps * torch.eye(self.dof, device=jac.device, dtype=jac.dtype)

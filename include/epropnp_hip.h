@@ -133,6 +133,14 @@ int epropnp_mc_loss_forward(const float* logweights, const float* cost_target, i
 int epropnp_mc_loss_backward(const float* logweights, const float* lse, const float* loss, const float* grad_loss,
                              int32_t mc_samples, int32_t num_obj, float* grad_logweights, void* stream);
 
+/* LMSolver.gn_step (epropnp/levenberg_marquardt.py:243-253), the differentiable Gauss-Newton step behind
+ * `pose_opt_plus`:  step = -(J^T J + eps I)^-1 J^T r  at `pose` (clip_jac on).   pose (B,pose_len) -> step (B,dof). */
+int epropnp_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, void* stream);
+/* Its backward w.r.t. x3d, x2d, w2d, delta (the pose is not differentiated, as in the reference):
+ * grad_step (B,dof) -> grad_x3d (B,N,3), grad_x2d (B,N,2), grad_w2d (B,N,2), grad_delta (B,). */
+int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
+                             float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream);
+
 /* Sub-sample indices of the RSLM initialiser (epropnp/levenberg_marquardt.py:305-308): for each of the P x B
  * (proposal, object) rows draw n_pts distinct point indices with probability proportional to mean(w2d[b,n,:]),
  * sequentially without replacement (exponential-race keys -log(u)/w, the n_pts smallest win; same law as
