@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['eval_kernels.hip', 'lm_kernel.hip', 'amis_kernels.hip', 'amis_forward_mfma.hip', 'gn_step_kernel.hip', 'c_api.hip']
+SOURCES = ['eval_kernels.hip', 'lm_kernel.hip', 'amis_kernels.hip', 'amis_forward_mfma.hip', 'amis_backward_mfma.hip', 'gn_step_kernel.hip', 'c_api.hip']
 HEADERS = ['pnp_math.h', 'wave_ops.h', 'pnp_sweep.h', 'pnp_host.h', 'dispatch.h', 'amis_common.h']
 
 
@@ -33,7 +33,7 @@ def _run(cmd):
     return r.stdout + r.stderr
 
 
-def build(emu=False, force=False, verbose=False, defines=(), tag=None):
+def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=()):
     deps_common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, 'include', 'epropnp_hip.h')]
     if emu:
         out_dir = os.path.join(ROOT, 'tests', 'emu', '_build')
@@ -47,7 +47,7 @@ def build(emu=False, force=False, verbose=False, defines=(), tag=None):
         lib = os.path.join(out_dir, 'libepropnp_hip.so')
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
         cc = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value']
-        cc += ['-D' + d for d in defines]
+        cc += ['-D' + d for d in defines] + list(flags)
     os.makedirs(out_dir, exist_ok=True)
     objs, jobs = [], []
     for src in SOURCES:
@@ -74,5 +74,6 @@ if __name__ == '__main__':
     ap.add_argument('-v', '--verbose', action='store_true')
     ap.add_argument('-D', dest='defines', action='append', default=[], help='extra -D for a tuning variant')
     ap.add_argument('--tag', default=None, help='build into lib/variants/<tag>/ (tuning variants)')
+    ap.add_argument('--flag', dest='flags', action='append', default=[], help='extra compiler flag for a tuning variant')
     a = ap.parse_args()
-    print(build(a.emu, a.force, a.verbose, a.defines, a.tag))
+    print(build(a.emu, a.force, a.verbose, a.defines, a.tag, a.flags))

@@ -1,0 +1,263 @@
+// amis_backward_mfma.hip -- backward of the AMIS log-weights with the pose x point projection on the matrix cores.
+//
+// Same contract as amis_backward_kernel (amis_kernels.hip): gradient of
+//     sum_j a_j * cost(pose_j; x3d, x2d, w2d, delta),   a_j = -g_logw[j]  (+ g_init * cost(pose_init))
+// w.r.t. the correspondences, recomputed from the points (the reference replays autograd through evaluate_pnp,
+// epropnp/common.py:67-100, camera.py:21-30,81-93, cost_fun.py:45-61).  What differs is where the arithmetic runs:
+//   * forward projection  h = (K R | K t)(X,Y,Z,1)^T of 16 poses x 16 points: three v_mfma_f32_16x16x4_f32, exactly
+//     as in amis_forward_mfma.hip (A = pose rows from LDS, B = point tile in a register);
+//   * back-projection  g_x3d[n] += sum_j (K R)_j^T g_h[j,n] stays on the VALU (9 FMAs per pair).  It IS expressible as
+//     the same MFMA with the roles swapped (A = the per-pair g_h values, which the forward MFMA leaves in exactly the
+//     lane layout an A operand needs; B = pose rows indexed by output coordinate), and that variant was built and
+//     measured: 12 more MFMAs per 16x16 tile for 3 useful output columns of 16, each waiting on VALU results and on
+//     the previous accumulate -- 1.6-1.9 ms instead of 1.08 ms at C2 (profiles/r01_bwd_mfma_sweep.txt).  Dropped.
+//   * the VALU keeps what is genuinely per pair: perspective divide, weighted residual, Huber weight, and the
+//     accumulation of the gradients (~40 instructions, 2 of them transcendental).
+// The weighted poses are built ONCE into an LDS table (compacted: poses whose weight is below 2^-30 of the object's
+// largest are dropped before tiling, see amis_kernels.hip), then every wave sweeps all pose tiles for its own points.
+#include "amis_common.h"
+#include "dispatch.h"
+
+namespace pnp {
+
+#ifndef EPROPNP_EMU
+typedef float bwd_floatx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bwd_floatx4 bwd_mfma(float a, float b, bwd_floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+#else
+typedef floatx4_emu bwd_floatx4;
+__device__ __forceinline__ bwd_floatx4 bwd_mfma(float a, float b, bwd_floatx4 c) { return emu::mfma_16x16x4(a, b, c); }
+#endif
+
+template <int DOF, bool BOUNDS, int NPT>
+__global__ __launch_bounds__(512, 2) void amis_backward_mfma_kernel(Problem p, const float* __restrict__ pose_samples,
+                                                                     const float* __restrict__ g_logw, int S,
+                                                                     const float* __restrict__ pose_init,
+                                                                     const float* __restrict__ g_init, int P16,
+                                                                     float* __restrict__ gx3d, float* __restrict__ gx2d,
+                                                                     float* __restrict__ gw2d, float* __restrict__ gdelta) {
+  constexpr int PL = PoseLen<DOF>::value;
+  const int b = object_of_block(p.B);
+  if (b >= p.B) return;
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), W = T >> 6;
+
+  PNP_DYN_SMEM(float, smem);
+  float* ptab = smem;                                   // [P16][12]  x | y | z rows of (K R | K t), compacted
+  float* wtab = ptab + 12 * P16;                        // [P16]      weights of the compacted poses
+  float* wraw = wtab + P16;                             // [P16]      weights by sample index (0 = dropped)
+  int* idx = reinterpret_cast<int*>(wraw + P16);        // [P16]      sample index of compacted pose c
+  float* red = reinterpret_cast<float*>(idx + P16);     // [80]       reductions, lane counts, active count
+
+  float Kc[9], delta;
+  Bounds bd;
+  load_camera<BOUNDS>(p, b, Kc, bd, delta);
+  const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
+
+  const bool with_init = (pose_init != nullptr) && (g_init != nullptr);
+  const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
+
+  // ---- weights, drop threshold, compaction ----
+  constexpr float kSkipRel = 9.313225746154785e-10f;   // 2^-30, see amis_backward_kernel
+  float amax = 0.f;
+  for (int m = tid; m < S; m += T) amax = fmaxf(amax, fabsf(g_logw[(size_t)m * p.B + b]));
+  amax = block_max(amax, red);
+  const float askip = amax * kSkipRel;
+  for (int m = tid; m < P; m += T) {
+    float w = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init[b];       // logw = -cost - const
+    if (m < S && fabsf(w) <= askip) w = 0.f;
+    wraw[m] = w;
+  }
+  __syncthreads();
+  if (wv == 0) {     // ordered compaction by one wave: lane l owns the contiguous samples [l*seg, (l+1)*seg)
+    const int seg = (P + 63) >> 6;
+    const int m0 = lane * seg, m1 = min(P, m0 + seg);
+    int cnt = 0;
+    for (int m = m0; m < m1; ++m) cnt += (wraw[m] != 0.f) ? 1 : 0;
+    int* lcnt = reinterpret_cast<int*>(red);
+    lcnt[lane] = cnt;
+    wave_lds_fence();
+    int off = 0, total = 0;
+    for (int l = 0; l < 64; ++l) {
+      const int c = lcnt[l];
+      off += (l < lane) ? c : 0;
+      total += c;
+    }
+    for (int m = m0; m < m1; ++m)
+      if (wraw[m] != 0.f) idx[off++] = m;
+    if (lane == 0) lcnt[64] = total;
+  }
+  __syncthreads();
+  const int nact = reinterpret_cast<const int*>(red)[64];
+  const int ntile = (nact + 15) >> 4;
+  for (int c = tid; c < ntile * 16; c += T) {
+    float4* row = reinterpret_cast<float4*>(ptab + 12 * c);
+    if (c < nact) {
+      const int m = idx[c];
+      const float* src = (m < S) ? pose_samples + ((size_t)m * p.B + b) * PL : pose_init + (size_t)b * PL;
+      float ps[PL], R[9], KR[9], Kt[3];
+#pragma unroll
+      for (int i = 0; i < PL; ++i) ps[i] = src[i];
+      pose_to_rot<DOF>(ps, R);
+      compose_kr_kt(Kc, R, ps, KR, Kt);
+      row[0] = make_float4(KR[0], KR[1], KR[2], Kt[0]);
+      row[1] = make_float4(KR[3], KR[4], KR[5], Kt[1]);
+      row[2] = make_float4(KR[6], KR[7], KR[8], Kt[2]);
+      wtab[c] = wraw[m];
+    } else {     // padding of the last tile: a harmless pose (depth 1) with zero weight
+      row[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      row[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      row[2] = make_float4(0.f, 0.f, 0.f, 1.f);
+      wtab[c] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int col = lane & 15, kk = lane >> 4, g4 = kk * 4;
+  const float ind0 = (col == 0) ? 1.f : 0.f, ind1 = (col == 1) ? 1.f : 0.f, ind2 = (col == 2) ? 1.f : 0.f,
+              ind3 = (col == 3) ? 1.f : 0.f;
+  float gd = 0.f;
+  const int chunk_pts = W * NPT * 16;
+  for (int c0 = 0; c0 < p.N; c0 += chunk_pts) {
+    // this wave's point tiles q = wv + W * i of the chunk; lane = (point column, k)
+    float rB[NPT];
+    float4 rW[NPT];
+    float A1x[NPT], A1y[NPT], A2x[NPT], A2y[NPT];
+    float gXv[NPT], gYv[NPT], gZv[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const Point q = load_point(p, b, c0 + (wv + W * i) * 16 + col);      // zero weight beyond N
+      rB[i] = (kk == 0) ? q.X : (kk == 1) ? q.Y : (kk == 2) ? q.Z : 1.0f;
+      rW[i] = make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
+      A1x[i] = A1y[i] = A2x[i] = A2y[i] = 0.f;
+      gXv[i] = gYv[i] = gZv[i] = 0.f;
+    }
+    const bwd_floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < ntile; ++t) {
+      const float* arow = ptab + 12 * (t * 16 + col) + kk;
+      const float ax = arow[0], ay = arow[4], az = arow[8];
+      const float4 a4 = *reinterpret_cast<const float4*>(wtab + t * 16 + g4);
+      const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
+      float4 krx[4], kry[4], krz[4];     // this lane's 4 poses: rows of (K R | K t), for the back-projection
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4* prow = reinterpret_cast<const float4*>(ptab + 12 * (t * 16 + g4 + r));
+        krx[r] = prow[0]; kry[r] = prow[1]; krz[r] = prow[2];
+      }
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        const bwd_floatx4 hx = bwd_mfma(ax, rB[i], zero);
+        const bwd_floatx4 hy = bwd_mfma(ay, rB[i], zero);
+        const bwd_floatx4 hz = bwd_mfma(az, rB[i], zero);
+        const float4 w4 = rW[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool front = hz[r] >= zmin_v;
+          const float zc = front ? hz[r] : zmin_v;
+          const float rz = fast_rcp(zc);
+          const float ppx = hx[r] * rz, ppy = hy[r] * rz;          // un-clamped projection
+          float px = ppx, py = ppy;
+          if (BOUNDS) {
+            px = fminf(fmaxf(px, bd.lbx), bd.ubx);
+            py = fminf(fmaxf(py, bd.lby), bd.uby);
+          }
+          const float rx = fmaf(px, w4.x, w4.z), ry = fmaf(py, w4.y, w4.w);
+          const float s2 = fmaf(rx, rx, ry * ry);
+          const float rs = fast_rsqrt(fmaxf(s2, 1e-30f));
+          const float rho = s2 * rs;
+          const float mm = fminf(rho, delta_v);
+          const float coef = aw[r] * mm * rs;                  // a * min(1, delta / rho)
+          gd = fmaf(aw[r], rho - mm, gd);                      // d huber / d delta = max(rho - delta, 0)
+          const float crx = coef * rx, cry = coef * ry;
+          // d/dw = crx * (px - u) = crx * rx / w and d/du = -crx * w: the per-point factors are applied once at the end
+          A2x[i] = fmaf(crx, rx, A2x[i]);
+          A2y[i] = fmaf(cry, ry, A2y[i]);
+          A1x[i] += crx;
+          A1y[i] += cry;
+          float gpx = crx * w4.x, gpy = cry * w4.y;
+          if (BOUNDS) {                                        // the clamp passes no gradient where it is active
+            gpx = (ppx < bd.lbx || ppx > bd.ubx) ? 0.f : gpx;
+            gpy = (ppy < bd.lby || ppy > bd.uby) ? 0.f : gpy;
+          }
+          const float ghx = gpx * rz, ghy = gpy * rz;
+          float ghz = fmaf(-ghx, ppx, -(ghy * ppy));
+          ghz = front ? ghz : 0.f;
+          gXv[i] = fmaf(krx[r].x, ghx, fmaf(kry[r].x, ghy, fmaf(krz[r].x, ghz, gXv[i])));
+          gYv[i] = fmaf(krx[r].y, ghx, fmaf(kry[r].y, ghy, fmaf(krz[r].y, ghz, gYv[i])));
+          gZv[i] = fmaf(krx[r].z, ghx, fmaf(kry[r].z, ghy, fmaf(krz[r].z, ghz, gZv[i])));
+        }
+      }
+    }
+    // ---- outputs of this chunk: sums over the 4 pose groups of a point via MFMAs against indicator columns ----
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      bwd_floatx4 D1 = zero;
+      D1 = bwd_mfma(gXv[i], ind0, D1);
+      D1 = bwd_mfma(gYv[i], ind1, D1);
+      D1 = bwd_mfma(gZv[i], ind2, D1);
+      const float4 w4 = rW[i];
+      bwd_floatx4 D2 = zero;
+      D2 = bwd_mfma(-w4.x * A1x[i], ind0, D2);                               // d/du
+      D2 = bwd_mfma(-w4.y * A1y[i], ind1, D2);                               // d/dv
+      D2 = bwd_mfma((w4.x != 0.f) ? A2x[i] / w4.x : 0.f, ind2, D2);          // d/dwu
+      D2 = bwd_mfma((w4.y != 0.f) ? A2y[i] / w4.y : 0.f, ind3, D2);          // d/dwv
+      const int nb = c0 + (wv + W * i) * 16 + g4;     // D rows: points nb + r; column = lane & 15
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + r;
+        if (n < p.N) {
+          const size_t o = (size_t)b * p.N + n;
+          if (col < 3) gx3d[o * 3 + col] = D1[r];
+          if (col < 2) gx2d[o * 2 + col] = D2[r];
+          else if (col < 4) gw2d[o * 2 + (col - 2)] = D2[r];
+        }
+      }
+    }
+  }
+  float one[1] = {gd};
+  block_sum<1>(one, red);
+  if (tid == 0) gdelta[b] = one[0];
+}
+
+template <class F>
+static int dispatch_bwd_npt(int npt, F&& f) {
+  switch (npt) {
+    case 1: return f(ic<1>{});
+    case 2: return f(ic<2>{});
+    case 4: return f(ic<4>{});
+    default: return f(ic<8>{});
+  }
+}
+
+// returns 1 when the shape is not supported (caller falls back to amis_backward_kernel)
+int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                              int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
+                              float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st) {
+  const Problem d = to_device_problem(prob);
+  const int P = mc_samples + ((pose_init && grad_cost_init) ? 1 : 0);
+  const int P16 = ((P + 15) / 16) * 16 + 16;
+  const size_t smem = sizeof(float) * (15 * (size_t)P16 + 80);
+  if (smem > 160 * 1024) return 1;
+  // 4 waves x NPT <= 4 point tiles of 16 per chunk (<= 164 VGPRs: 3 workgroups per CU); larger N loops over chunks of
+  // 256 points against the LDS-resident pose table.  Measured at C2: 4x4 (2 chunks) 1.07 ms, 4x8 1.11, 8x4 1.22.
+  const int ptiles = (d.N + 15) / 16;
+  int waves = 4, npt = 1;
+  while (npt < 4 && waves * npt < ptiles) npt *= 2;
+  { int ov[2]; if (env_ints("EPROPNP_BWD_MFMA", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8)) { waves = ov[0]; npt = ov[1]; } }
+  const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
+  dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+    return dispatch_bwd_npt(npt, [&](auto NPT) -> int {
+      auto kern = amis_backward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
+#ifndef EPROPNP_EMU
+      if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+      PNP_LAUNCH(kern, grid, block, smem, st, d, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init, P16,
+                 grad_x3d, grad_x2d, grad_w2d, grad_delta);
+      return 0;
+    });
+  });
+  return check_launch("amis_backward_mfma_kernel");
+}
+
+}  // namespace pnp

@@ -377,6 +377,16 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
   if (mc_samples < 0) return fail(EPROPNP_EINVAL, "amis_backward: negative mc_samples");
   if ((mc_samples > 0 && (!pose_samples || !grad_logweights)) || !grad_x3d || !grad_x2d || !grad_w2d || !grad_delta)
     return fail(EPROPNP_EINVAL, "amis_backward: NULL pointer");
+  {   // many objects: projection on the matrix cores (amis_backward_mfma.hip); EPROPNP_BWD_IMPL=valu|mfma forces one
+    const char* impl = getenv("EPROPNP_BWD_IMPL");
+    // few objects: this file's kernel spreads one object over more waves (choose_shape) and wins (C3 / C4 shapes)
+    const bool want_mfma = impl ? (impl[0] == 'm') : (prob->num_obj >= 2048 || prob->num_pts > kMaxResidentPoints);
+    if (want_mfma) {
+      const int rc = launch_amis_backward_mfma(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init,
+                                               grad_x3d, grad_x2d, grad_w2d, grad_delta, st);
+      if (rc <= 0) return rc;     // 1 = shape not supported there (pose table larger than LDS)
+    }
+  }
   if (prob->num_pts > kMaxResidentPoints)
     return fail(EPROPNP_EINVAL, "amis_backward: num_pts %d exceeds the register-resident limit %d", prob->num_pts,
                 kMaxResidentPoints);

@@ -84,6 +84,9 @@ inline bool env_ints(const char* name, int* out, int n) {
 int launch_evaluate_cost(const epropnp_problem* prob, const float* poses, int num_poses, float* cost, hipStream_t st);
 int launch_normal_equations(const epropnp_problem* prob, const float* pose, int clip_jac, float* jtj, float* jtr,
                             float* cost, hipStream_t st);
+int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                              int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
+                              float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);
 int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, hipStream_t st);
 int launch_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
                             float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);

@@ -42,19 +42,19 @@ def worker(B, N, S, K, L, reps=8):
     t_fw, (smp, logw) = timeit(lambda: F.amis_forward(hp, pose_opt, cov, S, K, seed=1))
     g = -torch.softmax(logw, 0) / B
     gi = torch.full((B,), 1.0 / B, device=dev)
-    t_bw, _ = timeit(lambda: F.amis_backward(hp, smp, g, prob['pose_init'], gi))
+    t_bw, grads = timeit(lambda: F.amis_backward(hp, smp, g, prob['pose_init'], gi))
+    gsum = sum(float(t.double().abs().sum()) for t in grads)
     lse = torch.logsumexp(logw, 0).mean().item()
-    print(json.dumps(dict(lm_ms=round(t_lm, 4), fwd_ms=round(t_fw, 4), bwd_ms=round(t_bw, 4), lse=round(lse, 4))))
+    print(json.dumps(dict(lm_ms=round(t_lm, 4), fwd_ms=round(t_fw, 4), bwd_ms=round(t_bw, 4), lse=round(lse, 4), gsum=round(gsum, 6))))
 
 
 VARIANTS = [
-    ('default (mfma regs 4x8)', {}),
-    ('mfma: no sweep', {'EPROPNP_ABLATE': '1'}),
-    ('mfma: no refit', {'EPROPNP_ABLATE': '2'}),
-    ('mfma regs 8 waves x4', {'EPROPNP_FWD_MFMA': '8,4'}),
-    ('mfma regs 2 waves x16', {'EPROPNP_FWD_MFMA': '2,16'}),
-    ('mfma lds 4 waves', {'EPROPNP_FWD_MFMA': '4,0'}),
-    ('valu sweep', {'EPROPNP_FWD_IMPL': 'valu'}),
+    ('default', {}),
+    ('bwd valu (old)', {'EPROPNP_BWD_IMPL': 'valu'}),
+    ('bwd mfma 8w x4', {'EPROPNP_BWD_MFMA': '8,4'}),
+    ('bwd mfma 4w x4 (2 chunks)', {'EPROPNP_BWD_MFMA': '4,4'}),
+    ('bwd mfma 2w x8 (2 chunks)', {'EPROPNP_BWD_MFMA': '2,8'}),
+    ('fwd valu', {'EPROPNP_FWD_IMPL': 'valu'}),
 ]
 
 
@@ -76,7 +76,7 @@ def main():
                 e['EPROPNP_LIB'] = lib
             r = subprocess.run([sys.executable, __file__, '--worker'], env=e, capture_output=True, text=True)
             line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else 'FAILED ' + r.stderr.strip()[-300:]
-            print(f'{tag or "base":16s} {name:22s} {line}', flush=True)
+            print(f'{tag or "base":10s} {name:30s} {line}', flush=True)
 
 
 if __name__ == '__main__':
