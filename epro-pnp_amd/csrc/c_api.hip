@@ -76,4 +76,11 @@ int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float
                                       (hipStream_t)stream);
 }
 
+int epropnp_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int32_t num_proposals,
+                       int32_t num_points, uint64_t seed, uint64_t offset, const int64_t* inds, const float* rot,
+                       float* pose, float* cost, void* stream) {
+  return pnp::launch_rslm_solve(prob, lm, num_proposals, num_points, seed, offset, (const long long*)inds, rot, pose, cost,
+                                (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -7,28 +7,10 @@
 // d x d damped system is solved in registers by a Jacobi-scaled fp32 Cholesky (the matrix is SPD by construction;
 // the reference's unscaled LU with pivoting gives the same solution up to its own, larger, rounding error).
 #include "dispatch.h"
+#include "lm_core.h"
 #include "pnp_host.h"
 
 namespace pnp {
-
-struct LmParams {
-  int num_iter, fast_mode;
-  float min_diag, max_diag, min_rel_decrease, radius0, radius_max, eps;
-};
-
-// acc (upper-tri JtJ | Jtr | cost)  ->  dense symmetric matrix
-template <int DOF>
-PNP_FN void unpack_h(const float (&acc)[NormalEq<DOF>::NV], float (&H)[DOF][DOF]) {
-  int idx = 0;
-#pragma unroll
-  for (int i = 0; i < DOF; ++i)
-#pragma unroll
-    for (int j = i; j < DOF; ++j) {
-      H[i][j] = acc[idx];
-      H[j][i] = acc[idx];
-      ++idx;
-    }
-}
 
 // MAXW == 0 selects the small-problem variant: N <= 16 points, one object per 16-lane DPP row (4 objects per wave,
 // reductions are row_ror adds only) -- the shape of the RSLM initialiser's 10^4..10^5 sub-problems.
@@ -88,88 +70,7 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
 
   float cur[NV];
   int accepted_bits = 0;
-
-  if (lm.fast_mode) {
-    // Gauss-Newton (levenberg_marquardt.py:136-152): J^T J + eps I, no clip_jac; pose_cov / cost come from the
-    // last EVALUATED (pre-update) point.
-    for (int it = 0; it < lm.num_iter; ++it) {
-      sweep(pose, false, cur);
-      float H[DOF][DOF], g[DOF];
-      ScaledFactor<DOF> f;
-      unpack_h<DOF>(cur, H);
-#pragma unroll
-      for (int i = 0; i < DOF; ++i) {
-        H[i][i] += lm.eps;
-        g[i] = cur[NH + i];
-      }
-      scaled_cholesky<DOF>(H, f);
-      scaled_solve<DOF>(f, g);
-      float step[DOF], nxt[PL];
-#pragma unroll
-      for (int i = 0; i < DOF; ++i) step[i] = -g[i];
-      pose_add<DOF>(pose, step, nxt);
-#pragma unroll
-      for (int i = 0; i < PL; ++i) pose[i] = nxt[i];
-    }
-    if (lm.num_iter == 0) sweep(pose, false, cur);
-  } else {
-    // trust-region LM (Ceres-style), levenberg_marquardt.py:154-169 + _lm_iter
-    sweep(pose, true, cur);
-    float radius = lm.radius0, decrease = 2.0f;
-    for (int it = 0; it < lm.num_iter; ++it) {
-      float H[DOF][DOF], Hlm[DOF][DOF], g[DOF], st[DOF];
-      ScaledFactor<DOF> f;
-      unpack_h<DOF>(cur, H);
-#pragma unroll
-      for (int i = 0; i < DOF; ++i) {
-#pragma unroll
-        for (int j = 0; j < DOF; ++j) Hlm[i][j] = H[i][j];
-        // diagonal += clamp(diagonal, min, max) / radius + eps   (:210-211)
-        const float d = H[i][i];
-        Hlm[i][i] = d + (fminf(fmaxf(d, lm.min_diag), lm.max_diag) / radius + lm.eps);
-        g[i] = cur[NH + i];
-        st[i] = g[i];
-      }
-      scaled_cholesky<DOF>(Hlm, f);
-      scaled_solve<DOF>(f, st);   // st = Hlm^-1 g ; step = -st
-      float step[DOF], pose_new[PL];
-#pragma unroll
-      for (int i = 0; i < DOF; ++i) step[i] = -st[i];
-      pose_add<DOF>(pose, step, pose_new);
-
-      float nxt[NV];
-      sweep(pose_new, true, nxt);
-
-      // model_cost_change = -step^T (H step / 2 + g)     (:225)
-      float mcc = 0.f;
-#pragma unroll
-      for (int i = 0; i < DOF; ++i) {
-        float hs = 0.f;
-#pragma unroll
-        for (int j = 0; j < DOF; ++j) hs = fmaf(H[i][j], step[j], hs);
-        mcc -= step[i] * (0.5f * hs + g[i]);
-      }
-      const float model_change = mcc;
-      const float rel = (cur[NV - 1] - nxt[NV - 1]) / model_change;
-      const bool ok = (rel >= lm.min_rel_decrease) && (model_change > 0.0f);
-      if (ok) {   // wave-uniform
-        accepted_bits |= (1 << (it & 31));
-#pragma unroll
-        for (int i = 0; i < PL; ++i) pose[i] = pose_new[i];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
-        const float t3 = 2.0f * rel - 1.0f;
-        radius = radius / fmaxf(1.0f - t3 * t3 * t3, 1.0f / 3.0f);
-      }
-      radius = fminf(fmaxf(radius, lm.eps), lm.radius_max);   // clamp applies to every object (:235)
-      if (ok) {
-        decrease = 2.0f;
-      } else {
-        radius = radius / decrease;   // reject path is not re-clamped in the same iteration (:239)
-        decrease *= 2.0f;
-      }
-    }
-  }
+  lm_iterate<DOF>(lm, sweep, pose, cur, accepted_bits);
 
   if (writer) {
 #pragma unroll

@@ -1,0 +1,266 @@
+// rslm_kernel.hip -- the random-sample LM initialiser (RSLMSolver.solve) as ONE kernel.
+//
+// Replaces epropnp/levenberg_marquardt.py:283-353: center_based_init, the weighted sub-sampling without replacement
+// (torch.multinomial), the random rotations, P x B small LM solves on the sub-samples, the full-set cost of every
+// proposal and the argmin -- ~100 ATen launches and (P,B,n,.) gathered copies in the reference (and ~80 in this
+// package's composite path), none of which does enough work to fill the GPU at the detection shape (600 objects x
+// 128 points x 64 proposals).
+//
+// One 256-thread workgroup owns one object: its N correspondences are staged once in LDS; the 16 DPP rows of the
+// workgroup each run one proposal at a time (16 lanes = the <= 16 sub-sampled points): draw the indices (exponential
+// race keys in LDS, row-wide argmin per pick: the same law as torch.multinomial(replacement=False) and the same
+// Philox stream as rslm_draw_kernel), solve (lm_iterate, reductions are row_ror adds), score on all N points, keep
+// the best.  P / 16 rounds, then a 16-way argmin.
+#include "dispatch.h"
+#include "lm_core.h"
+#include "pnp_host.h"
+
+namespace pnp {
+
+constexpr int kRslmMaxPts = 512;    // LDS: 28 B (points) + 16 x 4 B (keys of the 16 proposals in flight) per point
+constexpr int kRslmRows = 16;       // DPP rows per workgroup
+
+PNP_FN float row_min16(float x) { return -row_max16(-x); }
+
+template <int DOF, bool BOUNDS>
+__global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
+                                                          unsigned long long offset, const long long* __restrict__ inds,
+                                                          const float* __restrict__ rot, float* __restrict__ pose_out,
+                                                          float* __restrict__ cost_out) {
+  constexpr int PL = PoseLen<DOF>::value;
+  constexpr int NV = NormalEq<DOF>::NV;
+  const int b = object_of_block(p.B);
+  if (b >= p.B) return;
+  const int tid = (int)threadIdx.x, l16 = tid & 15, row = tid >> 4, N = p.N;
+  const int Np = (N + 3) & ~3;
+  PNP_DYN_SMEM(float, smem);
+  float* sX = smem;                 // [N][3]
+  float* sU = sX + 3 * Np;          // [N][2]
+  float* sW = sU + 2 * Np;          // [N][2]
+  float* key = sW + 2 * Np;         // [16][Np]
+  float* red = key + kRslmRows * Np;   // [128]
+
+  float K[9], delta;
+  Bounds bd;
+  load_camera<BOUNDS>(p, b, K, bd, delta);
+  for (int n = tid; n < N; n += 256) {
+    const Point q = load_point(p, b, n);
+    sX[3 * n] = q.X; sX[3 * n + 1] = q.Y; sX[3 * n + 2] = q.Z;
+    sU[2 * n] = q.u; sU[2 * n + 1] = q.v;
+    sW[2 * n] = q.wu; sW[2 * n + 1] = q.wv;
+  }
+  __syncthreads();
+
+  // ---- center_based_init (:283-298): t0 = [mean(rays), 1] * depth, rays = dehomogenised K^-1 [x2d, 1] ----
+  float t0[3];
+  {
+    const float c00 = K[4] * K[8] - K[5] * K[7], c01 = K[2] * K[7] - K[1] * K[8], c02 = K[1] * K[5] - K[2] * K[4];
+    const float c10 = K[5] * K[6] - K[3] * K[8], c11 = K[0] * K[8] - K[2] * K[6], c12 = K[2] * K[3] - K[0] * K[5];
+    const float c20 = K[3] * K[7] - K[4] * K[6], c21 = K[1] * K[6] - K[0] * K[7], c22 = K[0] * K[4] - K[1] * K[3];
+    const float idet = 1.0f / (K[0] * c00 + K[1] * c10 + K[2] * c20);
+    auto ray = [&](int n, float& rx, float& ry) {
+      const float u = sU[2 * n], v = sU[2 * n + 1];
+      const float hx = (c00 * u + c01 * v + c02) * idet, hy = (c10 * u + c11 * v + c12) * idet;
+      const float hz = fmaxf((c20 * u + c21 * v + c22) * idet, 1e-6f);
+      rx = hx / hz;
+      ry = hy / hz;
+    };
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = tid; n < N; n += 256) {
+      float rx, ry;
+      ray(n, rx, ry);
+      s[0] += rx; s[1] += ry; s[2] += sX[3 * n]; s[3] += sX[3 * n + 1]; s[4] += sX[3 * n + 2];
+    }
+    block_sum<5>(s, red);
+    float mean[5], d2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) mean[i] = s[i] / (float)N;
+    for (int n = tid; n < N; n += 256) {
+      float rx, ry;
+      ray(n, rx, ry);
+      const float e[5] = {rx - mean[0], ry - mean[1], sX[3 * n] - mean[2], sX[3 * n + 1] - mean[3], sX[3 * n + 2] - mean[4]};
+#pragma unroll
+      for (int i = 0; i < 5; ++i) d2[i] = fmaf(e[i], e[i], d2[i]);
+    }
+    block_sum<5>(d2, red);
+    float var[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) var[i] = d2[i] / (float)(N - 1);      // unbiased, as torch.std
+    float depth;
+    if (DOF == 4) {
+      depth = sqrtf(var[3]) / fmaxf(sqrtf(var[1]), 1e-6f);
+    } else {
+      depth = 0.816496580927726f * sqrtf(var[2] + var[3] + var[4]) / fmaxf(sqrtf(var[0] + var[1]), 1e-6f);
+    }
+    t0[0] = mean[0] * depth; t0[1] = mean[1] * depth; t0[2] = depth;
+  }
+
+  float Kv[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Kv[i] = to_vgpr(K[i]);
+  const float delta_v = to_vgpr(delta), zmin_v = to_vgpr(p.z_min);
+
+  float best_cost = INFINITY, best_pose[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) best_pose[i] = 0.f;
+  float* mykey = key + row * Np;
+  for (int j0 = 0; j0 < P; j0 += kRslmRows) {
+    const bool active = (j0 + row) < P;
+    const int j = active ? j0 + row : P - 1;
+    const size_t prow = (size_t)j * p.B + b;                 // (proposal, object) row of the composite path
+
+    // ---- sub-sample: n_pts distinct indices ~ mean weight (:305-308) ----
+    int my_idx = -1;
+    if (inds != nullptr) {
+      if (l16 < n_pts) my_idx = (int)inds[prow * n_pts + l16];
+    } else {
+      for (int n = l16; n < N; n += 16) {
+        const float wm = 0.5f * (sW[2 * n] + sW[2 * n + 1]);
+        const Philox4 r = philox4x32_10((uint32_t)prow, (uint32_t)n, (uint32_t)offset, (uint32_t)(offset >> 32),
+                                        (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
+        mykey[n] = (wm > 0.f) ? -logf(u01(r.v[0])) / wm : INFINITY;
+      }
+      wave_lds_fence();
+      for (int k = 0; k < n_pts; ++k) {
+        float bestk = INFINITY, best_n = 1e9f;
+        for (int n = l16; n < N; n += 16) {
+          const float v = mykey[n];
+          if (v < bestk) { bestk = v; best_n = (float)n; }
+        }
+        const float m = row_min16(bestk);
+        const float cand = (bestk == m) ? best_n : 1e9f;
+        const float win = row_min16(cand);                   // lowest index among ties
+        const int wi = (win < 1e8f) ? (int)win : (k % N);    // fewer positive weights than n_pts
+        if (l16 == k) my_idx = wi;
+        if (l16 == (wi & 15)) mykey[wi] = INFINITY;
+        wave_lds_fence();
+      }
+    }
+    Point pt;
+    if (my_idx >= 0 && my_idx < N) {
+      pt.X = sX[3 * my_idx]; pt.Y = sX[3 * my_idx + 1]; pt.Z = sX[3 * my_idx + 2];
+      pt.u = sU[2 * my_idx]; pt.v = sU[2 * my_idx + 1];
+      pt.wu = sW[2 * my_idx]; pt.wv = sW[2 * my_idx + 1];
+    } else {
+      pt.X = pt.Y = pt.Z = pt.u = pt.v = pt.wu = pt.wv = 0.f;
+    }
+
+    // ---- starting pose: centre-based translation + random rotation (:310-321) ----
+    float pose[PL];
+    pose[0] = t0[0]; pose[1] = t0[1]; pose[2] = t0[2];
+    if (rot != nullptr) {
+#pragma unroll
+      for (int i = 3; i < PL; ++i) pose[i] = rot[prow * (PL - 3) + (i - 3)];
+    } else {
+      const Philox4 r = philox4x32_10((uint32_t)prow, 0xffffffffu, (uint32_t)offset, (uint32_t)(offset >> 32),
+                                      (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x9e3779b9u);
+      if (DOF == 4) {
+        pose[3] = u01(r.v[0]) * 6.283185307179586f;
+      } else {
+        float g[4];
+        box_muller(r.v[0], r.v[1], g[0], g[1]);
+        box_muller(r.v[2], r.v[3], g[2], g[3]);
+        const float nrm = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3]);
+        const bool degenerate = nrm < lm.eps;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pose[3 + (i < PL - 3 ? i : 0)] = degenerate ? (i == 0 ? 1.f : 0.f) : g[i] / nrm;
+      }
+    }
+
+    // ---- LM / GN on the sub-sample, one problem per DPP row ----
+    auto sweep = [&](const float* ps, bool clip, float (&acc)[NV]) {
+      float R[9], t[3];
+      pose_to_rot<DOF>(ps, R);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t[i] = ps[i];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+      point_normal_eq<DOF, BOUNDS>(pt, Kv, R, t, zmin_v, delta_v, bd, clip, acc);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] = row_sum16(acc[i]);
+    };
+    float cur[NV];
+    int bits = 0;
+    lm_iterate<DOF>(lm, sweep, pose, cur, bits);
+
+    // ---- score the proposal on the full correspondence set (:343, cost-only IEEE path as evaluate_cost_kernel) ----
+    float c = 0.f;
+    {
+      float R[9], KR[9], Kt[3];
+      pose_to_rot<DOF>(pose, R);
+      compose_kr_kt(K, R, pose, KR, Kt);
+      for (int n = l16; n < N; n += 16) {
+        const float X = sX[3 * n], Y = sX[3 * n + 1], Z = sX[3 * n + 2];
+        const float hx = KR[0] * X + KR[1] * Y + KR[2] * Z + Kt[0];
+        const float hy = KR[3] * X + KR[4] * Y + KR[5] * Z + Kt[1];
+        const float hz = KR[6] * X + KR[7] * Y + KR[8] * Z + Kt[2];
+        const float z = fmaxf(hz, p.z_min);
+        float px = hx / z, py = hy / z;
+        if (BOUNDS) {
+          px = fminf(fmaxf(px, bd.lbx), bd.ubx);
+          py = fminf(fmaxf(py, bd.lby), bd.uby);
+        }
+        const float rx = (px - sU[2 * n]) * sW[2 * n], ry = (py - sU[2 * n + 1]) * sW[2 * n + 1];
+        c += huber_exact(sqrtf(rx * rx + ry * ry), delta);
+      }
+      c = row_sum16(c);
+    }
+    if (active && (j0 == 0 || c < best_cost)) {
+      best_cost = c;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) best_pose[i] = pose[i];
+    }
+  }
+
+  // ---- argmin over the 16 rows (ties: lowest row = lowest proposal index of the first round) ----
+  __syncthreads();
+  float* cand = red;      // [16][PL + 1]
+  if (l16 == 0) {
+    cand[row * (PL + 1)] = (row < P) ? best_cost : INFINITY;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) cand[row * (PL + 1) + 1 + i] = best_pose[i];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int w = 0;
+    float wc = cand[0];
+    for (int r = 1; r < kRslmRows && r < P; ++r) {
+      const float cr = cand[r * (PL + 1)];
+      if (cr < wc) { wc = cr; w = r; }
+    }
+#pragma unroll
+    for (int i = 0; i < PL; ++i) pose_out[(size_t)b * PL + i] = cand[w * (PL + 1) + 1 + i];
+    if (cost_out) cost_out[b] = wc;
+  }
+}
+
+int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
+                      unsigned long long offset, const long long* inds, const float* rot, float* pose_out, float* cost_out,
+                      hipStream_t st) {
+  if (int rc = check_problem(prob)) return rc;
+  if (!lm) return fail(EPROPNP_EINVAL, "rslm_solve: params NULL");
+  if (prob->num_obj == 0) return EPROPNP_OK;
+  if (!pose_out) return fail(EPROPNP_EINVAL, "rslm_solve: NULL pose pointer");
+  if (P < 1 || n_pts < 1 || n_pts > 16)
+    return fail(EPROPNP_EINVAL, "rslm_solve: need num_proposals >= 1 and 1 <= num_points <= 16 (got %d, %d)", P, n_pts);
+  if (prob->num_pts < 2 || prob->num_pts > kRslmMaxPts)
+    return fail(EPROPNP_EINVAL, "rslm_solve: num_pts %d outside [2, %d]", prob->num_pts, kRslmMaxPts);
+  if (lm->num_iter < 0 || lm->num_iter > 31 * 1000) return fail(EPROPNP_EINVAL, "rslm_solve: bad num_iter");
+  const Problem d = to_device_problem(prob);
+  LmParams k;
+  k.num_iter = lm->num_iter; k.fast_mode = lm->fast_mode;
+  k.min_diag = lm->min_lm_diagonal; k.max_diag = lm->max_lm_diagonal;
+  k.min_rel_decrease = lm->min_relative_decrease; k.radius0 = lm->initial_trust_region_radius;
+  k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps;
+  const int Np = (d.N + 3) & ~3;
+  const size_t smem = sizeof(float) * ((size_t)(7 + kRslmRows) * Np + 128);
+  const dim3 grid(padded_object_grid(d.B)), block(256);
+  dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+    PNP_LAUNCH((rslm_solve_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, smem, st, d, k, P, n_pts, seed,
+               offset, inds, rot, pose_out, cost_out);
+    return 0;
+  });
+  return check_launch("rslm_solve_kernel");
+}
+
+}  // namespace pnp

@@ -93,6 +93,23 @@ __device__ __forceinline__ float row_sum16(float x) {
 #endif
 }
 
+// max over the 16 lanes of a DPP row (every lane of the row receives it)
+__device__ __forceinline__ float row_max16(float x) {
+#ifndef EPROPNP_EMU
+  x = fmaxf(x, dpp_mov<0x128>(x));
+  x = fmaxf(x, dpp_mov<0x124>(x));
+  x = fmaxf(x, dpp_mov<0x122>(x));
+  x = fmaxf(x, dpp_mov<0x121>(x));
+  return x;
+#else
+  for (int m : {8, 4, 2, 1}) {
+    const int l = lane_id();
+    x = fmaxf(x, emu::shfl(x, (l & ~15) | ((l + m) & 15)));
+  }
+  return x;
+#endif
+}
+
 // Orders this wave's earlier LDS writes before its later LDS reads of OTHER lanes' data.  The hardware executes a
 // wave's DS instructions in order, so no s_barrier is needed; this only stops the compiler from reordering.
 __device__ __forceinline__ void wave_lds_fence() {

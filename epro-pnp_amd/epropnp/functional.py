@@ -249,6 +249,29 @@ def rslm_draw(w2d, num_proposals, num_points, seed, offset):
     return inds
 
 
+RSLM_MAX_POINTS = 512      # epropnp_rslm_solve keeps an object's correspondences + 16 key rows in LDS
+
+
+def rslm_solve(prob, num_proposals, num_points, num_iter, seed=0, offset=0, inds=None, rot=None, fast_mode=False,
+               min_lm_diagonal=1e-6, max_lm_diagonal=1e32, min_relative_decrease=1e-3,
+               initial_trust_region_radius=30.0, max_trust_region_radius=1e16, eps=1e-5):
+    """The whole random-sample LM initialiser in one launch -> pose (B,pose_len), cost (B,).
+    `inds` (P,B,n) int64 / `rot` (P,B[,4]) inject the random draws; None draws them on the device."""
+    P, n = int(num_proposals), int(num_points)
+    if inds is not None:
+        inds = inds.contiguous()
+        assert inds.dtype == torch.int64 and inds.shape == (P, prob.B, n), f'inds shape {tuple(inds.shape)}'
+    if rot is not None:
+        rot = _f32c(rot, 'rot')
+        assert rot.numel() == P * prob.B * (prob.pose_len - 3), f'rot shape {tuple(rot.shape)}'
+    pose, cost = prob.new(prob.B, prob.pose_len), prob.new(prob.B)
+    par = _hip.LmParams(int(num_iter), int(bool(fast_mode)), min_lm_diagonal, max_lm_diagonal, min_relative_decrease,
+                        initial_trust_region_radius, max_trust_region_radius, eps)
+    _hip.call('epropnp_rslm_solve', C.byref(prob.c), C.byref(par), P, n, int(seed), int(offset), _hip.ptr(inds),
+              _hip.ptr(rot), _hip.ptr(pose), _hip.ptr(cost), prob.stream)
+    return pose, cost
+
+
 class _GnStep(torch.autograd.Function):
     """step = -(J^T J + eps I)^-1 J^T r at `pose`, differentiable w.r.t. x3d, x2d, w2d, delta (one sweep forward,
     two sweeps backward, nothing materialised; reference: levenberg_marquardt.py:243-253 + autograd)."""

@@ -5,6 +5,7 @@ constructor arguments, call signatures and return tuples.  The iteration itself 
 (csrc/lm_kernel.hip via epropnp_lm_solve); there is no CPU implementation.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -171,6 +172,21 @@ class RSLMSolver(LMSolver):
             if bs == 0:
                 return x2d.new_empty((0, pose_len)), None, x2d.new_empty((0,))
             P, n = self.num_proposals, self.num_points
+            from . import _hip
+            if n <= 16 and 2 <= pn <= hip.RSLM_MAX_POINTS and _hip.on_hip_path(x3d, x2d, w2d) \
+                    and not os.environ.get('EPROPNP_RSLM_COMPOSITE'):
+                # one kernel: init translation, sub-sampling, P x B solves, scoring, argmin (csrc/rslm_kernel.hip)
+                prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+                if getattr(self.draw, '__func__', None) is RSLMSolver.draw:   # default sampler: device Philox
+                    inds, rot = None, None
+                else:                                       # overridden (reproducibility hooks): inject its draws
+                    inds, rot = self.draw(w2d)
+                if not hasattr(self, '_draw_seed'):
+                    self._draw_seed, self._draw_calls = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
+                self._draw_calls += 1
+                pose, min_cost = hip.rslm_solve(prob, P, n, self.num_iter, self._draw_seed, self._draw_calls - 1, inds,
+                                                rot, fast_mode=bool(kwargs.get('fast_mode', False)), **self._lm_kwargs())
+                return pose, None, min_cost
             inds, rot = self.draw(w2d)
             obj = torch.arange(bs, device=inds.device)[None, :, None]
             x3d_s, x2d_s, w2d_s = x3d[obj, inds], x2d[obj, inds], w2d[obj, inds]      # (P,B,n,.)

@@ -148,6 +148,16 @@ int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float
 int epropnp_rslm_draw(const float* w2d, int32_t num_obj, int32_t num_pts, int32_t num_proposals, int32_t n_pts,
                       uint64_t seed, uint64_t offset, int64_t* inds, void* stream);
 
+/* RSLMSolver.solve (epropnp/levenberg_marquardt.py:283-353) in one launch: center_based_init, weighted sub-sampling
+ * of `num_points` (<= 16) correspondences per proposal, random initial rotations, `num_proposals` LM/GN solves per
+ * object on the sub-samples (parameters `lm`, as LMSolver.solve), full-set cost of every proposal, argmin.
+ *   inds: NULL (drawn on the device, same stream as epropnp_rslm_draw) or (P,B,num_points) int64 injected indices
+ *   rot:  NULL (drawn on the device) or (P,B,1) yaw / (P,B,4) unit quaternions, injected
+ *   -> pose (B,pose_len) best proposal, cost (B,) its full-set Huber cost (may be NULL).   num_pts in [2, 512]. */
+int epropnp_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int32_t num_proposals,
+                       int32_t num_points, uint64_t seed, uint64_t offset, const int64_t* inds, const float* rot,
+                       float* pose, float* cost, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

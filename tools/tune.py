@@ -50,11 +50,11 @@ def worker(B, N, S, K, L, reps=8):
 
 VARIANTS = [
     ('default', {}),
-    ('bwd valu (old)', {'EPROPNP_BWD_IMPL': 'valu'}),
-    ('bwd mfma 8w x4', {'EPROPNP_BWD_MFMA': '8,4'}),
-    ('bwd mfma 4w x4 (2 chunks)', {'EPROPNP_BWD_MFMA': '4,4'}),
-    ('bwd mfma 2w x8 (2 chunks)', {'EPROPNP_BWD_MFMA': '2,8'}),
-    ('fwd valu', {'EPROPNP_FWD_IMPL': 'valu'}),
+    ('bwd mfma 4w x2 (4 chunks)', {'EPROPNP_BWD_MFMA': '4,2'}),
+    ('bwd mfma 4w x1 (8 chunks)', {'EPROPNP_BWD_MFMA': '4,1'}),
+    ('bwd mfma 8w x2 (2 chunks)', {'EPROPNP_BWD_MFMA': '8,2'}),
+    ('bwd mfma 2w x4 (4 chunks)', {'EPROPNP_BWD_MFMA': '2,4'}),
+    ('bwd mfma 1w x4 (8 chunks)', {'EPROPNP_BWD_MFMA': '1,4'}),
 ]
 
 
