@@ -83,4 +83,14 @@ int epropnp_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm,
                                 (hipStream_t)stream);
 }
 
+int epropnp_center_points(const float* x3d, int32_t num_obj, int32_t num_pts, float* offset, float* x3d_centered,
+                          void* stream) {
+  return pnp::launch_center_points(x3d, num_obj, num_pts, offset, x3d_centered, (hipStream_t)stream);
+}
+
+int epropnp_shift_poses(const float* pose, const float* offset, int32_t num_poses, int32_t num_obj, int32_t dof,
+                        float sign, float* out, void* stream) {
+  return pnp::launch_shift_poses(pose, offset, num_poses, num_obj, dof, sign, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -231,6 +231,71 @@ __global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__
   }
 }
 
+// pnp_normalize / pnp_denormalize (epropnp/common.py:103-136) as two launches instead of ~10 ATen launches each.
+// center: offset[b] = mean_n x3d[b,n,:];  out[b,n,:] = x3d[b,n,:] - offset[b]
+__global__ __launch_bounds__(256) void center_points_kernel(const float* __restrict__ x3d, int B, int N,
+                                                             float* __restrict__ offset, float* __restrict__ out) {
+  __shared__ float scratch[3 * 4];
+  const int b = object_of_block(B);
+  if (b >= B) return;
+  const float* src = x3d + (size_t)b * N * 3;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int n = (int)threadIdx.x; n < N; n += (int)blockDim.x) {
+    s[0] += src[3 * n]; s[1] += src[3 * n + 1]; s[2] += src[3 * n + 2];
+  }
+  block_sum<3>(s, scratch);
+  const float m0 = s[0] / (float)N, m1 = s[1] / (float)N, m2 = s[2] / (float)N;
+  float* dst = out + (size_t)b * N * 3;
+  for (int n = (int)threadIdx.x; n < N; n += (int)blockDim.x) {
+    dst[3 * n] = src[3 * n] - m0; dst[3 * n + 1] = src[3 * n + 1] - m1; dst[3 * n + 2] = src[3 * n + 2] - m2;
+  }
+  if (threadIdx.x == 0) {
+    offset[(size_t)b * 3] = m0; offset[(size_t)b * 3 + 1] = m1; offset[(size_t)b * 3 + 2] = m2;
+  }
+}
+
+// shift: out[j,b] = pose[j,b] with translation += sign * R(pose[j,b]) offset[b]
+template <int DOF>
+__global__ __launch_bounds__(256) void shift_poses_kernel(const float* __restrict__ pose, const float* __restrict__ offset,
+                                                           int P, int B, float sign, float* __restrict__ out) {
+  constexpr int PL = PoseLen<DOF>::value;
+  const size_t total = (size_t)P * B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % (size_t)B);
+    float ps[PL], R[9];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) ps[k] = pose[i * PL + k];
+    pose_to_rot<DOF>(ps, R);
+    const float ox = offset[(size_t)b * 3], oy = offset[(size_t)b * 3 + 1], oz = offset[(size_t)b * 3 + 2];
+    ps[0] += sign * (R[0] * ox + R[1] * oy + R[2] * oz);
+    ps[1] += sign * (R[3] * ox + R[4] * oy + R[5] * oz);
+    ps[2] += sign * (R[6] * ox + R[7] * oy + R[8] * oz);
+#pragma unroll
+    for (int k = 0; k < PL; ++k) out[i * PL + k] = ps[k];
+  }
+}
+
+int launch_center_points(const float* x3d, int B, int N, float* offset, float* out, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!x3d || !offset || !out || N < 1) return fail(EPROPNP_EINVAL, "center_points: bad argument");
+  int threads = 64;
+  while (threads < 256 && threads * 2 < N) threads *= 2;
+  PNP_LAUNCH(center_points_kernel, dim3(padded_object_grid(B)), dim3(threads), 0, st, x3d, B, N, offset, out);
+  return check_launch("center_points_kernel");
+}
+
+int launch_shift_poses(const float* pose, const float* offset, int P, int B, int dof, float sign, float* out,
+                       hipStream_t st) {
+  if (B <= 0 || P <= 0) return EPROPNP_OK;
+  if (!pose || !offset || !out || (dof != 4 && dof != 6)) return fail(EPROPNP_EINVAL, "shift_poses: bad argument");
+  const size_t total = (size_t)P * B;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dof == 6) PNP_LAUNCH(shift_poses_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, pose, offset, P, B, sign, out);
+  else PNP_LAUNCH(shift_poses_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, pose, offset, P, B, sign, out);
+  return check_launch("shift_poses_kernel");
+}
+
 int launch_rslm_draw(const float* w2d, int B, int N, int P, int n_pts, unsigned long long seed, unsigned long long offset,
                      long long* inds, hipStream_t st) {
   if (B <= 0 || P <= 0 || n_pts <= 0) return EPROPNP_OK;

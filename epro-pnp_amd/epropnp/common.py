@@ -61,12 +61,33 @@ def rotate_offset(pose, offset):
 
 def pnp_normalize(x3d, pose=None, detach_transformation=True):
     """Centre x3d on its mean; shift the pose translation accordingly.  -> offset (*,3), x3d_norm, pose_norm|None."""
-    offset = (x3d.detach() if detach_transformation else x3d).mean(dim=-2)
-    x3d_norm = x3d - offset.unsqueeze(-2)
+    if detach_transformation and x3d.dim() == 3 and x3d.size(0) > 0 and _fused(x3d):
+        from . import functional as hip      # two launches (csrc/eval_kernels.hip) instead of ~12
+        offset, x3d_norm = hip.center_points(x3d)
+    else:
+        offset = (x3d.detach() if detach_transformation else x3d).mean(dim=-2)
+        x3d_norm = x3d - offset.unsqueeze(-2)
     if pose is None:
         return offset, x3d_norm, None
+    if _can_shift(pose, offset):
+        from . import functional as hip
+        return offset, x3d_norm, hip.shift_poses(pose, offset, +1.0)
     return offset, x3d_norm, torch.cat((pose[..., :3] + rotate_offset(pose, offset), pose[..., 3:]), dim=-1)
 
 
+def _fused(*tensors):
+    from . import _hip
+    return _hip.on_hip_path(*tensors)
+
+
+def _can_shift(pose, offset):
+    """The fused pose shift has no autograd: use it for plain tensors of shape (...,B,pose_len) with offset (B,3)."""
+    return (not pose.requires_grad and not offset.requires_grad and offset.dim() == 2 and pose.dim() >= 2
+            and pose.size(-2) == offset.size(0) and pose.numel() > 0 and _fused(pose, offset))
+
+
 def pnp_denormalize(offset, pose_norm):
+    if _can_shift(pose_norm, offset):
+        from . import functional as hip
+        return hip.shift_poses(pose_norm, offset, -1.0)
     return torch.cat((pose_norm[..., :3] - rotate_offset(pose_norm, offset), pose_norm[..., 3:]), dim=-1)

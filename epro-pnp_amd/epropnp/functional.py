@@ -249,6 +249,37 @@ def rslm_draw(w2d, num_proposals, num_points, seed, offset):
     return inds
 
 
+class _CenterPoints(torch.autograd.Function):
+    """x3d -> (offset, x3d - offset) with the offset treated as a constant (detach_transformation=True)."""
+
+    @staticmethod
+    def forward(ctx, x3d):
+        x = _f32c(x3d, 'x3d')
+        B, N, _ = x.shape
+        offset, out = torch.empty((B, 3), dtype=x.dtype, device=x.device), torch.empty_like(x)
+        _hip.call('epropnp_center_points', _hip.ptr(x), B, N, _hip.ptr(offset), _hip.ptr(out), _hip.stream_of(x))
+        ctx.mark_non_differentiable(offset)
+        return offset, out
+
+    @staticmethod
+    def backward(ctx, _g_offset, g_out):
+        return g_out
+
+
+def center_points(x3d):
+    return _CenterPoints.apply(x3d)
+
+
+def shift_poses(pose, offset, sign):
+    """pose (...,B,pose_len) translation += sign * R(pose) offset (B,3); no autograd."""
+    ps, off = _f32c(pose.detach(), 'pose'), _f32c(offset.detach(), 'offset')
+    B, pl = ps.shape[-2], ps.shape[-1]
+    out = torch.empty_like(ps)
+    _hip.call('epropnp_shift_poses', _hip.ptr(ps), _hip.ptr(off), ps.numel() // (B * pl), B, 6 if pl == 7 else 4,
+              float(sign), _hip.ptr(out), _hip.stream_of(ps))
+    return out
+
+
 RSLM_MAX_POINTS = 512      # epropnp_rslm_solve keeps an object's correspondences + 16 key rows in LDS
 
 

@@ -148,6 +148,16 @@ int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float
 int epropnp_rslm_draw(const float* w2d, int32_t num_obj, int32_t num_pts, int32_t num_proposals, int32_t n_pts,
                       uint64_t seed, uint64_t offset, int64_t* inds, void* stream);
 
+/* pnp_normalize (epropnp/common.py:103-124): offset[b] = mean_n x3d[b,n,:], x3d_centered = x3d - offset.
+ * x3d (B,N,3) -> offset (B,3), x3d_centered (B,N,3). */
+int epropnp_center_points(const float* x3d, int32_t num_obj, int32_t num_pts, float* offset, float* x3d_centered,
+                          void* stream);
+/* The pose half of pnp_normalize / pnp_denormalize (epropnp/common.py:118-136):
+ * out[j,b] = pose[j,b] with translation += sign * R(pose[j,b]) offset[b]   (sign +1 normalise, -1 denormalise).
+ * pose (P,B,pose_len), offset (B,3) -> out (P,B,pose_len); out may alias pose. */
+int epropnp_shift_poses(const float* pose, const float* offset, int32_t num_poses, int32_t num_obj, int32_t dof,
+                        float sign, float* out, void* stream);
+
 /* RSLMSolver.solve (epropnp/levenberg_marquardt.py:283-353) in one launch: center_based_init, weighted sub-sampling
  * of `num_points` (<= 16) correspondences per proposal, random initial rotations, `num_proposals` LM/GN solves per
  * object on the sub-samples (parameters `lm`, as LMSolver.solve), full-set cost of every proposal, argmin.

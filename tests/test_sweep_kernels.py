@@ -28,3 +28,28 @@ def test_evaluate_cost_matches_reference(backend, name):
     torch.testing.assert_close(costs.cpu(), g['costs'], rtol=2e-5, atol=1e-5)
     one = F.evaluate_cost(prob, g['pose'].to(backend))
     torch.testing.assert_close(one.cpu(), g['cost'], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('dof', [4, 6])
+def test_normalize_kernels_match_composite(backend, dof):
+    """epropnp_center_points / epropnp_shift_poses vs the PyTorch definition of pnp_normalize / pnp_denormalize
+    (reference: epropnp/common.py:103-136)."""
+    import epropnp_oracle as orc
+    from epropnp import functional as F
+    from epropnp.common import pnp_denormalize, pnp_normalize, rotate_offset
+    B, N, S = 5, 77, 9
+    p = orc.make_problem(B, N, dof=dof, seed=3)
+    x3d = (p['x3d'] + torch.tensor([0.3, -1.2, 2.0])).to(backend).requires_grad_(True)
+    pose = p['pose_init'].to(backend)
+    offset, x3d_n, pose_n = pnp_normalize(x3d, pose)
+    ref_off = x3d.detach().mean(dim=-2)
+    torch.testing.assert_close(offset, ref_off, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(x3d_n.detach(), x3d.detach() - ref_off.unsqueeze(-2), rtol=1e-6, atol=1e-6)
+    ref_pose = torch.cat((pose[..., :3] + rotate_offset(pose, ref_off), pose[..., 3:]), dim=-1)
+    torch.testing.assert_close(pose_n, ref_pose, rtol=1e-6, atol=1e-6)
+    x3d_n.square().sum().backward()                      # gradient passes through the centring unchanged
+    torch.testing.assert_close(x3d.grad, 2 * x3d_n.detach(), rtol=1e-6, atol=1e-6)
+    samples = pose_n.unsqueeze(0).repeat(S, 1, 1) + 0.0
+    back = pnp_denormalize(offset, samples)
+    torch.testing.assert_close(back, pose.unsqueeze(0).expand(S, -1, -1), rtol=1e-5, atol=1e-5)
+    assert F.shift_poses(samples, offset, -1.0).shape == samples.shape
