@@ -214,9 +214,45 @@ struct AmisCtx {
   float* cpart;   // [WP][s]      partial costs of the current iteration (one row per point slice)
   float* prop;    // [K][kPropStride] fitted proposals
   float* red;     // [256]        block-reduction scratch
+  float* nzb;     // [s][8] base noise of the NEXT draw, generated ahead by the idle waves (nullptr: drawn inline)
   int S, K, s, T, tid, b;
   int cstride;    // row stride of cpart (s, or s rounded up to 16 for the MFMA kernel)
 };
+
+// Base draws of sample m of object b: 3 normals + Chi2(3) for the Student-t translation, 4 normals for the ACG
+// rotation (6-DoF).  Philox4x32-10 counter (b, m, offset, q), Box-Muller.  They do not depend on the fitted proposal,
+// which is what lets the otherwise idle waves produce them while one lane runs the fp64 proposal fit.
+template <int DOF>
+PNP_FN void base_noise(const AmisParams& a, int b, int m, float (&out)[8]) {
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  const uint32_t c2 = (uint32_t)a.offset, c3base = (uint32_t)(a.offset >> 32) * 64u;
+  float nrm[12];
+#pragma unroll
+  for (int q = 0; q < (DOF == 6 ? 3 : 2); ++q) {
+    const Philox4 r = philox4x32_10((uint32_t)b, (uint32_t)m, c2, c3base + q, k0, k1);
+    box_muller(r.v[0], r.v[1], nrm[q * 4], nrm[q * 4 + 1]);
+    box_muller(r.v[2], r.v[3], nrm[q * 4 + 2], nrm[q * 4 + 3]);
+  }
+  out[0] = nrm[0]; out[1] = nrm[1]; out[2] = nrm[2];
+  out[3] = nrm[3] * nrm[3] + nrm[4] * nrm[4] + nrm[5] * nrm[5];   // Chi2(3)
+  if (DOF == 6) {
+    out[4] = nrm[6]; out[5] = nrm[7]; out[6] = nrm[8]; out[7] = nrm[9];
+  } else {
+    out[4] = out[5] = out[6] = out[7] = 0.f;
+  }
+}
+
+// threads [first, T) of the workgroup fill cx.nzb with the base noise of iteration `it`
+template <int DOF>
+PNP_FN void amis_base_noise(const AmisCtx& cx, const AmisParams& a, int it, int first) {
+  if (cx.nzb == nullptr || cx.tid < first) return;
+  for (int n = cx.tid - first; n < cx.s; n += cx.T - first) {
+    float nz8[8];
+    base_noise<DOF>(a, cx.b, it * cx.s + n, nz8);
+    reinterpret_cast<float4*>(cx.nzb)[2 * n] = make_float4(nz8[0], nz8[1], nz8[2], nz8[3]);
+    reinterpret_cast<float4*>(cx.nzb)[2 * n + 1] = make_float4(nz8[4], nz8[5], nz8[6], nz8[7]);
+  }
+}
 
 // ---------------- 1. draw s samples from proposal `it` (lane = sample) ----------------
 template <int DOF>
@@ -236,21 +272,15 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
       if (DOF == 6) {
         g[0] = nz[4]; g[1] = nz[5]; g[2] = nz[6]; g[3] = nz[7];
       }
+    } else if (cx.nzb != nullptr) {      // generated ahead of time by amis_base_noise
+      const float4 n0 = reinterpret_cast<const float4*>(cx.nzb)[2 * n], n1 = reinterpret_cast<const float4*>(cx.nzb)[2 * n + 1];
+      z[0] = n0.x; z[1] = n0.y; z[2] = n0.z; chi2 = n0.w;
+      g[0] = n1.x; g[1] = n1.y; g[2] = n1.z; g[3] = n1.w;
     } else {
-      const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-      const uint32_t c2 = (uint32_t)a.offset, c3base = (uint32_t)(a.offset >> 32) * 64u;
-      float nrm[12];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const Philox4 r = philox4x32_10((uint32_t)b, (uint32_t)m, c2, c3base + q, k0, k1);
-        box_muller(r.v[0], r.v[1], nrm[q * 4], nrm[q * 4 + 1]);
-        box_muller(r.v[2], r.v[3], nrm[q * 4 + 2], nrm[q * 4 + 3]);
-      }
-      z[0] = nrm[0]; z[1] = nrm[1]; z[2] = nrm[2];
-      chi2 = nrm[3] * nrm[3] + nrm[4] * nrm[4] + nrm[5] * nrm[5];   // Chi2(3)
-      if (DOF == 6) {
-        g[0] = nrm[6]; g[1] = nrm[7]; g[2] = nrm[8]; g[3] = nrm[9];
-      }
+      float nz8[8];
+      base_noise<DOF>(a, b, m, nz8);
+      z[0] = nz8[0]; z[1] = nz8[1]; z[2] = nz8[2]; chi2 = nz8[3];
+      g[0] = nz8[4]; g[1] = nz8[5]; g[2] = nz8[6]; g[3] = nz8[7];
     }
     float ps[PL];
     // translation: mode + L_t (z * rsqrt(chi2 / 3))
@@ -362,6 +392,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
   const int M = (it + 1) * s;
   float* nrec = prop + (it + 1) * kPropStride;
   if (wave_id() != 0) {
+    amis_base_noise<DOF>(cx, a, it + 1, 64);     // the next draw's Philox / Box-Muller work hides under the fit
     __syncthreads();
     return;
   }

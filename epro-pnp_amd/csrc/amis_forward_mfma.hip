@@ -29,6 +29,71 @@ __device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
 #endif
 }
 
+#ifdef PNP_TUNING
+// tuning builds: shader-clock cycles per phase (initial fit+load | draw | sweep | weights | refit | store), summed over
+// workgroups by thread 0 of each; read back through epropnp_tuning_phase_cycles (c_api.hip).
+__device__ unsigned long long g_fwd_phase[8];
+#define PNP_PHASE(i)                                                        \
+  do {                                                                      \
+    if (tid == 0) {                                                         \
+      const long long now_ = clock64();                                     \
+      atomicAdd(&g_fwd_phase[i], (unsigned long long)(now_ - phase_t0_));   \
+      phase_t0_ = now_;                                                     \
+    }                                                                       \
+  } while (0)
+#else
+#define PNP_PHASE(i)
+#endif
+
+// Two point-poses at a time, written on 2-vectors so that the multiplies / FMAs become v_pk_mul_f32 / v_pk_fma_f32.
+// Packed ops run at the scalar flop rate on gfx950, but the transcendental ops between them (rcp, sqrt) then cost
+// ~3 ns instead of ~5.6 ns per wave (tools/ubench: "2 trans : 6 pk_fma" vs "2 trans : 6 fma") -- a fifth of this loop.
+#ifndef EPROPNP_EMU
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+typedef float f32x2 __attribute__((vector_size(8)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
+  return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+}
+#endif
+
+__device__ __forceinline__ float clamp_below(float x, float lo) {
+#ifndef EPROPNP_EMU
+  float r;      // the builtin max is expanded to a canonicalising v_max(x, x) + v_max: emit the single instruction
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo));
+  return r;
+#else
+  return (x > lo) ? x : lo;
+#endif
+}
+
+// Huber costs of the 4 poses a lane holds for one point (MFMA outputs hx, hy, hz) added to acc2 = {poses 0,1}, {2,3}
+template <bool BOUNDS>
+__device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& hy, const floatx4& hz, const float4& w4,
+                                             float zmin_v, float delta_v, const Bounds& bd, f32x2 (&acc2)[2]) {
+  const f32x2 wu2 = {w4.x, w4.x}, wv2 = {w4.y, w4.y}, cu2 = {w4.z, w4.z}, cv2 = {w4.w, w4.w};
+  const f32x2 mhalf = {-0.5f, -0.5f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    // z = max(h_z, z_min) as ONE v_max_f32: fmaxf on an MFMA result is expanded to a canonicalising v_max(x, x)
+    // plus the max (IEEE mode), and compare+select measured 3.4 ns per pair against 1.8 ns (tools/ubench)
+    const float z0 = clamp_below(hz[2 * h], zmin_v), z1 = clamp_below(hz[2 * h + 1], zmin_v);
+    const f32x2 rz2 = {fast_rcp(z0), fast_rcp(z1)};
+    const f32x2 hx2 = {hx[2 * h], hx[2 * h + 1]}, hy2 = {hy[2 * h], hy[2 * h + 1]};
+    f32x2 px2 = hx2 * rz2, py2 = hy2 * rz2;
+    if (BOUNDS) {
+      px2 = f32x2{fminf(fmaxf(px2[0], bd.lbx), bd.ubx), fminf(fmaxf(px2[1], bd.lbx), bd.ubx)};
+      py2 = f32x2{fminf(fmaxf(py2[0], bd.lby), bd.uby), fminf(fmaxf(py2[1], bd.lby), bd.uby)};
+    }
+    const f32x2 rx2 = fma2(px2, wu2, cu2), ry2 = fma2(py2, wv2, cv2);
+    const f32x2 s2 = fma2(rx2, rx2, ry2 * ry2);
+    const f32x2 rho2 = {fast_sqrt(s2[0]), fast_sqrt(s2[1])};
+    const f32x2 m2 = {fminf(rho2[0], delta_v), fminf(rho2[1], delta_v)};
+    acc2[h] = fma2(m2, fma2(mhalf, m2, rho2), acc2[h]);       // huber = m (rho - m / 2), m = min(rho, delta)
+  }
+}
+
 constexpr int kChunk = 1024;   // points per LDS chunk (32 KiB of point tables)
 
 struct MfmaShape {
@@ -39,8 +104,11 @@ struct MfmaShape {
 // NPT > 0: the workgroup's waves split the POINTS, each wave keeps its NPT point tiles (B operand + residual
 // constants, 5 VGPRs per tile) in registers for the whole kernel and sweeps every pose tile; per-wave partial costs
 // meet in LDS.  NPT == 0: waves split the pose tiles and points stream through LDS in chunks (any N).
+#ifndef PNP_FWD_MINW
+#define PNP_FWD_MINW 4
+#endif
 template <int DOF, bool BOUNDS, int NPT>
-__global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_kernel(Problem p, AmisParams a, MfmaShape sh,
+__global__ __launch_bounds__(512, ((NPT <= 8 && DOF == 6) ? PNP_FWD_MINW : 2)) void amis_forward_mfma_kernel(Problem p, AmisParams a, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
                                                                   const float* __restrict__ noise,
@@ -53,6 +121,9 @@ __global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_ker
   const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), W = T >> 6;
   const int S = a.S, K = a.K, s = S / K, s16 = sh.s16, NC = sh.chunk;
 
+#ifdef PNP_TUNING
+  long long phase_t0_ = clock64();
+#endif
   PNP_DYN_SMEM(float, smem);
   constexpr bool kRegs = NPT > 0;
   const int WPs = kRegs ? W : 1;      // point slices whose partial costs are summed in amis_weights
@@ -66,11 +137,17 @@ __global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_ker
   float* cpart = lgw + S;             // [WPs][s16]
   float* prop = cpart + WPs * s16;    // [K][kPropStride]
   float* red = prop + K * kPropStride;   // [256]
+  float* nzb = red + 256;                // [s][8]  (only when the draws come from Philox and W > 1)
 
   float Kc[9], delta;
   Bounds bd;
   load_camera<BOUNDS>(p, b, Kc, bd, delta);
   const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
+
+  AmisCtx cx;
+  cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
+  cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s16;
+  cx.nzb = (noise == nullptr && W > 1) ? nzb : nullptr;
 
   for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last tile
   if (tid == 0) initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop);
@@ -97,16 +174,15 @@ __global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_ker
   } else if (nchunk == 1) {
     load_chunk(0);
   }
+  amis_base_noise<DOF>(cx, a, 0, 64);     // waves 1.. draw the first iteration's base noise while lane 0 fits proposal 0
   __syncthreads();
 
-  AmisCtx cx;
-  cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
-  cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s16;
-
   const int g4 = (lane >> 4) * 4, col = lane & 15, kk = lane >> 4;
+  PNP_PHASE(0);
   for (int it = 0; it < K; ++it) {
     amis_draw<DOF>(cx, p, a, it, Kc, noise, pose_samples);
     __syncthreads();
+    PNP_PHASE(1);
 
     // ---------------- cost sweep: 16 x 16 (pose, point) tiles on the matrix pipe ----------------
 #ifdef PNP_TUNING
@@ -119,29 +195,15 @@ __global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_ker
       for (int t = 0; t < (s16 >> 4); ++t) {
         const float* arow = ptab + 12 * (t * 16 + col) + kk;
         const float ax = arow[0], ay = arow[4], az = arow[8];
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
         for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
           const floatx4 hx = mfma_16x16x4(ax, rB[i], zero);
           const floatx4 hy = mfma_16x16x4(ay, rB[i], zero);
           const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
-          const float4 w4 = rW[i];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float zc = (hz[r] > zmin_v) ? hz[r] : zmin_v;
-            const float rz = fast_rcp(zc);
-            float px = hx[r] * rz, py = hy[r] * rz;
-            if (BOUNDS) {
-              px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-              py = fminf(fmaxf(py, bd.lby), bd.uby);
-            }
-            const float rx = fmaf(px, w4.x, w4.z);
-            const float ry = fmaf(py, w4.y, w4.w);
-            const float rho = fast_sqrt(fmaf(rx, rx, ry * ry));
-            const float m = fminf(rho, delta_v);
-            acc[r] = fmaf(m, fmaf(-0.5f, m, rho), acc[r]);
-          }
+          huber_cost_4<BOUNDS>(hx, hy, hz, rW[i], zmin_v, delta_v, bd, acc2);
         }
+        float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
         if (col == 0) {
@@ -161,10 +223,10 @@ __global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_ker
       for (int t = wv; t < (s16 >> 4); t += W) {
         const float* arow = ptab + 12 * (t * 16 + col) + kk;
         const float ax = arow[0], ay = arow[4], az = arow[8];
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
         const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
         // software pipeline: tile q+1's operands are fetched and its three MFMAs issued before tile q's VALU work,
-        // so the matrix pipe (32 cycles per MFMA) runs underneath the ~55 VALU instructions of the previous tile
+        // so the matrix pipe (32 cycles per MFMA) runs underneath the VALU instructions of the previous tile
         float bq = pB[4 * col + kk];
         float4 w4 = reinterpret_cast<const float4*>(pW)[col];
         floatx4 hx = mfma_16x16x4(ax, bq, zero), hy = mfma_16x16x4(ay, bq, zero), hz = mfma_16x16x4(az, bq, zero);
@@ -175,25 +237,10 @@ __global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_ker
           const floatx4 hxn = mfma_16x16x4(ax, bn, zero);
           const floatx4 hyn = mfma_16x16x4(ay, bn, zero);
           const floatx4 hzn = mfma_16x16x4(az, bn, zero);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            // compare+select instead of fmaxf: v_max_f32 issues at half rate and needs a canonicalising
-            // v_max(x, x) on an MFMA result first (IEEE mode); a NaN depth maps to z_min either way
-            const float zc = (hz[r] > zmin_v) ? hz[r] : zmin_v;
-            const float rz = fast_rcp(zc);
-            float px = hx[r] * rz, py = hy[r] * rz;
-            if (BOUNDS) {
-              px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-              py = fminf(fmaxf(py, bd.lby), bd.uby);
-            }
-            const float rx = fmaf(px, w4.x, w4.z);
-            const float ry = fmaf(py, w4.y, w4.w);
-            const float rho = fast_sqrt(fmaf(rx, rx, ry * ry));
-            const float m = fminf(rho, delta_v);
-            acc[r] = fmaf(m, fmaf(-0.5f, m, rho), acc[r]);
-          }
+          huber_cost_4<BOUNDS>(hx, hy, hz, w4, zmin_v, delta_v, bd, acc2);
           hx = hxn; hy = hyn; hz = hzn; w4 = wn;
         }
+        float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
         if (col == 0) {
@@ -206,17 +253,32 @@ __global__ __launch_bounds__(512, (NPT <= 8 ? 4 : 2)) void amis_forward_mfma_ker
       }
     }
     __syncthreads();
+    PNP_PHASE(2);
 
     amis_weights<DOF>(cx, a, it, WPs);
     __syncthreads();
+    PNP_PHASE(3);
     if (it == K - 1) break;
     amis_refit<DOF>(cx, a, it);
+    PNP_PHASE(4);
   }
 
   for (int m = tid; m < S; m += T) logweights[(size_t)m * p.B + b] = lgw[m];
   if (proposals != nullptr)
     for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
+  PNP_PHASE(5);
 }
+
+#ifdef PNP_TUNING
+int tuning_phase_cycles(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 template <class F>
 static int dispatch_npt(int npt, F&& f) {
@@ -264,7 +326,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   k.seed = am->seed; k.offset = am->offset; k.ablate = 0;
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
   const size_t smem = sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (size_t)PL * S + 3 * (size_t)S +
-                                       (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256);
+                                       (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256 + 8 * (size_t)s);
   if (smem > 160 * 1024) return fail(EPROPNP_EINVAL, "amis_forward: mc_samples %d needs %zu B of LDS (> 160 KiB)", S, smem);
   const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) vo
   AmisCtx cx;
   cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
   cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s;
+  cx.nzb = nullptr;
 
   for (int it = 0; it < K; ++it) {
     amis_draw<DOF>(cx, p, a, it, Kc, noise, pose_samples);

@@ -2,6 +2,9 @@
 #include "pnp_host.h"
 
 namespace pnp {
+#ifdef PNP_TUNING
+int tuning_phase_cycles(unsigned long long* out, int reset);
+#endif
 char* last_error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
@@ -92,5 +95,10 @@ int epropnp_shift_poses(const float* pose, const float* offset, int32_t num_pose
                         float sign, float* out, void* stream) {
   return pnp::launch_shift_poses(pose, offset, num_poses, num_obj, dof, sign, out, (hipStream_t)stream);
 }
+
+#ifdef PNP_TUNING
+// tuning builds only (not part of the ABI): per-phase shader-clock totals of amis_forward_mfma_kernel
+int epropnp_tuning_phase_cycles(unsigned long long* out, int reset) { return pnp::tuning_phase_cycles(out, reset); }
+#endif
 
 }  // extern "C"

@@ -40,21 +40,30 @@ def worker(B, N, S, K, L, reps=8):
         return ts[len(ts) // 2], out
     t_lm, (pose_opt, cov, _) = timeit(lambda: F.lm_solve(hp, prob['pose_init'], L, with_pose_cov=True, with_cost=True))
     t_fw, (smp, logw) = timeit(lambda: F.amis_forward(hp, pose_opt, cov, S, K, seed=1))
+    phases = None
+    try:      # tuning builds export per-phase cycle totals of the forward kernel
+        import ctypes
+        from epropnp import _hip
+        fn = _hip.lib().epropnp_tuning_phase_cycles
+        buf = (ctypes.c_ulonglong * 8)()
+        fn(buf, 1)
+        F.amis_forward(hp, pose_opt, cov, S, K, seed=1)
+        torch.cuda.synchronize()
+        fn(buf, 0)
+        tot = float(sum(buf)) or 1.0
+        phases = [round(v / tot, 3) for v in buf][:6]
+    except AttributeError:
+        pass
     g = -torch.softmax(logw, 0) / B
     gi = torch.full((B,), 1.0 / B, device=dev)
     t_bw, grads = timeit(lambda: F.amis_backward(hp, smp, g, prob['pose_init'], gi))
     gsum = sum(float(t.double().abs().sum()) for t in grads)
     lse = torch.logsumexp(logw, 0).mean().item()
-    print(json.dumps(dict(lm_ms=round(t_lm, 4), fwd_ms=round(t_fw, 4), bwd_ms=round(t_bw, 4), lse=round(lse, 4), gsum=round(gsum, 6))))
+    print(json.dumps(dict(lm_ms=round(t_lm, 4), fwd_ms=round(t_fw, 4), bwd_ms=round(t_bw, 4), lse=round(lse, 4), gsum=round(gsum, 6), fwd_phases=phases)))
 
 
 VARIANTS = [
     ('default', {}),
-    ('bwd mfma 4w x2 (4 chunks)', {'EPROPNP_BWD_MFMA': '4,2'}),
-    ('bwd mfma 4w x1 (8 chunks)', {'EPROPNP_BWD_MFMA': '4,1'}),
-    ('bwd mfma 8w x2 (2 chunks)', {'EPROPNP_BWD_MFMA': '8,2'}),
-    ('bwd mfma 2w x4 (4 chunks)', {'EPROPNP_BWD_MFMA': '2,4'}),
-    ('bwd mfma 1w x4 (8 chunks)', {'EPROPNP_BWD_MFMA': '1,4'}),
 ]
 
 

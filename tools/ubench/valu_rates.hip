@@ -63,6 +63,14 @@ __global__ void k(float* out, long long* clk, int iters, float a, float b) {
                    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
     } else if (MODE == 14) SC2("v_min_f32");
     else if (MODE == 15) SC1("v_rsq_f32");
+    else if (MODE == 16) SC("v_med3_f32");
+    else if (MODE == 17) SC("v_max3_f32");
+    else if (MODE == 18) SC2("v_add_f32");
+    else if (MODE == 19) {   // v_cmp_gt + v_cndmask pairs (what `x > t ? x : t` compiles to)
+      asm volatile(X8("v_cmp_gt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %8, %0, vcc\n v_cmp_gt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %8, %1, vcc\n"
+                      "v_cmp_gt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %8, %2, vcc\n v_cmp_gt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %8, %3, vcc\n")
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
+    }
   }
   long long t1 = clock64();
   if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
@@ -90,11 +98,12 @@ void run(const char* name, int waves_per_simd, double flops_per_instr) {
 }
 
 int main() {
-  for (int w : {1, 2, 4, 8}) {
+  for (int w : {2, 8}) {
     run<0>("v_fma_f32", w, 2); run<9>("v_fma_f32 (sgpr src)", w, 2); run<8>("v_fmac_f32", w, 2); run<5>("v_mul_f32", w, 1);
     run<1>("v_pk_fma_f32", w, 4); run<6>("v_pk_mul_f32", w, 2); run<7>("v_pk_add_f32", w, 2);
     run<4>("v_max_f32", w, 1); run<14>("v_min_f32", w, 1); run<13>("v_add_f32_dpp", w, 1);
     run<2>("v_rcp_f32", w, 1); run<3>("v_sqrt_f32", w, 1); run<15>("v_rsq_f32", w, 1);
+    run<16>("v_med3_f32", w, 1); run<17>("v_max3_f32", w, 1); run<18>("v_add_f32", w, 1); run<19>("v_cmp_gt+v_cndmask (x1)", w, 1);
     run<10>("1 rcp : 7 fma", w, 1.875); run<11>("2 trans : 6 fma", w, 1.75); run<12>("2 trans : 6 pk_fma", w, 3.25);
     printf("\n");
   }
