@@ -225,10 +225,10 @@ def main():
                          'algorithmic_bytes_per_launch': lm_bytes, 'logical_sweeps': sweeps,
                          'launch_ms': round(t_lm, 4)},
             'roofline_valu': {
-                'amis_forward_kernel': {'bound': 'valu_fp32', 'achieved': round(fw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
+                'amis_forward_mfma_kernel': {'bound': 'valu_fp32', 'achieved': round(fw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
                                         'unit': 'TFLOP/s', 'frac': round(fw_tf / FP32_VECTOR_PEAK_TF, 4),
                                         'flops_per_point_pose': 40, 'launch_ms': round(t_fw, 4)},
-                'amis_backward_kernel': {'bound': 'valu_fp32', 'achieved': round(bw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
+                'amis_backward_mfma_kernel': {'bound': 'valu_fp32', 'achieved': round(bw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
                                          'unit': 'TFLOP/s', 'frac': round(bw_tf / FP32_VECTOR_PEAK_TF, 4),
                                          'flops_per_point_pose': 80, 'launch_ms': round(t_bw, 4)}},
             'kernel_ms': {'evaluate_cost': round(t_ci, 4), 'lm_solve': round(t_lm, 4), 'amis_forward': round(t_fw, 4),

@@ -141,26 +141,39 @@ __global__ __launch_bounds__(256) void adaptive_delta_kernel(const float* __rest
   }
 }
 
-// (S,B) log-weights: a 512-thread block owns 32 adjacent objects (columns) and splits the S rows over 16 row groups;
-// each thread keeps an online (max, sum) pair, the 16 partials of a column are merged through LDS.
+// (S,B) log-weights: a 512-thread block owns 16 adjacent objects (columns: 64-byte row segments) and splits the S rows
+// over 32 row groups; each thread keeps an online (max, sum) pair over batches of 8 independent loads, the 32 partials
+// of a column are merged through LDS.
+constexpr int kLossCols = 16, kLossRows = 32;
 __global__ __launch_bounds__(512) void mc_loss_forward_kernel(const float* __restrict__ logw, const float* __restrict__ ct,
                                                                int S, int B, float* __restrict__ loss,
                                                                float* __restrict__ lse) {
-  __shared__ float smax[16][33], ssum[16][33];
-  const int c = (int)(threadIdx.x & 31u), rg = (int)(threadIdx.x >> 5);
-  const int b = (int)blockIdx.x * 32 + c;
+  __shared__ float smax[kLossRows][kLossCols + 1], ssum[kLossRows][kLossCols + 1];
+  const int c = (int)(threadIdx.x % kLossCols), rg = (int)(threadIdx.x / kLossCols);
+  const int b = (int)blockIdx.x * kLossCols + c;
   float m = -INFINITY, acc = 0.f;
   bool nan = false;
   if (b < B) {
-    for (int j = rg; j < S; j += 16) {
-      const float v = logw[(size_t)j * B + b];
-      nan = nan || (v != v);
-      if (v > m) {
-        acc = acc * expf(m - v) + 1.0f;      // exp(-inf - v) = 0 on the first element
-        m = v;
-      } else if (v == v) {
-        acc += (v == -INFINITY) ? 0.f : expf(v - m);
+    for (int j0 = rg; j0 < S; j0 += kLossRows * 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int j = j0 + k * kLossRows;
+        v[k] = (j < S) ? logw[(size_t)j * B + b] : -INFINITY;
       }
+      float cm = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        nan = nan || (v[k] != v[k]);
+        cm = (v[k] > cm) ? v[k] : cm;
+      }
+      if (cm > m) {
+        acc *= expf(m - cm);                  // exp(-inf - x) = 0 on the first batch
+        m = cm;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        acc += (v[k] == -INFINITY || v[k] != v[k]) ? 0.f : ((v[k] == m) ? 1.0f : expf(v[k] - m));
     }
   }
   smax[rg][c] = nan ? NAN : m;
@@ -169,15 +182,15 @@ __global__ __launch_bounds__(512) void mc_loss_forward_kernel(const float* __res
   if (rg == 0 && b < B) {
     float M = -INFINITY;
     bool bad = false;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < kLossRows; ++k) {
       const float mk = smax[k][c];
       bad = bad || (mk != mk);
       M = fmaxf(M, mk);
     }
     float tot = 0.f;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < kLossRows; ++k) {
       const float mk = smax[k][c];
-      if (mk == mk && mk > -INFINITY) tot += ssum[k][c] * expf(mk - M);
+      if (mk == mk && mk > -INFINITY) tot += ssum[k][c] * ((mk == M) ? 1.0f : expf(mk - M));
     }
     float l = (M == -INFINITY || M == INFINITY) ? M : M + logf(tot);
     if (bad) l = NAN;
@@ -319,7 +332,7 @@ int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, floa
 int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, float* loss, float* lse, hipStream_t st) {
   if (B <= 0) return EPROPNP_OK;
   if (!logw || !loss || !lse || S < 1) return fail(EPROPNP_EINVAL, "mc_loss_forward: bad argument");
-  PNP_LAUNCH(mc_loss_forward_kernel, dim3((B + 31) / 32), dim3(512), 0, st, logw, ct, S, B, loss, lse);
+  PNP_LAUNCH(mc_loss_forward_kernel, dim3((B + kLossCols - 1) / kLossCols), dim3(512), 0, st, logw, ct, S, B, loss, lse);
   return check_launch("mc_loss_forward_kernel");
 }
 

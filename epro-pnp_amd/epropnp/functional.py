@@ -148,6 +148,7 @@ class _MonteCarloCost(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x3d, x2d, w2d, delta, prob, pose_opt, pose_cov, pose_init, cost_init_value, cfg):
         samples, logw = amis_forward(prob, pose_opt, pose_cov, **cfg)
+        ctx.set_materialize_grads(False)      # no (S,B,7) zero tensor for the non-differentiable samples output
         ctx.prob, ctx.pose_init = prob, pose_init
         ctx.save_for_backward(samples)
         ctx.mark_non_differentiable(samples)
@@ -160,6 +161,8 @@ class _MonteCarloCost(torch.autograd.Function):
     def backward(ctx, _g_samples, g_logw, g_cost_init=None):
         (samples,) = ctx.saved_tensors
         prob = ctx.prob
+        if g_logw is None and g_cost_init is None:
+            return (None,) * 10
         if g_logw is None:
             g_logw = torch.zeros(samples.shape[:2], dtype=torch.float32, device=samples.device)
         gx3d, gx2d, gw2d, gdel = amis_backward(prob, samples, g_logw, ctx.pose_init, g_cost_init)
@@ -186,12 +189,15 @@ class _AdaptiveDelta(torch.autograd.Function):
         stats = torch.empty(B, 4, dtype=torch.float32, device=x.device)
         _hip.call('epropnp_adaptive_delta', _hip.ptr(x), _hip.ptr(w), B, N, float(relative_delta), _hip.ptr(delta),
                   _hip.ptr(stats), _hip.stream_of(x))
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, stats)
         ctx.rel, ctx.N = float(relative_delta), N
         return delta
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None
         x, stats = ctx.saved_tensors
         N, rel = ctx.N, ctx.rel
         mw, sd = stats[:, 0], stats[:, 1]
@@ -225,6 +231,8 @@ class _McPoseLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         lw, lse, loss = ctx.saved_tensors
         S, B = lw.shape
         g = g.contiguous()
@@ -259,6 +267,7 @@ class _CenterPoints(torch.autograd.Function):
         offset, out = torch.empty((B, 3), dtype=x.dtype, device=x.device), torch.empty_like(x)
         _hip.call('epropnp_center_points', _hip.ptr(x), B, N, _hip.ptr(offset), _hip.ptr(out), _hip.stream_of(x))
         ctx.mark_non_differentiable(offset)
+        ctx.set_materialize_grads(False)
         return offset, out
 
     @staticmethod
@@ -312,6 +321,7 @@ class _GnStep(torch.autograd.Function):
         ps = _f32c(pose, 'pose')
         step = prob.new(prob.B, prob.dof)
         _hip.call('epropnp_gn_step_forward', C.byref(prob.c), float(eps), _hip.ptr(ps), _hip.ptr(step), prob.stream)
+        ctx.set_materialize_grads(False)
         ctx.prob, ctx.eps = prob, float(eps)
         ctx.save_for_backward(ps)
         ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
@@ -319,6 +329,8 @@ class _GnStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 7
         (ps,) = ctx.saved_tensors
         prob = ctx.prob
         B, N = prob.B, prob.N

@@ -241,3 +241,21 @@ def test_rslm_draw_is_weighted_sampling_without_replacement(backend):
         freq = torch.bincount(first[:, b], minlength=N).float() / P
         assert (freq - pw[b]).abs().max() < 6 * (pw[b].max() / P) ** 0.5 + 2.0 / P
     assert not torch.equal(inds, F.rslm_draw(w.to(backend), P, n, seed=5, offset=1).cpu())
+
+
+def test_mc_loss_kernel_edge_values(backend):
+    """Several row batches per thread (S > 256), -inf weights (ignored), a +inf weight (loss +inf) and an all -inf
+    column (loss -inf), against torch.logsumexp."""
+    from epropnp.losses import monte_carlo_pose_loss
+    g = torch.Generator().manual_seed(11)
+    S, B = 700, 37
+    logw = torch.randn(S, B, generator=g).mul(4)
+    logw[5:40, 3] = float('-inf')
+    logw[:, 8] = float('-inf')
+    logw[123, 9] = float('inf')
+    ct = torch.rand(B, generator=g)
+    loss = monte_carlo_pose_loss(logw.to(backend), ct.to(backend)).cpu()
+    ref = ct + torch.logsumexp(logw, 0)
+    fin = torch.isfinite(ref)
+    torch.testing.assert_close(loss[fin], ref[fin], rtol=1e-5, atol=1e-5)
+    assert loss[8].item() == float('-inf') and loss[9].item() == float('inf')
