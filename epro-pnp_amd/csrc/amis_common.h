@@ -14,7 +14,10 @@ constexpr int kPropStride = 40;   // floats per fitted proposal (layout below)
 // proposal record:  [0..2] t-mode | [3..8] L_t (lower, row-major packed) | [9..14] L_t^-1 | [15] Student-t log-norm
 //   6-DoF: [16..25] L_r (lower 4x4 packed) | [26..35] L_r^-1 | [36] sum log diag L_r
 //   4-DoF: [16] yaw mode | [17] kappa | [18] log I0(kappa)
-constexpr int kVmTries = 16;
+#ifndef PNP_VM_TRIES
+#define PNP_VM_TRIES 16      // tuning builds may lower it to time the rejection loop; the noise layout assumes 16
+#endif
+constexpr int kVmTries = PNP_VM_TRIES;
 constexpr int kRedStride = 68;                      // 64 lanes + 4 floats of padding per parked sample
 constexpr int kWaveRed = 16 * kRedStride + 64;     // per-wave LDS scratch of the transposed cost reduction
 
@@ -175,32 +178,66 @@ PNP_FN float proposal_logprob(const float* rec, const float* smp /*PL*/) {
 }
 
 // Best & Fisher (1979) von Mises draw with at most kVmTries attempts; u = 3 uniforms per attempt.
-// Same bounded procedure as oracle/epropnp_oracle.py:vm_sample_bounded.
+// Same bounded procedure (and the same accept / reject decisions) as oracle/epropnp_oracle.py:vm_sample_bounded, which
+// follows numpy's legacy sampler:  z = cos(pi u1), f = (1 + r z) / (r + z), c = kappa (r - f),
+// accept iff c (2 - c) > u2 or log(c / u2) + 1 - c >= 0, result = +-acos(f).
+// Evaluated in a cancellation-free form so that fp32 suffices even for kappa ~ 1e4 (sharp posteriors):
+//   r - f = (r^2 - 1) / (r + z),  r + z = (r - 1) + 2 cos^2(pi u1 / 2),  (1 -+ f) / 2 = (r -+ 1) {sin,cos}^2(pi u1 / 2) / (r + z)
+// with (r - 1), (r^2 - 1) formed once per proposal in fp64.  Decisions whose margin is within 1e-4 (1 + c) of zero are
+// re-evaluated in fp64 (a few per 10^4 attempts), so the outcome is that of the fp64 procedure.
 // `next(a, u1, u2, u3)` supplies the three uniforms of attempt a (from injected noise or Philox): no per-lane array.
+PNP_FN void sincos_half_pi(float u, float& s, float& c) {      // sin, cos of (pi / 2) u,  u in [0, 1]
+#ifndef EPROPNP_EMU
+  s = __builtin_amdgcn_sinf(0.25f * u);      // hardware argument is in revolutions
+  c = __builtin_amdgcn_cosf(0.25f * u);
+#else
+  s = sinf(1.5707963267948966f * u);
+  c = cosf(1.5707963267948966f * u);
+#endif
+}
+
 template <class Uniforms>
 PNP_FN float vm_sample_bounded(float loc, float kappa, Uniforms next) {
   const double k = fmax((double)kappa, 1e-12);
   const double tau = 1.0 + sqrt(1.0 + 4.0 * k * k);
   const double rho = (tau - sqrt(2.0 * tau)) / (2.0 * k);
   const double r = (k < 1e-5) ? (1.0 / k + k) : (1.0 + rho * rho) / (2.0 * rho);
-  double x = 0.0;
+  const double rm1 = (k < 1e-5) ? (r - 1.0) : (1.0 - rho) * (1.0 - rho) / (2.0 * rho);
+  const double kq = k * rm1 * (r + 1.0);                  // kappa (r^2 - 1)
+  const float kqf = (float)kq, rm1f = (float)rm1, srm1 = (float)sqrt(rm1), srp1 = (float)sqrt(r + 1.0);
+  float x = 0.f;
   bool done = false;
   for (int a = 0; a < kVmTries; ++a) {
-    float f1, f2, f3;
-    next(a, f1, f2, f3);
-    const double u1 = f1, u2 = f2, u3 = f3;
-    const double zc = cos(3.141592653589793 * u1);
-    const double f = (1.0 + r * zc) / (r + zc);
-    const double c = k * (r - f);
-    const bool acc = ((c * (2.0 - c) - u2) > 0.0) || ((log(c / fmax(u2, 1e-300)) + 1.0 - c) >= 0.0);
+#ifndef EPROPNP_EMU
+    // every active lane of the wave has accepted: the remaining attempts could not change anything (the acceptance
+    // rate of Best-Fisher is >= 0.66, so a full wave is through after ~4-5 attempts instead of 16)
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+#endif
+    float u1, u2, u3;
+    next(a, u1, u2, u3);
+    float sh, ch;
+    sincos_half_pi(u1, sh, ch);
+    const float den = fmaf(2.0f * ch, ch, rm1f);          // r + z > 0
+    const float c = kqf / den;
+    const float m1 = c * (2.0f - c) - u2;
+    const float m2 = logf(c / fmaxf(u2, 1e-30f)) + 1.0f - c;
+    const float tol = 1e-4f * (1.0f + c);
+    bool acc = (m1 > 0.0f) || (m2 >= 0.0f);
+    const bool clear = (u2 >= 1e-30f) && ((m1 > tol) || (m2 > tol) || ((m1 < -tol) && (m2 < -tol)));
+    if (!clear) {                                          // borderline: decide in fp64
+      const double chd = cos(1.5707963267948966 * (double)u1);
+      const double cd = kq / (rm1 + 2.0 * chd * chd);
+      acc = ((cd * (2.0 - cd) - (double)u2) > 0.0) || ((log(cd / fmax((double)u2, 1e-300)) + 1.0 - cd) >= 0.0);
+    }
     if (!done && (acc || a == kVmTries - 1)) {
-      x = ((u3 - 0.5 >= 0.0) ? 1.0 : -1.0) * acos(fmin(fmax(f, -1.0), 1.0));
+      // acos(f) = 2 atan2(sqrt((1 - f) / 2), sqrt((1 + f) / 2)); the common factor 1 / sqrt(r + z) cancels
+      x = ((u3 - 0.5f >= 0.0f) ? 2.0f : -2.0f) * atan2f(srm1 * sh, srp1 * ch);
     }
     done = done || acc;
   }
-  double y = x + 3.141592653589793 + (double)loc;
-  y = y - 6.283185307179586 * floor(y / 6.283185307179586);
-  return (float)(y - 3.141592653589793);
+  float y = x + loc + 3.14159265358979f;
+  y = y - 6.283185307179586f * floorf(y * 0.15915494309189535f);
+  return y - 3.14159265358979f;
 }
 
 
@@ -381,6 +418,21 @@ PNP_FN void amis_weights(const AmisCtx& cx, const AmisParams& a, int it, int WP)
 
 }
 
+#ifdef PNP_TUNING
+// tuning builds: cycles spent by the fitting lane in [moment pass + reductions | ACG fixed-point iterations | final fits]
+__device__ unsigned long long g_refit_phase[4];
+#define PNP_REFIT_PHASE(i)                                                   \
+  do {                                                                       \
+    if (tid == 0) {                                                          \
+      const long long now_ = clock64();                                      \
+      atomicAdd(&g_refit_phase[i], (unsigned long long)(now_ - refit_t0_));  \
+      refit_t0_ = now_;                                                      \
+    }                                                                        \
+  } while (0)
+#else
+#define PNP_REFIT_PHASE(i)
+#endif
+
 // ---------------- 5. fit proposal it+1 to the weighted samples (epropnp.py:238-260 / :317-342) ---------
 template <int DOF>
 PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
@@ -398,6 +450,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
   }
   const int T = 64, tid = lane_id();
 #ifdef PNP_TUNING
+  long long refit_t0_ = clock64();
   if (a.ablate & 2) {
     for (int i = tid; i < kPropStride; i += T) nrec[i] = rec[i];
     __syncthreads();
@@ -415,6 +468,10 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     float mom[21];
 #pragma unroll
     for (int i = 0; i < 21; ++i) mom[i] = 0.f;
+#ifdef PNP_TUNING
+    if (a.ablate & 8) mom[0] = mom[4] = mom[6] = mom[9] = mom[10] = mom[12] = mom[15] = mom[19] = mom[20] = 1.f;
+    else
+#endif
     for (int m = tid; m < M; m += T) {
       const float e = expf(lgw[m] - mx);
       const float d0 = smp[m] - p0, d1 = smp[S + m] - p1, d2 = smp[2 * S + m] - p2;
@@ -430,6 +487,9 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       mom[16] += iw * q3 * q0; mom[17] += iw * q3 * q1; mom[18] += iw * q3 * q2; mom[19] += iw * q3 * q3;
       mom[20] += iw;
     }
+#ifdef PNP_TUNING
+    if (!(a.ablate & 16))
+#endif
 #pragma unroll
     for (int i = 0; i < 21; ++i) mom[i] = wave_sum(mom[i]);
     const float invZ = 1.0f / mom[0];
@@ -441,6 +501,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     float acc[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) acc[i] = mom[10 + i];
+    PNP_REFIT_PHASE(0);
     float Si[10];
     for (int r = 1; r < a.mle_iter; ++r) {
       // Sigma^-1 of the previous fixed-point iterate (one lane, fp64), broadcast through LDS
@@ -483,6 +544,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
 #pragma unroll
       for (int i = 0; i < 11; ++i) acc[i] = wave_sum(acc[i]);
     }
+    PNP_REFIT_PHASE(1);
     if (tid == 0) {
       nrec[0] = mu0; nrec[1] = mu1; nrec[2] = mu2;
       double Ct[3][3];
@@ -508,6 +570,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
         }
       fit_rotation_acg(Sg, a.dispersion, nrec);
     }
+    PNP_REFIT_PHASE(2);
   } else {
     float mom[12];
 #pragma unroll

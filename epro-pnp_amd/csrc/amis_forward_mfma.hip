@@ -272,6 +272,14 @@ __global__ __launch_bounds__(512, ((NPT <= 8 && DOF == 6) ? PNP_FWD_MINW : 2)) v
 #ifdef PNP_TUNING
 int tuning_phase_cycles(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (out) {    // slots 6, 7 are unused by the kernel phases: cycles of the refit's [ACG fixed-point iterations | final fp64 fits]
+    unsigned long long rf[4];
+    if (hipMemcpyFromSymbol(rf, HIP_SYMBOL(g_refit_phase), sizeof(rf)) != hipSuccess) return -1;
+    out[6] = rf[1];
+    out[7] = rf[2];
+    const unsigned long long z4[4] = {0, 0, 0, 0};
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_refit_phase), z4, sizeof(z4)) != hipSuccess) return -1;
+  }
   if (reset) {
     const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_phase), z, sizeof(z)) != hipSuccess) return -1;

@@ -23,3 +23,14 @@ for it in range(8):
     o = layer4.monte_carlo_forward(x3d, x2d, w2d, cam, cf4, pose_init=p['pose_init'], force_init_solve=True)
     monte_carlo_pose_loss(o[4], o[5]).mean().backward()
 torch.cuda.synchronize()
+try:      # tuning builds (build.py -D PNP_TUNING, EPROPNP_LIB=...): per-phase cycle shares of the forward kernel
+    import ctypes
+    from epropnp import _hip
+    fn = _hip.lib().epropnp_tuning_phase_cycles
+    buf = (ctypes.c_ulonglong * 8)()
+    tot = float(sum(buf[:6])) if fn(buf, 0) == 0 else 0.0
+    if tot > 0:
+        print('forward phases [init, draw, sweep, weights, refit, store]:', [round(v / tot, 3) for v in buf[:6]],
+              'cycles/block', round(tot / (8 * B)))
+except AttributeError:
+    pass

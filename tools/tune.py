@@ -51,7 +51,8 @@ def worker(B, N, S, K, L, reps=8):
         torch.cuda.synchronize()
         fn(buf, 0)
         tot = float(sum(buf)) or 1.0
-        phases = [round(v / tot, 3) for v in buf][:6]
+        tot = float(sum(buf[:6])) or 1.0
+        phases = [round(v / tot, 3) for v in buf][:8]
     except AttributeError:
         pass
     g = -torch.softmax(logw, 0) / B
