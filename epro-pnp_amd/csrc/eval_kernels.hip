@@ -220,12 +220,18 @@ __global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__
   const int b = row % B;
   const int lane = lane_id();
   const float2* w = reinterpret_cast<const float2*>(w2d) + (size_t)b * N;
-  for (int n = lane; n < N; n += 64) {
-    const float2 wi = w[n];
-    const float wm = 0.5f * (wi.x + wi.y);
-    const Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)n, (uint32_t)offset, (uint32_t)(offset >> 32),
+  for (int n4 = lane; 4 * n4 < N; n4 += 64) {      // one Philox block = the uniforms of points 4 n4 .. 4 n4 + 3
+    const Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)n4, (uint32_t)offset, (uint32_t)(offset >> 32),
                                     (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
-    key[n] = (wm > 0.f) ? -logf(u01(r.v[0])) / wm : INFINITY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = 4 * n4 + q;
+      if (n < N) {
+        const float2 wi = w[n];
+        const float wm = 0.5f * (wi.x + wi.y);
+        key[n] = (wm > 0.f) ? -logf(u01(r.v[q])) / wm : INFINITY;
+      }
+    }
   }
   wave_lds_fence();
   for (int k = 0; k < n_pts; ++k) {

@@ -114,11 +114,17 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
     if (inds != nullptr) {
       if (l16 < n_pts) my_idx = (int)inds[prow * n_pts + l16];
     } else {
-      for (int n = l16; n < N; n += 16) {
-        const float wm = 0.5f * (sW[2 * n] + sW[2 * n + 1]);
-        const Philox4 r = philox4x32_10((uint32_t)prow, (uint32_t)n, (uint32_t)offset, (uint32_t)(offset >> 32),
+      for (int n4 = l16; 4 * n4 < N; n4 += 16) {     // same stream as rslm_draw_kernel: one Philox block per 4 points
+        const Philox4 r = philox4x32_10((uint32_t)prow, (uint32_t)n4, (uint32_t)offset, (uint32_t)(offset >> 32),
                                         (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
-        mykey[n] = (wm > 0.f) ? -logf(u01(r.v[0])) / wm : INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 4 * n4 + q;
+          if (n < N) {
+            const float wm = 0.5f * (sW[2 * n] + sW[2 * n + 1]);
+            mykey[n] = (wm > 0.f) ? -logf(u01(r.v[q])) / wm : INFINITY;
+          }
+        }
       }
       wave_lds_fence();
       for (int k = 0; k < n_pts; ++k) {
@@ -183,25 +189,19 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
     int bits = 0;
     lm_iterate<DOF>(lm, sweep, pose, cur, bits);
 
-    // ---- score the proposal on the full correspondence set (:343, cost-only IEEE path as evaluate_cost_kernel) ----
+    // ---- score the proposal on the full correspondence set (:343); hardware rcp / sqrt as in the AMIS sweeps: the
+    // score only ranks proposals (and is compared with another pose's cost by LMSolver.solve), 1-ulp effects are moot
     float c = 0.f;
     {
       float R[9], KR[9], Kt[3];
       pose_to_rot<DOF>(pose, R);
       compose_kr_kt(K, R, pose, KR, Kt);
       for (int n = l16; n < N; n += 16) {
-        const float X = sX[3 * n], Y = sX[3 * n + 1], Z = sX[3 * n + 2];
-        const float hx = KR[0] * X + KR[1] * Y + KR[2] * Z + Kt[0];
-        const float hy = KR[3] * X + KR[4] * Y + KR[5] * Z + Kt[1];
-        const float hz = KR[6] * X + KR[7] * Y + KR[8] * Z + Kt[2];
-        const float z = fmaxf(hz, p.z_min);
-        float px = hx / z, py = hy / z;
-        if (BOUNDS) {
-          px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-          py = fminf(fmaxf(py, bd.lby), bd.uby);
-        }
-        const float rx = (px - sU[2 * n]) * sW[2 * n], ry = (py - sU[2 * n + 1]) * sW[2 * n + 1];
-        c += huber_exact(sqrtf(rx * rx + ry * ry), delta);
+        SweepPoint sp;
+        sp.X = sX[3 * n]; sp.Y = sX[3 * n + 1]; sp.Z = sX[3 * n + 2];
+        sp.wu = sW[2 * n]; sp.wv = sW[2 * n + 1];
+        sp.cu = -sU[2 * n] * sp.wu; sp.cv = -sU[2 * n + 1] * sp.wv;
+        c += sweep_cost<BOUNDS>(sp, KR, Kt, zmin_v, delta_v, bd);
       }
       c = row_sum16(c);
     }
