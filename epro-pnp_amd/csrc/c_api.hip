@@ -96,6 +96,20 @@ int epropnp_shift_poses(const float* pose, const float* offset, int32_t num_pose
   return pnp::launch_shift_poses(pose, offset, num_poses, num_obj, dof, sign, out, (hipStream_t)stream);
 }
 
+int epropnp_prepare_forward(const float* noc, const float* dim, const float* logits, const float* scale,
+                            int32_t num_obj, int32_t num_pts, int32_t mode, float* x3d, float* w2d, float* stats,
+                            void* stream) {
+  return pnp::launch_prepare_forward(noc, dim, logits, scale, num_obj, num_pts, mode, x3d, w2d, stats, (hipStream_t)stream);
+}
+
+int epropnp_prepare_backward(const float* noc, const float* dim, const float* logits, const float* scale,
+                             const float* stats, const float* grad_x3d, const float* grad_w2d, int32_t num_obj,
+                             int32_t num_pts, int32_t mode, float* grad_noc, float* grad_dim, float* grad_logits,
+                             float* grad_scale, void* stream) {
+  return pnp::launch_prepare_backward(noc, dim, logits, scale, stats, grad_x3d, grad_w2d, num_obj, num_pts, mode, grad_noc,
+                                      grad_dim, grad_logits, grad_scale, (hipStream_t)stream);
+}
+
 #ifdef PNP_TUNING
 // tuning builds only (not part of the ABI): per-phase shader-clock totals of amis_forward_mfma_kernel
 int epropnp_tuning_phase_cycles(unsigned long long* out, int reset) { return pnp::tuning_phase_cycles(out, reset); }

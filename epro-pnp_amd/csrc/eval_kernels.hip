@@ -315,6 +315,156 @@ int launch_shift_poses(const float* pose, const float* offset, int P, int B, int
   return check_launch("shift_poses_kernel");
 }
 
+// Correspondence pre-processing of the reference's callers, fused (forward + backward):
+//   x3d = noc * dim                                   (EPro-PnP-6DoF/lib/train.py:141, Det deform_pnp_head.py:873)
+//   mode 0: w2d = softmax_N(logits) * scale           (Det deform_pnp_head.py:418-423,874)
+//   mode 1: w2d = exp(logits - mean_N(logits) - log N) * scale     ("mean-normalised exp", lib/train.py:163-166)
+// One workgroup per object; stats[b] = {max or mean (x, y), sum of exponentials (x, y)} is kept for the backward.
+__global__ __launch_bounds__(256) void prepare_forward_kernel(const float* __restrict__ noc, const float* __restrict__ dim,
+                                                               const float* __restrict__ logits,
+                                                               const float* __restrict__ scale, int B, int N, int mode,
+                                                               float* __restrict__ x3d, float* __restrict__ w2d,
+                                                               float* __restrict__ stats) {
+  __shared__ float scratch[4 * 4];
+  const int b = object_of_block(B);
+  if (b >= B) return;
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+  const float2* lg = reinterpret_cast<const float2*>(logits) + (size_t)b * N;
+  float ref[2];
+  if (mode == 0) {
+    float mx = -INFINITY, my = -INFINITY;
+    for (int n = tid; n < N; n += T) {
+      const float2 v = lg[n];
+      mx = fmaxf(mx, v.x); my = fmaxf(my, v.y);
+    }
+    ref[0] = block_max(mx, scratch);
+    ref[1] = block_max(my, scratch);
+  } else {
+    float s[2] = {0.f, 0.f};
+    for (int n = tid; n < N; n += T) {
+      const float2 v = lg[n];
+      s[0] += v.x; s[1] += v.y;
+    }
+    block_sum<2>(s, scratch);
+    ref[0] = s[0] / (float)N; ref[1] = s[1] / (float)N;
+  }
+  float se[2] = {0.f, 0.f};
+  if (mode == 0) {
+    for (int n = tid; n < N; n += T) {
+      const float2 v = lg[n];
+      se[0] += expf(v.x - ref[0]); se[1] += expf(v.y - ref[1]);
+    }
+    block_sum<2>(se, scratch);
+  } else {
+    se[0] = se[1] = (float)N;                // exp(l - mean - log N) = exp(l - mean) / N
+  }
+  const float sx = scale ? scale[(size_t)b * 2] : 1.f, sy = scale ? scale[(size_t)b * 2 + 1] : 1.f;
+  const float kx = sx / se[0], ky = sy / se[1];
+  float2* wo = reinterpret_cast<float2*>(w2d) + (size_t)b * N;
+  for (int n = tid; n < N; n += T) {
+    const float2 v = lg[n];
+    wo[n] = make_float2(expf(v.x - ref[0]) * kx, expf(v.y - ref[1]) * ky);
+  }
+  if (x3d != nullptr) {
+    const float d0 = dim[(size_t)b * 3], d1 = dim[(size_t)b * 3 + 1], d2 = dim[(size_t)b * 3 + 2];
+    const float* src = noc + (size_t)b * N * 3;
+    float* dst = x3d + (size_t)b * N * 3;
+    for (int n = tid; n < N; n += T) {
+      dst[3 * n] = src[3 * n] * d0; dst[3 * n + 1] = src[3 * n + 1] * d1; dst[3 * n + 2] = src[3 * n + 2] * d2;
+    }
+  }
+  if (tid == 0) {
+    stats[(size_t)b * 4] = ref[0]; stats[(size_t)b * 4 + 1] = ref[1];
+    stats[(size_t)b * 4 + 2] = se[0]; stats[(size_t)b * 4 + 3] = se[1];
+  }
+}
+
+// grad_x3d (B,N,3) | NULL, grad_w2d (B,N,2) -> grad_noc, grad_dim (B,3), grad_logits (B,N,2), grad_scale (B,2)
+__global__ __launch_bounds__(256) void prepare_backward_kernel(const float* __restrict__ noc, const float* __restrict__ dim,
+                                                                const float* __restrict__ logits,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ gx3d,
+                                                                const float* __restrict__ gw2d, int B, int N, int mode,
+                                                                float* __restrict__ gnoc, float* __restrict__ gdim,
+                                                                float* __restrict__ glogits, float* __restrict__ gscale) {
+  __shared__ float scratch[5 * 4];
+  const int b = object_of_block(B);
+  if (b >= B) return;
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+  const float2* lg = reinterpret_cast<const float2*>(logits) + (size_t)b * N;
+  const float2* gw = reinterpret_cast<const float2*>(gw2d) + (size_t)b * N;
+  const float r0 = stats[(size_t)b * 4], r1 = stats[(size_t)b * 4 + 1];
+  const float ie0 = 1.0f / stats[(size_t)b * 4 + 2], ie1 = 1.0f / stats[(size_t)b * 4 + 3];
+  const float sx = scale ? scale[(size_t)b * 2] : 1.f, sy = scale ? scale[(size_t)b * 2 + 1] : 1.f;
+  // sums: sum_n g_n p_n per channel (p = normalised exponential without the scale), sum_n gx3d_n * noc_n per axis
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int n = tid; n < N; n += T) {
+    const float2 v = lg[n], g = gw[n];
+    s[0] = fmaf(g.x, expf(v.x - r0) * ie0, s[0]);
+    s[1] = fmaf(g.y, expf(v.y - r1) * ie1, s[1]);
+    if (gx3d != nullptr) {
+      const size_t o = ((size_t)b * N + n) * 3;
+      s[2] = fmaf(gx3d[o], noc[o], s[2]); s[3] = fmaf(gx3d[o + 1], noc[o + 1], s[3]); s[4] = fmaf(gx3d[o + 2], noc[o + 2], s[4]);
+    }
+  }
+  block_sum<5>(s, scratch);
+  // softmax:          dL/dl_n = s p_n (g_n - sum_m g_m p_m)
+  // mean-normalised:  dL/dl_n = s (g_n p_n - (1/N) sum_m g_m p_m)
+  float2* gl = reinterpret_cast<float2*>(glogits) + (size_t)b * N;
+  const float invn = 1.0f / (float)N;
+  for (int n = tid; n < N; n += T) {
+    const float2 v = lg[n], g = gw[n];
+    const float px = expf(v.x - r0) * ie0, py = expf(v.y - r1) * ie1;
+    float ox, oy;
+    if (mode == 0) {
+      ox = sx * px * (g.x - s[0]); oy = sy * py * (g.y - s[1]);
+    } else {
+      ox = sx * (g.x * px - invn * s[0]); oy = sy * (g.y * py - invn * s[1]);
+    }
+    gl[n] = make_float2(ox, oy);
+  }
+  if (gx3d != nullptr) {
+    const float d0 = dim[(size_t)b * 3], d1 = dim[(size_t)b * 3 + 1], d2 = dim[(size_t)b * 3 + 2];
+    for (int n = tid; n < N; n += T) {
+      const size_t o = ((size_t)b * N + n) * 3;
+      gnoc[o] = gx3d[o] * d0; gnoc[o + 1] = gx3d[o + 1] * d1; gnoc[o + 2] = gx3d[o + 2] * d2;
+    }
+  }
+  if (tid == 0) {
+    if (gscale) { gscale[(size_t)b * 2] = s[0]; gscale[(size_t)b * 2 + 1] = s[1]; }
+    if (gdim && gx3d != nullptr) { gdim[(size_t)b * 3] = s[2]; gdim[(size_t)b * 3 + 1] = s[3]; gdim[(size_t)b * 3 + 2] = s[4]; }
+  }
+}
+
+static int prepare_threads(int N) {
+  int t = 64;
+  while (t < 256 && t * 2 < N) t *= 2;
+  return t;
+}
+
+int launch_prepare_forward(const float* noc, const float* dim, const float* logits, const float* scale, int B, int N,
+                           int mode, float* x3d, float* w2d, float* stats, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!logits || !w2d || !stats || N < 1 || (mode != 0 && mode != 1) || ((x3d != nullptr) && (!noc || !dim)))
+    return fail(EPROPNP_EINVAL, "prepare_forward: bad argument");
+  PNP_LAUNCH(prepare_forward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc, dim, logits, scale, B,
+             N, mode, x3d, w2d, stats);
+  return check_launch("prepare_forward_kernel");
+}
+
+int launch_prepare_backward(const float* noc, const float* dim, const float* logits, const float* scale, const float* stats,
+                            const float* gx3d, const float* gw2d, int B, int N, int mode, float* gnoc, float* gdim,
+                            float* glogits, float* gscale, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!logits || !stats || !gw2d || !glogits || N < 1 || (mode != 0 && mode != 1) ||
+      ((gx3d != nullptr) && (!noc || !dim || !gnoc)))
+    return fail(EPROPNP_EINVAL, "prepare_backward: bad argument");
+  PNP_LAUNCH(prepare_backward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc, dim, logits, scale,
+             stats, gx3d, gw2d, B, N, mode, gnoc, gdim, glogits, gscale);
+  return check_launch("prepare_backward_kernel");
+}
+
 int launch_rslm_draw(const float* w2d, int B, int N, int P, int n_pts, unsigned long long seed, unsigned long long offset,
                      long long* inds, hipStream_t st) {
   if (B <= 0 || P <= 0 || n_pts <= 0) return EPROPNP_OK;

@@ -93,6 +93,11 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
 int launch_center_points(const float* x3d, int B, int N, float* offset, float* out, hipStream_t st);
 int launch_shift_poses(const float* pose, const float* offset, int P, int B, int dof, float sign, float* out,
                        hipStream_t st);
+int launch_prepare_forward(const float* noc, const float* dim, const float* logits, const float* scale, int B, int N,
+                           int mode, float* x3d, float* w2d, float* stats, hipStream_t st);
+int launch_prepare_backward(const float* noc, const float* dim, const float* logits, const float* scale, const float* stats,
+                            const float* gx3d, const float* gw2d, int B, int N, int mode, float* gnoc, float* gdim,
+                            float* glogits, float* gscale, hipStream_t st);
 int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, hipStream_t st);
 int launch_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
                             float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);

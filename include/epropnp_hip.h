@@ -158,6 +158,24 @@ int epropnp_center_points(const float* x3d, int32_t num_obj, int32_t num_pts, fl
 int epropnp_shift_poses(const float* pose, const float* offset, int32_t num_poses, int32_t num_obj, int32_t dof,
                         float sign, float* out, void* stream);
 
+/* Correspondence pre-processing of the reference's training loops, fused (the callers' side of the layer):
+ *   x3d = noc * dim                                            EPro-PnP-6DoF/lib/train.py:141, Det deform_pnp_head.py:873
+ *   mode 0: w2d = softmax_N(logits) * scale                    Det deform_pnp_head.py:418-423,874
+ *   mode 1: w2d = exp(logits - mean_N(logits) - log N) * scale EPro-PnP-6DoF/lib/train.py:163-166
+ * noc (B,N,3), dim (B,3) (both NULL with x3d NULL: weights only), logits (B,N,2), scale (B,2) or NULL
+ * -> x3d (B,N,3), w2d (B,N,2), stats (B,4) kept for the backward. */
+#define EPROPNP_W2D_SOFTMAX 0
+#define EPROPNP_W2D_MEAN_EXP 1
+int epropnp_prepare_forward(const float* noc, const float* dim, const float* logits, const float* scale,
+                            int32_t num_obj, int32_t num_pts, int32_t mode, float* x3d, float* w2d, float* stats,
+                            void* stream);
+/* grad_x3d (B,N,3) or NULL, grad_w2d (B,N,2) -> grad_noc (B,N,3), grad_dim (B,3), grad_logits (B,N,2),
+ * grad_scale (B,2) (grad_noc / grad_dim / grad_scale may be NULL). */
+int epropnp_prepare_backward(const float* noc, const float* dim, const float* logits, const float* scale,
+                             const float* stats, const float* grad_x3d, const float* grad_w2d, int32_t num_obj,
+                             int32_t num_pts, int32_t mode, float* grad_noc, float* grad_dim, float* grad_logits,
+                             float* grad_scale, void* stream);
+
 /* RSLMSolver.solve (epropnp/levenberg_marquardt.py:283-353) in one launch: center_based_init, weighted sub-sampling
  * of `num_points` (<= 16) correspondences per proposal, random initial rotations, `num_proposals` LM/GN solves per
  * object on the sub-samples (parameters `lm`, as LMSolver.solve), full-set cost of every proposal, argmin.
