@@ -220,8 +220,8 @@ def main():
                          'frac': round(lm_gbs / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from rocprofv3 PMC (separate passes): 2 x FETCH_SIZE (gfx950 counts a
                          # coalesced read at half size, MI355X_MICROARCH.md) + WRITE_SIZE, for the default C2 workload:
-                         # profiles/r01_run8_pmc_counters.txt (FETCH_SIZE 29256.5 KiB, WRITE_SIZE 688.4 KiB)
-                         'traffic': (2 * 29256.5 + 688.4) * 1024 if (B, N, L) == (4096, 512, 3) else None,
+                         # profiles/r01_final_pmc_counters.txt (FETCH_SIZE 29260.6 KiB, WRITE_SIZE 688.9 KiB)
+                         'traffic': (2 * 29260.6 + 688.9) * 1024 if (B, N, L) == (4096, 512, 3) else None,
                          'algorithmic_bytes_per_launch': lm_bytes, 'logical_sweeps': sweeps,
                          'launch_ms': round(t_lm, 4)},
             'roofline_valu': {

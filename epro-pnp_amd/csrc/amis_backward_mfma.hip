@@ -240,8 +240,9 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
   if (smem > 160 * 1024) return 1;
   // 4 waves x NPT <= 4 point tiles of 16 per chunk (<= 164 VGPRs: 3 workgroups per CU); larger N loops over chunks of
   // 256 points against the LDS-resident pose table.  Measured at C2: 4x4 (2 chunks) 1.07 ms, 4x8 1.11, 8x4 1.22.
+  // Few objects (fewer than two waves per SIMD otherwise): 8 waves, one chunk of 512 points (B = 32 / 256: -7..9 %).
   const int ptiles = (d.N + 15) / 16;
-  int waves = 4, npt = 1;
+  int waves = (d.B < 512 && ptiles > 16) ? 8 : 4, npt = 1;
   while (npt < 4 && waves * npt < ptiles) npt *= 2;
   { int ov[2]; if (env_ints("EPROPNP_BWD_MFMA", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8)) { waves = ov[0]; npt = ov[1]; } }
   const dim3 grid(padded_object_grid(d.B)), block(64 * waves);

@@ -28,6 +28,7 @@ struct AmisParams {
   int mle_iter;
   float dispersion;
   unsigned long long seed, offset;
+  const unsigned long long* offset_dev;   // optional device-side addend to `offset` (graph replay)
   int ablate;          // tuning builds only (-DPNP_TUNING): bit0 skip sweep, bit1 skip proposal refit, bit2 skip densities
 };
 

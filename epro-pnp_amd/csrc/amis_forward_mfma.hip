@@ -108,7 +108,7 @@ struct MfmaShape {
 #define PNP_FWD_MINW 4
 #endif
 template <int DOF, bool BOUNDS, int NPT>
-__global__ __launch_bounds__(512, ((NPT <= 8 && DOF == 6) ? PNP_FWD_MINW : 2)) void amis_forward_mfma_kernel(Problem p, AmisParams a, MfmaShape sh,
+__global__ __launch_bounds__(512, ((NPT <= 8 && DOF == 6) ? PNP_FWD_MINW : 2)) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
                                                                   const float* __restrict__ noise,
@@ -118,6 +118,8 @@ __global__ __launch_bounds__(512, ((NPT <= 8 && DOF == 6) ? PNP_FWD_MINW : 2)) v
   constexpr int PL = PoseLen<DOF>::value;
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
+  AmisParams a = a_in;
+  if (a.offset_dev != nullptr) a.offset += *a.offset_dev;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), W = T >> 6;
   const int S = a.S, K = a.K, s = S / K, s16 = sh.s16, NC = sh.chunk;
 
@@ -331,7 +333,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   }
   AmisParams k;
   k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
-  k.seed = am->seed; k.offset = am->offset; k.ablate = 0;
+  k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
   const size_t smem = sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (size_t)PL * S + 3 * (size_t)S +
                                        (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256 + 8 * (size_t)s);

@@ -21,7 +21,7 @@ namespace pnp {
 // forward
 // ================================================================================================================
 template <int DOF, int PPL, bool BOUNDS, int MAXW>
-__global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) void amis_forward_kernel(Problem p, AmisParams a,
+__global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) void amis_forward_kernel(Problem p, AmisParams a_in,
                                                                    const float* __restrict__ pose_opt,
                                                                    const float* __restrict__ pose_cov,
                                                                    const float* __restrict__ noise,
@@ -32,6 +32,8 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) vo
   constexpr int NZ = (DOF == 6) ? 8 : 4 + 3 * kVmTries;
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
+  AmisParams a = a_in;
+  if (a.offset_dev != nullptr) a.offset += *a.offset_dev;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
   const int S = a.S, K = a.K, s = S / K, WP = a.WP, WS = (T >> 6) / WP;
   const int wp = wv % WP, ws = wv / WP;
@@ -350,7 +352,7 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   }
   AmisParams k;
   k.S = S; k.K = K; k.WP = WP; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
-  k.seed = am->seed; k.offset = am->offset;
+  k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev;
   k.ablate = 0;
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
   // the float4-viewed arrays (ptab rows, wred) come first so that they are 16-B aligned for any S
@@ -378,11 +380,10 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
   if (mc_samples < 0) return fail(EPROPNP_EINVAL, "amis_backward: negative mc_samples");
   if ((mc_samples > 0 && (!pose_samples || !grad_logweights)) || !grad_x3d || !grad_x2d || !grad_w2d || !grad_delta)
     return fail(EPROPNP_EINVAL, "amis_backward: NULL pointer");
-  {   // many objects: projection on the matrix cores (amis_backward_mfma.hip); EPROPNP_BWD_IMPL=valu|mfma forces one
+  {   // projection on the matrix cores (amis_backward_mfma.hip) unless its LDS pose table does not fit;
+      // EPROPNP_BWD_IMPL=valu forces this file's all-VALU kernel
     const char* impl = getenv("EPROPNP_BWD_IMPL");
-    // few objects: this file's kernel spreads one object over more waves (choose_shape) and wins (C3 / C4 shapes)
-    const bool want_mfma = impl ? (impl[0] == 'm') : (prob->num_obj >= 2048 || prob->num_pts > kMaxResidentPoints);
-    if (want_mfma) {
+    if (!(impl && impl[0] == 'v')) {
       const int rc = launch_amis_backward_mfma(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init,
                                                grad_x3d, grad_x2d, grad_w2d, grad_delta, st);
       if (rc <= 0) return rc;     // 1 = shape not supported there (pose table larger than LDS)

@@ -80,10 +80,10 @@ int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float
 }
 
 int epropnp_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int32_t num_proposals,
-                       int32_t num_points, uint64_t seed, uint64_t offset, const int64_t* inds, const float* rot,
-                       float* pose, float* cost, void* stream) {
-  return pnp::launch_rslm_solve(prob, lm, num_proposals, num_points, seed, offset, (const long long*)inds, rot, pose, cost,
-                                (hipStream_t)stream);
+                       int32_t num_points, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                       const int64_t* inds, const float* rot, float* pose, float* cost, void* stream) {
+  return pnp::launch_rslm_solve(prob, lm, num_proposals, num_points, seed, offset, (const unsigned long long*)offset_dev,
+                                (const long long*)inds, rot, pose, cost, (hipStream_t)stream);
 }
 
 int epropnp_center_points(const float* x3d, int32_t num_obj, int32_t num_pts, float* offset, float* x3d_centered,

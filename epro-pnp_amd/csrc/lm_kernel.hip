@@ -120,7 +120,9 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
     });
     return check_launch("lm_solve_kernel (row variant)");
   }
-  Shape s = choose_shape(d.B, d.N);
+  // fewest waves per object at every batch size: more waves only add cross-wave reduction + barrier latency to each of
+  // the 1+L dependent sweeps (measured on MI355X at B = 32 / 256 / 600: 1 wave 38 / 30 / 30 us vs 86 / 62 / 41 us)
+  Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/0);
   int ov[2];
   if (env_ints("EPROPNP_LM_SHAPE", ov, 2) && 64 * ov[0] * ov[1] >= d.N) { s.waves = ov[0]; s.ppl = ov[1]; }
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);

@@ -88,8 +88,8 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
                               int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
                               float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
-                      unsigned long long offset, const long long* inds, const float* rot, float* pose_out, float* cost_out,
-                      hipStream_t st);
+                      unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
+                      float* pose_out, float* cost_out, hipStream_t st);
 int launch_center_points(const float* x3d, int B, int N, float* offset, float* out, hipStream_t st);
 int launch_shift_poses(const float* pose, const float* offset, int P, int B, int dof, float sign, float* out,
                        hipStream_t st);

@@ -24,7 +24,9 @@ PNP_FN float row_min16(float x) { return -row_max16(-x); }
 
 template <int DOF, bool BOUNDS>
 __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
-                                                          unsigned long long offset, const long long* __restrict__ inds,
+                                                          unsigned long long offset_in,
+                                                          const unsigned long long* __restrict__ offset_dev,
+                                                          const long long* __restrict__ inds,
                                                           const float* __restrict__ rot, float* __restrict__ pose_out,
                                                           float* __restrict__ cost_out) {
   constexpr int PL = PoseLen<DOF>::value;
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
   const int tid = (int)threadIdx.x, l16 = tid & 15, row = tid >> 4, N = p.N;
+  const unsigned long long offset = offset_in + (offset_dev ? *offset_dev : 0ull);
   const int Np = (N + 3) & ~3;
   PNP_DYN_SMEM(float, smem);
   float* sX = smem;                 // [N][3]
@@ -235,8 +238,8 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
 }
 
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
-                      unsigned long long offset, const long long* inds, const float* rot, float* pose_out, float* cost_out,
-                      hipStream_t st) {
+                      unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
+                      float* pose_out, float* cost_out, hipStream_t st) {
   if (int rc = check_problem(prob)) return rc;
   if (!lm) return fail(EPROPNP_EINVAL, "rslm_solve: params NULL");
   if (prob->num_obj == 0) return EPROPNP_OK;
@@ -257,7 +260,7 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
   const dim3 grid(padded_object_grid(d.B)), block(256);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     PNP_LAUNCH((rslm_solve_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, smem, st, d, k, P, n_pts, seed,
-               offset, inds, rot, pose_out, cost_out);
+               offset, offset_dev, inds, rot, pose_out, cost_out);
     return 0;
   });
   return check_launch("rslm_solve_kernel");

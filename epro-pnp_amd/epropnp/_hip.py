@@ -32,10 +32,10 @@ class LmParams(C.Structure):
 class AmisParams(C.Structure):
     _fields_ = [('mc_samples', C.c_int32), ('num_iter', C.c_int32), ('eps', C.c_float),
                 ('acg_mle_iter', C.c_int32), ('acg_dispersion', C.c_float), ('seed', C.c_uint64),
-                ('offset', C.c_uint64)]
+                ('offset', C.c_uint64), ('offset_dev', C.c_void_p)]
 
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 _emulated = False     # True only when a test installed the CPU logic-emulation build (tests/emu)
 
@@ -58,7 +58,7 @@ def _declare(lib):
     lib.epropnp_prepare_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.epropnp_prepare_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.epropnp_rslm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), i32, i32, C.c_uint64, C.c_uint64, vp, vp, vp,
-                                       vp, vp]
+                                       vp, vp, vp]
     lib.epropnp_adaptive_delta.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp]
     lib.epropnp_mc_loss_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.epropnp_mc_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]

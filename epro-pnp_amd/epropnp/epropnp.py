@@ -56,6 +56,21 @@ class EProPnPBase(torch.nn.Module):
         self.solver = solver
         self.seed = seed
         self._calls = 0
+        self.rng_counter = None      # device int64 counter (enable_graph_safe_rng): fresh draws on hipGraph replays
+
+    def enable_graph_safe_rng(self, device):
+        """Keep the Philox call counter in DEVICE memory (and advance it with an in-stream add) instead of in this
+        Python object, so that a step captured into a hipGraph (torch.cuda.CUDAGraph) draws fresh samples on every
+        replay.  Also covers the RSLM initialiser of the solver.  Seeds are fixed now (no host sync later)."""
+        if self.seed is None:
+            self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=device)
+        init = getattr(self.solver, 'init_solver', None)
+        if init is not None and hasattr(init, 'num_proposals'):
+            if not hasattr(init, '_draw_seed'):
+                init._draw_seed, init._draw_calls = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
+            init.rng_counter = torch.zeros(1, dtype=torch.int64, device=device)     # its own call counter
+        return self
 
     def forward(self, *args, **kwargs):
         return self.solver(*args, **kwargs)
@@ -66,7 +81,10 @@ class EProPnPBase(torch.nn.Module):
         cfg = dict(mc_samples=self.mc_samples, num_iter=self.num_iter, eps=self.eps, noise=noise, seed=self.seed,
                    offset=self._calls, acg_mle_iter=getattr(self, 'acg_mle_iter', 3),
                    acg_dispersion=getattr(self, 'acg_dispersion', 0.001))
-        self._calls += 1
+        if self.rng_counter is not None:
+            cfg.update(offset=0, offset_dev=self.rng_counter)
+        else:
+            self._calls += 1
         return cfg
 
     def monte_carlo_forward(self, x3d, x2d, w2d, camera, cost_fun, pose_init=None, force_init_solve=True,
@@ -97,6 +115,8 @@ class EProPnPBase(torch.nn.Module):
                                        pose_opt, pose_cov, pose_init, cost_init_value, self._amis_config(noise))
             pose_samples, pose_sample_logweights = out[0], out[1]
             cost_init = out[2] if pose_init is not None else None
+            if self.rng_counter is not None and noise is None:
+                self.rng_counter.add_(1)          # in-stream: part of a captured graph
         else:   # keep autograd connectivity for empty batches (DDP callers rely on it)
             pose_samples = x2d.new_zeros((self.mc_samples,) + pose_opt.size())
             pose_sample_logweights = x3d.reshape(self.mc_samples, 0) + x2d.reshape(self.mc_samples, 0) \

@@ -107,7 +107,7 @@ def noise_stride(dof):
 
 
 def amis_forward(prob, pose_opt, pose_cov, mc_samples, num_iter, eps=1e-5, acg_mle_iter=3, acg_dispersion=0.001,
-                 noise=None, seed=0, offset=0, with_proposals=False):
+                 noise=None, seed=0, offset=0, with_proposals=False, offset_dev=None):
     """-> pose_samples (S,B,pose_len), logweights (S,B) [, proposals (B,K,40)]."""
     po, pc = _f32c(pose_opt, 'pose_opt'), _f32c(pose_cov, 'pose_cov')
     S, B = int(mc_samples), prob.B
@@ -117,7 +117,8 @@ def amis_forward(prob, pose_opt, pose_cov, mc_samples, num_iter, eps=1e-5, acg_m
     if noise is not None:
         nz = _f32c(noise, 'noise')
         assert nz.shape == (B, num_iter, S // num_iter, noise_stride(prob.dof)), f'noise shape {tuple(nz.shape)}'
-    par = _hip.AmisParams(S, int(num_iter), eps, int(acg_mle_iter), acg_dispersion, int(seed), int(offset))
+    par = _hip.AmisParams(S, int(num_iter), eps, int(acg_mle_iter), acg_dispersion, int(seed), int(offset),
+                          _hip.ptr(offset_dev))
     _hip.call('epropnp_amis_forward', C.byref(prob.c), C.byref(par), _hip.ptr(po), _hip.ptr(pc), _hip.ptr(nz),
               _hip.ptr(samples), _hip.ptr(logw), _hip.ptr(props), prob.stream)
     return (samples, logw, props) if with_proposals else (samples, logw)
@@ -293,6 +294,7 @@ RSLM_MAX_POINTS = 512      # epropnp_rslm_solve keeps an object's correspondence
 
 
 def rslm_solve(prob, num_proposals, num_points, num_iter, seed=0, offset=0, inds=None, rot=None, fast_mode=False,
+               offset_dev=None,
                min_lm_diagonal=1e-6, max_lm_diagonal=1e32, min_relative_decrease=1e-3,
                initial_trust_region_radius=30.0, max_trust_region_radius=1e16, eps=1e-5):
     """The whole random-sample LM initialiser in one launch -> pose (B,pose_len), cost (B,).
@@ -307,8 +309,8 @@ def rslm_solve(prob, num_proposals, num_points, num_iter, seed=0, offset=0, inds
     pose, cost = prob.new(prob.B, prob.pose_len), prob.new(prob.B)
     par = _hip.LmParams(int(num_iter), int(bool(fast_mode)), min_lm_diagonal, max_lm_diagonal, min_relative_decrease,
                         initial_trust_region_radius, max_trust_region_radius, eps)
-    _hip.call('epropnp_rslm_solve', C.byref(prob.c), C.byref(par), P, n, int(seed), int(offset), _hip.ptr(inds),
-              _hip.ptr(rot), _hip.ptr(pose), _hip.ptr(cost), prob.stream)
+    _hip.call('epropnp_rslm_solve', C.byref(prob.c), C.byref(par), P, n, int(seed), int(offset), _hip.ptr(offset_dev),
+              _hip.ptr(inds), _hip.ptr(rot), _hip.ptr(pose), _hip.ptr(cost), prob.stream)
     return pose, cost
 
 

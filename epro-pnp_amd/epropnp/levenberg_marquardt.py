@@ -183,9 +183,15 @@ class RSLMSolver(LMSolver):
                     inds, rot = self.draw(w2d)
                 if not hasattr(self, '_draw_seed'):
                     self._draw_seed, self._draw_calls = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
-                self._draw_calls += 1
-                pose, min_cost = hip.rslm_solve(prob, P, n, self.num_iter, self._draw_seed, self._draw_calls - 1, inds,
-                                                rot, fast_mode=bool(kwargs.get('fast_mode', False)), **self._lm_kwargs())
+                counter = getattr(self, 'rng_counter', None)       # device-side call counter (hipGraph replay)
+                if counter is None:
+                    self._draw_calls += 1
+                pose, min_cost = hip.rslm_solve(prob, P, n, self.num_iter, self._draw_seed,
+                                                0 if counter is not None else self._draw_calls - 1, inds, rot,
+                                                fast_mode=bool(kwargs.get('fast_mode', False)), offset_dev=counter,
+                                                **self._lm_kwargs())
+                if counter is not None and inds is None:
+                    counter.add_(1)
                 return pose, None, min_cost
             inds, rot = self.draw(w2d)
             obj = torch.arange(bs, device=inds.device)[None, :, None]

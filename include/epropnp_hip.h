@@ -28,7 +28,7 @@ extern "C" {
 #define EPROPNP_ELAUNCH (-2)  /* HIP launch/runtime error                                         */
 #define EPROPNP_ENODEV (-3)   /* no HIP device / not a gfx950 code object                         */
 
-#define EPROPNP_ABI_VERSION 1
+#define EPROPNP_ABI_VERSION 2
 
 /* Correspondences + camera + robust-cost parameters of one batch of objects.
  * Mirrors the state of PerspectiveCamera (epropnp/camera.py:35-62) and HuberPnPCost.delta
@@ -68,6 +68,8 @@ typedef struct epropnp_amis_params {
   float acg_dispersion;   /* 0.001 (6-DoF only)       */
   uint64_t seed;          /* Philox key when `noise` is NULL */
   uint64_t offset;        /* Philox counter offset (advance by 1 per call for fresh draws) */
+  const uint64_t* offset_dev; /* optional DEVICE counter added to `offset` when the kernel runs: lets a captured hipGraph
+                                 draw fresh samples on every replay (the caller increments it inside the graph) */
 } epropnp_amis_params;
 
 int epropnp_abi_version(void);
@@ -181,10 +183,11 @@ int epropnp_prepare_backward(const float* noc, const float* dim, const float* lo
  * object on the sub-samples (parameters `lm`, as LMSolver.solve), full-set cost of every proposal, argmin.
  *   inds: NULL (drawn on the device, same stream as epropnp_rslm_draw) or (P,B,num_points) int64 injected indices
  *   rot:  NULL (drawn on the device) or (P,B,1) yaw / (P,B,4) unit quaternions, injected
+ *   offset_dev: optional device counter added to `offset` at run time (hipGraph replay), or NULL
  *   -> pose (B,pose_len) best proposal, cost (B,) its full-set Huber cost (may be NULL).   num_pts in [2, 512]. */
 int epropnp_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int32_t num_proposals,
-                       int32_t num_points, uint64_t seed, uint64_t offset, const int64_t* inds, const float* rot,
-                       float* pose, float* cost, void* stream);
+                       int32_t num_points, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                       const int64_t* inds, const float* rot, float* pose, float* cost, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ def test_exports_match_header(lib):
 
 
 def test_abi_version_and_noise_stride(lib):
-    assert lib.epropnp_abi_version() == 1
+    assert lib.epropnp_abi_version() == 2
     assert lib.epropnp_noise_stride(6) == 8 and lib.epropnp_noise_stride(4) == 52 and lib.epropnp_noise_stride(5) == -1
 
 
