@@ -169,3 +169,89 @@ def test_c5_stress_shard_properties(dev):
     assert (samples[..., 3:].norm(dim=-1) - 1).abs().max() < 1e-5
     assert bool((cost <= cost_init.detach() * (1 + 1e-5) + 1e-6).all())
     assert (pose_opt[:, :3] - prob['pose_init'][:, :3]).norm(dim=-1).max() < 1.0
+
+
+def test_c2_gn_step_fused_vs_composite_and_backward_variants(dev, monkeypatch):
+    """C2 size: the fused Gauss-Newton step against the PyTorch composite on a slice of the batch (values + input
+    gradients), batch-composition independence of the fused kernel, and agreement of the two backward kernels
+    (matrix-core projection vs all-VALU) on the full batch."""
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    from epropnp.levenberg_marquardt import LMSolver
+    B, N = 4096, 512
+    prob = device_problem(B, N, 6, dev, seed=12)
+    cf = AdaptiveHuberPnPCost(relative_delta=0.5)
+    cf.set_param(prob['x2d'], prob['w2d'])
+    solver = LMSolver(dof=6, num_iter=3)
+    x3d, x2d, w2d = (prob[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+    cam = PerspectiveCamera(cam_mats=prob['cam_mats'])
+    pose_opt, _, _, plus = solver(x3d, x2d, w2d, cam, cf, with_pose_opt_plus=True, pose_init=prob['pose_init'])
+    up = torch.linspace(0.5, 1.5, 7, device=dev)
+    (plus * up).sum().backward()
+    assert torch.isfinite(plus).all() and all(torch.isfinite(t.grad).all() for t in (x3d, x2d, w2d))
+    # composite (autograd through the materialised Jacobian) on the first 64 objects
+    sl = slice(0, 64)
+    cam_s = PerspectiveCamera(cam_mats=prob['cam_mats'][sl])
+    cf_s = AdaptiveHuberPnPCost(relative_delta=0.5)
+    cf_s.delta = cf.delta[sl].detach()
+    leaves = [prob[k][sl].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d')]
+    from epropnp.common import evaluate_pnp
+    res, _, jac = evaluate_pnp(*leaves, pose_opt[sl], cam_s, cf_s, out_jacobian=True, out_residual=True)
+    jt = jac.transpose(-1, -2)
+    step = -torch.linalg.solve(jt @ jac + 1e-5 * torch.eye(6, device=dev), jt @ res.unsqueeze(-1)).squeeze(-1)
+    ref = solver.pose_add(pose_opt[sl], step, cam_s)
+    (ref * up).sum().backward()
+    assert (plus[sl] - ref).abs().max() < 2e-4
+    for got, want in zip((x3d, x2d, w2d), leaves):
+        den = want.grad.abs().amax(dim=(1, 2), keepdim=True).clamp(min=1e-12)
+        assert ((got.grad[sl] - want.grad).abs() / den).max() < 5e-3
+    # batch-composition independence: objects 100..163 alone give the same step bit for bit
+    sub = slice(100, 164)
+    hp = F.PnPProblem(prob['x3d'][sub], prob['x2d'][sub], prob['w2d'][sub], PerspectiveCamera(cam_mats=prob['cam_mats'][sub]),
+                      type('C', (), {'delta': cf.delta[sub].detach().contiguous()})(), 6)
+    hp_all = F.PnPProblem(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf, 6)
+    s_all = F.gn_step(prob['x3d'], prob['x2d'], prob['w2d'], None, hp_all, pose_opt, 1e-5)
+    s_sub = F.gn_step(prob['x3d'][sub], prob['x2d'][sub], prob['w2d'][sub], None, hp, pose_opt[sub].contiguous(), 1e-5)
+    torch.testing.assert_close(s_all[sub], s_sub, rtol=0, atol=0)
+    # backward kernels: same gradients from the MFMA and the VALU implementation
+    layer = layer6(512, 4, 3)
+    noise = device_noise(B, 512, 4, dev, 3)
+    o = layer.monte_carlo_forward(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf, pose_init=prob['pose_init'],
+                                  force_init_solve=False, noise=noise)
+    g = -torch.softmax(o[4].detach(), 0) / B
+    gi = torch.full((B,), 1.0 / B, device=dev)
+    outs = {}
+    for impl in ('mfma', 'valu'):
+        monkeypatch.setenv('EPROPNP_BWD_IMPL', impl)
+        outs[impl] = F.amis_backward(hp_all, o[3], g, prob['pose_init'], gi)
+    for a, b in zip(outs['mfma'], outs['valu']):
+        den = b.abs().max().clamp(min=1e-20)
+        assert ((a - b).abs().max() / den) < 2e-4
+
+
+def test_c4_fused_rslm_vs_composite(dev, monkeypatch):
+    """Detection shape (600 objects x 128 points, 4-DoF, 64 proposals of 16 points): the one-launch initialiser and the
+    composite path reach equally good poses from the same index draws; both beat the perturbed start."""
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    from epropnp.levenberg_marquardt import RSLMSolver
+    B, N, P, n = 600, 128, 64, 16
+    prob = device_problem(B, N, 4, dev, seed=21)
+    cam = PerspectiveCamera(z_min=0.1, allowed_border=200)
+    cam.set_param(prob['cam_mats'], img_shape=torch.tensor([[480., 640.]], device=dev).expand(B, 2))
+    cf = AdaptiveHuberPnPCost(relative_delta=0.5)
+    cf.set_param(prob['x2d'], prob['w2d'])
+    inds = F.rslm_draw(prob['w2d'], P, n, seed=11, offset=0)
+    rot = torch.rand(P, B, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 6.283185307179586
+    solver = RSLMSolver(dof=4, num_points=n, num_proposals=P, num_iter=3)
+    solver.draw = lambda w2d: (inds, rot)
+    monkeypatch.setenv('EPROPNP_RSLM_COMPOSITE', '1')
+    pose_c, _, cost_c = solver.solve(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf)
+    monkeypatch.delenv('EPROPNP_RSLM_COMPOSITE')
+    pose_f, _, cost_f = solver.solve(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf)
+    torch.testing.assert_close(cost_f, cost_c, rtol=5e-4, atol=1e-5)
+    assert int(((pose_f - pose_c).abs().max(-1).values < 1e-3).sum()) >= B - 6          # rounding-level ties may differ
+    hp = F.PnPProblem(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf, 4)
+    assert float((cost_f <= F.evaluate_cost(hp, prob['pose_init']) * 1.5 + 1e-3).float().mean()) > 0.9
