@@ -10,10 +10,10 @@ cat gpurun_out/smoke.log
 (timeout 600 python bench.py 2>&1 | tail -1) > gpurun_out/bench.log
 cat gpurun_out/bench.log
 cd /tmp; rm -rf /tmp/prof
-(timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python /root/repo/bench.py --no-cpu-baseline 2>&1 | tail -1) > /root/repo/gpurun_out/bench_under_rocprof.log
+(timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python /root/repo/bench.py --no-cpu-baseline --no-hipgraph 2>&1 | tail -1) > /root/repo/gpurun_out/bench_under_rocprof.log
 python /root/repo/tools/rocprof_summary.py /tmp/prof/bench_results.db | cut -c1-190 > /root/repo/gpurun_out/kernel_stats.txt
 head -12 /root/repo/gpurun_out/kernel_stats.txt
-B="python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-hipgraph"
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VALU_TRANS SQ_LDS_BANK_CONFLICT" \
