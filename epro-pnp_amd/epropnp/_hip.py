@@ -124,6 +124,11 @@ def ptr(t):
 def stream_of(t):
     if _emulated:
         return None
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        # kernels are launched on the calling thread's current device: a foreign stream would fail inside HIP
+        raise RuntimeError(f'epropnp: tensors live on {t.device} but the current device is '
+                           f'cuda:{torch.cuda.current_device()}; call torch.cuda.set_device({t.device.index}) '
+                           f'(one process per GPU, as under torch.distributed)')
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
