@@ -104,7 +104,7 @@ def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
     assert (logw - expect).abs().max().item() <= 2e-4 * max(1.0, expect.abs().max().item())
 
 
-@pytest.mark.parametrize('impl,N', [('valu', 150), ('mfma', 150), ('mfma', 300), ('mfma', 16), ('valu', 16)])
+@pytest.mark.parametrize('impl,N', [('valu', 150), ('mfma', 150), ('mfma', 300), ('mfma', 16), ('valu', 16), ('mfma', 17)])
 def test_backward_matches_autograd_of_oracle_at_fixed_samples(backend, monkeypatch, impl, N):
     """The backward kernels alone (VALU sweep / MFMA projection; N=300 loops over two point chunks): arbitrary
     upstream gradients, samples fixed -> compare with autograd through the oracle's evaluate (which is what the
@@ -113,6 +113,8 @@ def test_backward_matches_autograd_of_oracle_at_fixed_samples(backend, monkeypat
     monkeypatch.setenv('EPROPNP_BWD_IMPL', impl)
     for dof, bounds in ((6, None), (4, 'tight'), (6, 'tight')):
         B, S = 3, 40
+        if N == 17:                               # pose table larger than LDS: the MFMA launcher hands over to the VALU kernel
+            B, S = 1, 2800
         prob = orc.make_problem(B, N, dof, seed=11, bounds=bounds)
         g = torch.Generator().manual_seed(5)
         poses = prob['pose_gt'].unsqueeze(0).repeat(S, 1, 1)
@@ -125,7 +127,7 @@ def test_backward_matches_autograd_of_oracle_at_fixed_samples(backend, monkeypat
         poses[0, 0, 2] = -1.0                     # behind the camera: z clamp active
         g_logw = torch.randn(S, B, generator=g)
         g_logw[3] = 0.0                           # exact zeros are skipped by the kernel
-        g_logw[5:9, 1] *= 1e-12                   # below the 2^-30 relative drop threshold
+        g_logw[5:9, B - 1] *= 1e-12               # below the 2^-30 relative drop threshold
         g_init = torch.randn(B, generator=g)
         x3d, x2d, w2d, delta = (prob[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta'))
         ocam = orc.Cam(prob['cam_mats'], 0.1, prob.get('lb'), prob.get('ub'))
