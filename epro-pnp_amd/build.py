@@ -15,6 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['eval_kernels.hip', 'lm_kernel.hip', 'amis_kernels.hip', 'amis_forward_mfma.hip', 'amis_backward_mfma.hip', 'gn_step_kernel.hip', 'rslm_kernel.hip', 'c_api.hip']
+# per-source flags (HIP build only).  Where the SLP vectoriser packs independent scalar FMAs into v_pk_* it pays for it in
+# v_mov shuffles and gains nothing (packed fp32 runs at the scalar flop rate): lm 79 -> 70 us at C2, rslm 117 -> 107 us at
+# C4, forward 0.84 -> 0.82 ms (its Huber sweep is packed explicitly, on 2-vectors).  The backward keeps the default.
+_NO_SLP = ['-fno-slp-vectorize']
+FILE_FLAGS = {'lm_kernel.hip': _NO_SLP, 'rslm_kernel.hip': _NO_SLP, 'amis_forward_mfma.hip': _NO_SLP}
 HEADERS = ['pnp_math.h', 'wave_ops.h', 'pnp_sweep.h', 'pnp_host.h', 'dispatch.h', 'amis_common.h', 'lm_core.h']
 
 
@@ -55,7 +60,7 @@ def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=())
         obj = os.path.join(out_dir, src.replace('.hip', '.emu.o' if emu else '.o'))
         objs.append(obj)
         if force or _stale(obj, [sp] + deps_common):
-            jobs.append(cc + ['-c', sp, '-o', obj])
+            jobs.append(cc + ([] if emu else FILE_FLAGS.get(src, [])) + ['-c', sp, '-o', obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             for out in ex.map(_run, jobs):
