@@ -34,7 +34,7 @@ __device__ __forceinline__ bwd_floatx4 bwd_mfma(float a, float b, bwd_floatx4 c)
 #define PNP_BWD_MINW 3
 #endif
 template <int DOF, bool BOUNDS, int NPT>
-__global__ __launch_bounds__(512, PNP_BWD_MINW) void amis_backward_mfma_kernel(Problem p, const float* __restrict__ pose_samples,
+__global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backward_mfma_kernel(Problem p, const float* __restrict__ pose_samples,
                                                                      const float* __restrict__ g_logw, int S,
                                                                      const float* __restrict__ pose_init,
                                                                      const float* __restrict__ g_init, int P16,
