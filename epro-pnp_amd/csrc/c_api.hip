@@ -4,6 +4,7 @@
 namespace pnp {
 #ifdef PNP_TUNING
 int tuning_phase_cycles(unsigned long long* out, int reset);
+int tuning_rslm_phase_cycles(unsigned long long* out, int reset);
 #endif
 char* last_error_buffer() {
   static thread_local char buf[512] = {0};
@@ -113,6 +114,7 @@ int epropnp_prepare_backward(const float* noc, const float* dim, const float* lo
 #ifdef PNP_TUNING
 // tuning builds only (not part of the ABI): per-phase shader-clock totals of amis_forward_mfma_kernel
 int epropnp_tuning_phase_cycles(unsigned long long* out, int reset) { return pnp::tuning_phase_cycles(out, reset); }
+int epropnp_tuning_rslm_cycles(unsigned long long* out, int reset) { return pnp::tuning_rslm_phase_cycles(out, reset); }
 #endif
 
 }  // extern "C"

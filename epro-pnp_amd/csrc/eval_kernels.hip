@@ -212,13 +212,17 @@ __global__ __launch_bounds__(256) void mc_loss_backward_kernel(const float* __re
 }
 
 // One wave per (proposal, object) row.  Keys live in LDS; each of the n_pts rounds is a wave-wide argmin.
+// N <= 512 uses the packed keys of pnp_math.h (race_key): one integer min per round, the same stream and the same
+// winners as the fused initialiser (rslm_kernel.hip).  Larger N keeps float keys with an explicit lowest-index tie-break.
 __global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__ w2d, int B, int N, int P, int n_pts,
                                                         unsigned long long seed, unsigned long long offset,
                                                         long long* __restrict__ inds) {
   PNP_DYN_SMEM(float, key);
+  unsigned* ukey = reinterpret_cast<unsigned*>(key);
   const int row = (int)blockIdx.x;          // row = proposal * B + object
   const int b = row % B;
   const int lane = lane_id();
+  const bool packed = N <= (int)(kRaceIdxMask + 1);
   const float2* w = reinterpret_cast<const float2*>(w2d) + (size_t)b * N;
   for (int n4 = lane; 4 * n4 < N; n4 += 64) {      // one Philox block = the uniforms of points 4 n4 .. 4 n4 + 3
     const Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)n4, (uint32_t)offset, (uint32_t)(offset >> 32),
@@ -229,23 +233,34 @@ __global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__
       if (n < N) {
         const float2 wi = w[n];
         const float wm = 0.5f * (wi.x + wi.y);
-        key[n] = (wm > 0.f) ? -logf(u01(r.v[q])) / wm : INFINITY;
+        if (packed) ukey[n] = race_key(r.v[q], wm, n);
+        else key[n] = (wm > 0.f) ? fabsf(logf(u01(r.v[q]))) / wm : INFINITY;
       }
     }
   }
   wave_lds_fence();
   for (int k = 0; k < n_pts; ++k) {
-    float best = INFINITY, best_n = 1e9f;
-    for (int n = lane; n < N; n += 64) {
-      const float v = key[n];
-      if (v < best) { best = v; best_n = (float)n; }
+    int wi;
+    if (packed) {
+      unsigned best = 0xffffffffu;
+      for (int n = lane; n < N; n += 64) best = min(best, ukey[n]);
+      const unsigned m = wave_min_u32(best);
+      const int slot = (int)(m & kRaceIdxMask);
+      wi = (m < kRaceInf) ? slot : (k % N);   // fewer positive weights than n_pts: fall back deterministically
+      if (m != 0xffffffffu && lane == (slot & 63)) ukey[slot] = 0xffffffffu;
+    } else {
+      float best = INFINITY, best_n = 1e9f;
+      for (int n = lane; n < N; n += 64) {
+        const float v = key[n];
+        if (v < best) { best = v; best_n = (float)n; }
+      }
+      const float m = -wave_max(-best);
+      const float cand = (best == m) ? best_n : 1e9f;
+      const float win = -wave_max(-cand);       // lowest index among ties
+      wi = (win < 1e8f) ? (int)win : (k % N);
+      if (lane == (wi & 63)) key[wi] = INFINITY;
     }
-    const float m = -wave_max(-best);
-    const float cand = (best == m) ? best_n : 1e9f;
-    const float win = -wave_max(-cand);       // lowest index among ties
-    const int wi = (win < 1e8f) ? (int)win : (k % N);   // fewer positive weights than n_pts: fall back deterministically
     if (lane == 0) inds[(size_t)row * n_pts + k] = (long long)wi;
-    if (lane == (wi & 63)) key[wi] = INFINITY;
     wave_lds_fence();
   }
 }

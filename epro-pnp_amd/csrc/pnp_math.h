@@ -443,6 +443,24 @@ PNP_FN float u01(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 1677721
 // two independent N(0,1) from two uint32
 // Hardware v_log / v_sin / v_cos (the latter take their argument in revolutions, exactly what Box-Muller wants):
 // ~10 instructions instead of ~110 for the libm versions; absolute error ~1e-6, irrelevant for random draws.
+// Exponential-race key of point n with weight w (weighted sampling without replacement: the n_pts smallest keys win),
+// packed for integer min-reductions: a non-negative float orders like its bit pattern, and the low 9 mantissa bits
+// carry the point index (n < 512; the 2^-14 relative perturbation of the key is immaterial to the sampling law, and ties
+// break towards the lower index for free).  Zero-weight points get +inf | n: never picked before any positive weight.
+constexpr unsigned kRaceIdxBits = 9, kRaceIdxMask = (1u << kRaceIdxBits) - 1, kRaceInf = 0x7F800000u;
+PNP_FN unsigned race_key(uint32_t rnd, float w, int n) {
+  if (!(w > 0.f)) return kRaceInf | (unsigned)n;
+  // -ln(u) / w up to the constant factor ln 2 (irrelevant to the order): hardware log2, one division
+#ifndef EPROPNP_EMU
+  const float k = fabsf(__builtin_amdgcn_logf(u01(rnd))) / w;
+#else
+  const float k = fabsf(log2f(u01(rnd))) / w;
+#endif
+  unsigned bits;
+  memcpy(&bits, &k, sizeof(bits));       // bit cast (compiles to a move)
+  return (bits & ~kRaceIdxMask) | (unsigned)n;
+}
+
 PNP_FN void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
 #ifndef EPROPNP_EMU
   const float r = fast_sqrt(-1.3862943611198906f * __builtin_amdgcn_logf(u01(a)));   // -2 ln u = -2 ln2 log2 u

@@ -22,6 +22,29 @@ constexpr int kRslmRows = 16;       // DPP rows per workgroup
 
 PNP_FN float row_min16(float x) { return -row_max16(-x); }
 
+#ifdef PNP_TUNING
+// tuning builds: cycles of thread 0 in [staging + centre init | key draw | 16 picks | sub-sample solve | scoring | argmin]
+__device__ unsigned long long g_rslm_phase[8];
+#define PNP_RSLM_PHASE(i)                                                  \
+  do {                                                                     \
+    if (tid == 0) {                                                        \
+      const long long now_ = clock64();                                    \
+      atomicAdd(&g_rslm_phase[i], (unsigned long long)(now_ - rslm_t0_));  \
+      rslm_t0_ = now_;                                                     \
+    }                                                                      \
+  } while (0)
+int tuning_rslm_phase_cycles(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rslm_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rslm_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define PNP_RSLM_PHASE(i)
+#endif
+
 template <int DOF, bool BOUNDS>
 __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
                                                           unsigned long long offset_in,
@@ -35,6 +58,9 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
   if (b >= p.B) return;
   const int tid = (int)threadIdx.x, l16 = tid & 15, row = tid >> 4, N = p.N;
   const unsigned long long offset = offset_in + (offset_dev ? *offset_dev : 0ull);
+#ifdef PNP_TUNING
+  long long rslm_t0_ = clock64();
+#endif
   const int Np = (N + 3) & ~3;
   PNP_DYN_SMEM(float, smem);
   float* sX = smem;                 // [N][3]
@@ -98,6 +124,7 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
     t0[0] = mean[0] * depth; t0[1] = mean[1] * depth; t0[2] = depth;
   }
 
+  PNP_RSLM_PHASE(0);
   float Kv[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) Kv[i] = to_vgpr(K[i]);
@@ -117,34 +144,57 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
     if (inds != nullptr) {
       if (l16 < n_pts) my_idx = (int)inds[prow * n_pts + l16];
     } else {
-      for (int n4 = l16; 4 * n4 < N; n4 += 16) {     // same stream as rslm_draw_kernel: one Philox block per 4 points
+      // exponential-race keys, packed with the point index (pnp_math.h: race_key); same Philox stream and the same
+      // winners as rslm_draw_kernel.  N <= 128: each lane sorts its 8 keys in registers once (19 compare-exchanges) and
+      // a pick is a row-wide min over the heads + a conditional shift; larger N scans the keys in LDS per pick.
+      unsigned* ukey = reinterpret_cast<unsigned*>(mykey);
+      for (int n4 = l16; 4 * n4 < N; n4 += 16) {
         const Philox4 r = philox4x32_10((uint32_t)prow, (uint32_t)n4, (uint32_t)offset, (uint32_t)(offset >> 32),
                                         (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = 4 * n4 + q;
-          if (n < N) {
-            const float wm = 0.5f * (sW[2 * n] + sW[2 * n + 1]);
-            mykey[n] = (wm > 0.f) ? -logf(u01(r.v[q])) / wm : INFINITY;
-          }
+          if (n < N) ukey[n] = race_key(r.v[q], 0.5f * (sW[2 * n] + sW[2 * n + 1]), n);
         }
       }
       wave_lds_fence();
-      for (int k = 0; k < n_pts; ++k) {
-        float bestk = INFINITY, best_n = 1e9f;
-        for (int n = l16; n < N; n += 16) {
-          const float v = mykey[n];
-          if (v < bestk) { bestk = v; best_n = (float)n; }
+      PNP_RSLM_PHASE(1);
+      if (N <= 128) {
+        unsigned k8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int n = l16 + 16 * i;
+          k8[i] = (n < N) ? ukey[n] : 0xffffffffu;
         }
-        const float m = row_min16(bestk);
-        const float cand = (bestk == m) ? best_n : 1e9f;
-        const float win = row_min16(cand);                   // lowest index among ties
-        const int wi = (win < 1e8f) ? (int)win : (k % N);    // fewer positive weights than n_pts
-        if (l16 == k) my_idx = wi;
-        if (l16 == (wi & 15)) mykey[wi] = INFINITY;
-        wave_lds_fence();
+        auto cx = [&](int i, int j) {
+          const unsigned lo = min(k8[i], k8[j]), hi = max(k8[i], k8[j]);
+          k8[i] = lo; k8[j] = hi;
+        };
+        cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7); cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7); cx(1, 2); cx(5, 6); cx(0, 4);
+        cx(3, 7); cx(1, 5); cx(2, 6); cx(1, 4); cx(3, 6); cx(2, 4); cx(3, 5); cx(3, 4);
+        for (int k = 0; k < n_pts; ++k) {
+          const unsigned m = row_min16_u32(k8[0]);
+          const bool own = (k8[0] == m) && (m != 0xffffffffu);
+          const int wi = (m < kRaceInf) ? (int)(m & kRaceIdxMask) : (k % N);   // fewer positive weights than n_pts
+          if (l16 == k) my_idx = wi;
+#pragma unroll
+          for (int i = 0; i < 7; ++i) k8[i] = own ? k8[i + 1] : k8[i];
+          k8[7] = own ? 0xffffffffu : k8[7];
+        }
+      } else {
+        for (int k = 0; k < n_pts; ++k) {
+          unsigned best = 0xffffffffu;
+          for (int n = l16; n < N; n += 16) best = min(best, ukey[n]);
+          const unsigned m = row_min16_u32(best);
+          const int slot = (int)(m & kRaceIdxMask);
+          const int wi = (m < kRaceInf) ? slot : (k % N);
+          if (l16 == k) my_idx = wi;
+          if (m != 0xffffffffu && l16 == (slot & 15)) ukey[slot] = 0xffffffffu;
+          wave_lds_fence();
+        }
       }
     }
+    PNP_RSLM_PHASE(2);
     Point pt;
     if (my_idx >= 0 && my_idx < N) {
       pt.X = sX[3 * my_idx]; pt.Y = sX[3 * my_idx + 1]; pt.Z = sX[3 * my_idx + 2];
@@ -191,6 +241,7 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
     float cur[NV];
     int bits = 0;
     lm_iterate<DOF>(lm, sweep, pose, cur, bits);
+    PNP_RSLM_PHASE(3);
 
     // ---- score the proposal on the full correspondence set (:343); hardware rcp / sqrt as in the AMIS sweeps: the
     // score only ranks proposals (and is compared with another pose's cost by LMSolver.solve), 1-ulp effects are moot
@@ -208,6 +259,7 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
       }
       c = row_sum16(c);
     }
+    PNP_RSLM_PHASE(4);
     if (active && (j0 == 0 || c < best_cost)) {
       best_cost = c;
 #pragma unroll

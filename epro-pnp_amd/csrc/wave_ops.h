@@ -110,6 +110,31 @@ __device__ __forceinline__ float row_max16(float x) {
 #endif
 }
 
+// min over the 16 lanes of a DPP row / over the wave, unsigned (packed sort keys)
+__device__ __forceinline__ unsigned row_min16_u32(unsigned x) {
+#ifndef EPROPNP_EMU
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false));
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false));
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false));
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false));
+  return x;
+#else
+  for (int m : {8, 4, 2, 1}) {
+    const int l = lane_id();
+    const unsigned o = (unsigned)emu::shfl((int)x, (l & ~15) | ((l + m) & 15));
+    x = o < x ? o : x;
+  }
+  return x;
+#endif
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+  x = row_min16_u32(x);
+  const unsigned a = (unsigned)wave_bcast((int)x, 0), b = (unsigned)wave_bcast((int)x, 16);
+  const unsigned c = (unsigned)wave_bcast((int)x, 32), d = (unsigned)wave_bcast((int)x, 48);
+  const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
+}
+
 // Orders this wave's earlier LDS writes before its later LDS reads of OTHER lanes' data.  The hardware executes a
 // wave's DS instructions in order, so no s_barrier is needed; this only stops the compiler from reordering.
 __device__ __forceinline__ void wave_lds_fence() {

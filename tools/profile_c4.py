@@ -34,3 +34,12 @@ try:      # tuning builds (build.py -D PNP_TUNING, EPROPNP_LIB=...): per-phase c
               'cycles/block', round(tot / (8 * B)))
 except AttributeError:
     pass
+try:
+    fn = _hip.lib().epropnp_tuning_rslm_cycles
+    buf = (ctypes.c_ulonglong * 8)()
+    tot = float(sum(buf[:5])) if fn(buf, 0) == 0 else 0.0
+    if tot > 0:
+        print('rslm phases [stage+centre, keys, picks, solve, score]:', [round(v / tot, 3) for v in buf[:5]],
+              'cycles/block', round(tot / (8 * B)))
+except (AttributeError, NameError):
+    pass
