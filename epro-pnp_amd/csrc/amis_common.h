@@ -257,6 +257,21 @@ struct AmisCtx {
   int cstride;    // row stride of cpart (s, or s rounded up to 16 for the MFMA kernel)
 };
 
+#ifdef PNP_TUNING
+// tuning builds: cycles spent by the fitting lane in [moment pass + reductions | ACG fixed-point iterations | final fits]
+__device__ unsigned long long g_refit_phase[4];
+#define PNP_REFIT_PHASE(i)                                                   \
+  do {                                                                       \
+    if (tid == 0) {                                                          \
+      const long long now_ = clock64();                                      \
+      atomicAdd(&g_refit_phase[i], (unsigned long long)(now_ - refit_t0_));  \
+      refit_t0_ = now_;                                                      \
+    }                                                                        \
+  } while (0)
+#else
+#define PNP_REFIT_PHASE(i)
+#endif
+
 // Base draws of sample m of object b: 3 normals + Chi2(3) for the Student-t translation, 4 normals for the ACG
 // rotation (6-DoF).  Philox4x32-10 counter (b, m, offset, q), Box-Muller.  They do not depend on the fitted proposal,
 // which is what lets the otherwise idle waves produce them while one lane runs the fp64 proposal fit.
@@ -327,6 +342,9 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
     ps[0] = rec[0] + rec[3] * y0;
     ps[1] = rec[1] + (rec[4] * y0 + rec[5] * y1);
     ps[2] = rec[2] + (rec[6] * y0 + rec[7] * y1 + rec[8] * y2);
+#ifdef PNP_TUNING
+    const long long rot_t0_ = clock64();
+#endif
     if (DOF == 6) {   // ACG: L_r g / |L_r g|   (distributions.py:42-52)
       const float v0 = rec[16] * g[0];
       const float v1 = rec[17] * g[0] + rec[18] * g[1];
@@ -362,6 +380,9 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
         ps[3] = vm_sample_bounded(rec[16], rec[17], uniforms);
       }
     }
+#ifdef PNP_TUNING
+    if (tid == 0) atomicAdd(&g_refit_phase[3], (unsigned long long)(clock64() - rot_t0_));
+#endif
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
       smp[i * S + m] = ps[i];
@@ -418,21 +439,6 @@ PNP_FN void amis_weights(const AmisCtx& cx, const AmisParams& a, int it, int WP)
   }
 
 }
-
-#ifdef PNP_TUNING
-// tuning builds: cycles spent by the fitting lane in [moment pass + reductions | ACG fixed-point iterations | final fits]
-__device__ unsigned long long g_refit_phase[4];
-#define PNP_REFIT_PHASE(i)                                                   \
-  do {                                                                       \
-    if (tid == 0) {                                                          \
-      const long long now_ = clock64();                                      \
-      atomicAdd(&g_refit_phase[i], (unsigned long long)(now_ - refit_t0_));  \
-      refit_t0_ = now_;                                                      \
-    }                                                                        \
-  } while (0)
-#else
-#define PNP_REFIT_PHASE(i)
-#endif
 
 // ---------------- 5. fit proposal it+1 to the weighted samples (epropnp.py:238-260 / :317-342) ---------
 template <int DOF>

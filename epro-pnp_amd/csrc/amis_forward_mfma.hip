@@ -277,8 +277,8 @@ int tuning_phase_cycles(unsigned long long* out, int reset) {
   if (out) {    // slots 6, 7 are unused by the kernel phases: cycles of the refit's [ACG fixed-point iterations | final fp64 fits]
     unsigned long long rf[4];
     if (hipMemcpyFromSymbol(rf, HIP_SYMBOL(g_refit_phase), sizeof(rf)) != hipSuccess) return -1;
-    out[6] = rf[1];
-    out[7] = rf[2];
+    out[6] = rf[1] + rf[2];
+    out[7] = rf[3];      // rotation sampling inside the draw phase (ACG / von Mises)
     const unsigned long long z4[4] = {0, 0, 0, 0};
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_refit_phase), z4, sizeof(z4)) != hipSuccess) return -1;
   }

@@ -1,0 +1,67 @@
+"""Randomised shapes / degenerate inputs for the sweep-level kernels against the oracle (CPU emulation of the same
+kernel sources; the GPU run repeats a fixed subset).  Edge cases the reference's code paths care about: points behind
+the camera (z clamp + clip_jac), projection bounds hit, zero weights, N not a multiple of any tile size, tiny N."""
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import epropnp_oracle as orc
+from helpers import make_layer_objects
+
+
+def _check(backend, B, N, dof, bounds, seed, behind, zero_w):
+    from epropnp import functional as F
+    p = orc.make_problem(B, N, dof=dof, seed=seed, bounds=bounds)
+    g = torch.Generator().manual_seed(seed)
+    if behind:                       # push a few points behind the camera for the first object
+        k = max(1, N // 7)
+        p['x3d'][0, :k, 2] -= 30.0
+    if zero_w:
+        p['w2d'][:, torch.randperm(N, generator=g)[: max(1, N // 5)]] = 0.0
+    pose = p['pose_init']
+    d, cam, cf = make_layer_objects(p, backend)
+    hp = F.PnPProblem(d['x3d'], d['x2d'], d['w2d'], cam, cf, dof)
+    jtj, jtr, cost = F.normal_equations(hp, pose.to(backend), clip_jac=True)
+    # oracle in fp64 through its public entry points
+    q = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in p.items()}
+    ocam = orc.Cam(q['cam_mats'], 0.1, q.get('lb'), q.get('ub'))
+    res, _, jac = orc.evaluate(q['x3d'], q['x2d'], q['w2d'], pose.double(), ocam, q['delta'], True, True)
+    c_ref = orc.evaluate(q['x3d'], q['x2d'], q['w2d'], pose.double(), ocam, q['delta'], want_cost=True)[1]
+    jt = jac.transpose(-1, -2)
+    jtj_ref, jtr_ref = jt @ jac, (jt @ res.unsqueeze(-1)).squeeze(-1)
+    scale = jtj_ref.abs().amax(dim=(-1, -2), keepdim=True).clamp(min=1e-12)
+    assert ((jtj.cpu().double() - jtj_ref).abs() / scale).max() < 5e-5
+    assert ((jtr.cpu().double() - jtr_ref).abs() / jtr_ref.abs().amax(-1, keepdim=True).clamp(min=1e-6)).max() < 5e-4
+    torch.testing.assert_close(cost.cpu().double(), c_ref, rtol=5e-5, atol=1e-6)
+    poses = torch.stack((pose, p['pose_gt']))
+    costs = F.evaluate_cost(hp, poses.to(backend))
+    ref = torch.stack([orc.evaluate(q['x3d'], q['x2d'], q['w2d'], pp.double(), ocam, q['delta'], want_cost=True)[1]
+                       for pp in poses])
+    torch.testing.assert_close(costs.cpu().double(), ref, rtol=2e-4, atol=1e-6)
+    step = F.gn_step(d['x3d'], d['x2d'], d['w2d'], None, hp, pose.to(backend), 1e-5)
+    step_ref = orc.gn_step(q['x3d'], q['x2d'], q['w2d'], pose.double(), ocam, q['delta'])
+    den = step_ref.abs().amax(-1, keepdim=True).clamp(min=1e-9)
+    assert ((step.cpu().double() - step_ref).abs() / den).max() < 2e-3
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(B=st.integers(1, 4), N=st.sampled_from([4, 5, 15, 16, 17, 63, 64, 65, 100, 257]), dof=st.sampled_from([4, 6]),
+       bounds=st.sampled_from([None, 'tensor', 'tight']), seed=st.integers(0, 10_000), behind=st.booleans(),
+       zero_w=st.booleans())
+def test_sweep_kernels_random_shapes(B, N, dof, bounds, seed, behind, zero_w):
+    from epropnp import _hip
+    import conftest
+    _hip._use_emulation_library(conftest._emu_lib())
+    try:
+        _check(torch.device('cpu'), B, N, dof, bounds, seed, behind, zero_w)
+    finally:
+        _hip._use_emulation_library(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,N,dof,bounds,behind,zero_w', [(3, 17, 6, 'tight', True, True), (2, 257, 4, None, True, False),
+                                                          (4, 5, 4, 'tensor', False, False), (1, 1000, 6, 'tight', True, True)])
+def test_sweep_kernels_edge_shapes_gpu(B, N, dof, bounds, behind, zero_w):
+    from epropnp import _hip
+    _hip._use_emulation_library(None)
+    _check(torch.device('cuda:0'), B, N, dof, bounds, 123, behind, zero_w)

@@ -30,7 +30,7 @@ try:      # tuning builds (build.py -D PNP_TUNING, EPROPNP_LIB=...): per-phase c
     buf = (ctypes.c_ulonglong * 8)()
     tot = float(sum(buf[:6])) if fn(buf, 0) == 0 else 0.0
     if tot > 0:
-        print('forward phases [init, draw, sweep, weights, refit, store]:', [round(v / tot, 3) for v in buf[:6]],
+        print('forward phases [init, draw, sweep, weights, refit, store | refit fp64 part, rotation draw]:', [round(v / tot, 3) for v in buf[:8]],
               'cycles/block', round(tot / (8 * B)))
 except AttributeError:
     pass
