@@ -40,12 +40,35 @@ def evaluate_pnp(x3d, x2d, w2d, pose, camera, cost_fun, out_jacobian=False, out_
     """Project, then apply the robust cost.  Each out_* is False (skip), True (return) or a tensor (filled).
     Returns (residual (*,2n) | None, cost (*) | None, jacobian (*,2n,4|6) | None).
     Reference: epropnp/common.py:67-100."""
+    if out_cost is True and out_jacobian is False and out_residual is False and not kwargs and _cost_only_fast_path(
+            x3d, x2d, w2d, pose, cost_fun):
+        # cost of one pose / a grid of poses per object (AMIS-style broadcast, Det's orientation grid): the cost-only
+        # sweep kernel, no (P,B,N,.) temporaries
+        from . import functional as hip
+        prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, 4 if pose.size(-1) == 4 else 6)
+        return None, hip.evaluate_cost(prob, pose), None
     jac_buf = out_jacobian
     if isinstance(out_jacobian, torch.Tensor):
         jac_buf = out_jacobian.view(x2d.shape[:-1] + (2, out_jacobian.size(-1)))
     x2d_proj, jac_cam = camera.project(x3d, pose, out_jac=jac_buf, **kwargs)
     return cost_fun.compute(x2d_proj, x2d, w2d, jac_cam=jac_cam, out_residual=out_residual, out_cost=out_cost,
                             out_jacobian=out_jacobian)
+
+
+def _cost_only_fast_path(x3d, x2d, w2d, pose, cost_fun):
+    """HIP tensors, nothing to differentiate, points (B,N,.) and poses (B,p) or (P,B,p)."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (x3d, x2d, w2d, pose)):
+        return False
+    delta = getattr(cost_fun, 'delta', None)
+    if isinstance(delta, torch.Tensor) and (delta.requires_grad and torch.is_grad_enabled()):
+        return False
+    if x3d.dim() != 3 or x2d.dim() != 3 or w2d.dim() != 3 or x3d.size(0) == 0:
+        return False
+    B = x3d.size(0)
+    if not ((pose.dim() == 2 and pose.size(0) == B) or (pose.dim() == 3 and pose.size(1) == B)):
+        return False
+    from . import _hip
+    return _hip.on_hip_path(x3d, x2d, w2d, pose)
 
 
 def rotate_offset(pose, offset):

@@ -259,3 +259,25 @@ def test_mc_loss_kernel_edge_values(backend):
     fin = torch.isfinite(ref)
     torch.testing.assert_close(loss[fin], ref[fin], rtol=1e-5, atol=1e-5)
     assert loss[8].item() == float('-inf') and loss[9].item() == float('inf')
+
+
+def test_evaluate_pnp_cost_only_uses_the_sweep_kernel(backend):
+    """evaluate_pnp(out_cost=True) on plain tensors (one pose per object, or a (P,B,p) grid of poses as in the Det head's
+    orientation debug, deform_pnp_head.py:540-551) equals the PyTorch composite."""
+    from epropnp.common import evaluate_pnp
+    g = load_golden('eval4_clip')
+    p, cam, cf = make_layer_objects(g['prob'], backend)
+    poses = g['poses'].to(backend)                                   # (P,B,4)
+    with torch.no_grad():
+        fast = evaluate_pnp(p['x3d'], p['x2d'], p['w2d'], poses, cam, cf, out_cost=True)
+        one = evaluate_pnp(p['x3d'], p['x2d'], p['w2d'], g['pose'].to(backend), cam, cf, out_cost=True)
+    assert fast[0] is None and fast[2] is None
+    torch.testing.assert_close(fast[1].cpu(), g['costs'], rtol=2e-5, atol=1e-5)
+    torch.testing.assert_close(one[1].cpu(), g['cost'], rtol=2e-5, atol=1e-6)
+    # with autograd in play the composite path runs (and is differentiable)
+    x3d = p['x3d'].clone().requires_grad_(True)
+    if backend.type == 'cpu':
+        return          # the composite itself needs real tensors; on the emulation backend only the fast path exists
+    c = evaluate_pnp(x3d, p['x2d'], p['w2d'], g['pose'].to(backend), cam, cf, out_cost=True)[1]
+    c.sum().backward()
+    assert torch.isfinite(x3d.grad).all()
