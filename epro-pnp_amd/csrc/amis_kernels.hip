@@ -1,4 +1,7 @@
-// amis_kernels.hip -- the AMIS Monte-Carlo pose sampler (forward) and its gradient (backward) for gfx950.
+// amis_kernels.hip -- the AMIS Monte-Carlo pose sampler (forward) and its gradient (backward) for gfx950: the all-VALU
+// kernels plus the two launchers.  The default paths are the matrix-core variants (amis_forward_mfma.hip,
+// amis_backward_mfma.hip), which share the sampler stages of amis_common.h; the kernels in this file are selected with
+// EPROPNP_{FWD,BWD}_IMPL=valu and take over where the MFMA backward's LDS pose table does not fit (> ~2700 samples).
 //
 // Forward replaces the loop of EProPnPBase.monte_carlo_forward (epropnp/epropnp.py:132-182) with ONE kernel:
 // initial_fit (:216-220,:288-302), sampling from Student-t x {ACG | von-Mises/uniform mix}
