@@ -316,6 +316,17 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
   float* ptab = cx.ptab; float* smp = cx.smp;
   const int S = cx.S, K = cx.K, s = cx.s, T = cx.T, tid = cx.tid, b = cx.b;
   const float* rec = cx.prop + it * kPropStride;
+  // The pre-generated base noise may share LDS with the pose table this function fills (the two are never live at the
+  // same time except here): every lane takes its noise into registers before any lane writes a pose row.
+  const bool nz_aliased = (cx.nzb != nullptr) && (cx.nzb == cx.ptab);
+  float4 nz_a = make_float4(0.f, 0.f, 0.f, 0.f), nz_b = nz_a;
+  if (nz_aliased) {          // launcher guarantees s <= T in this mode: one sample per lane
+    if (tid < s) {
+      nz_a = reinterpret_cast<const float4*>(cx.nzb)[2 * tid];
+      nz_b = reinterpret_cast<const float4*>(cx.nzb)[2 * tid + 1];
+    }
+    __syncthreads();
+  }
   for (int n = tid; n < s; n += T) {
     const int m = it * s + n;
     float z[3], chi2, g[4];
@@ -326,7 +337,8 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
         g[0] = nz[4]; g[1] = nz[5]; g[2] = nz[6]; g[3] = nz[7];
       }
     } else if (cx.nzb != nullptr) {      // generated ahead of time by amis_base_noise
-      const float4 n0 = reinterpret_cast<const float4*>(cx.nzb)[2 * n], n1 = reinterpret_cast<const float4*>(cx.nzb)[2 * n + 1];
+      const float4 n0 = nz_aliased ? nz_a : reinterpret_cast<const float4*>(cx.nzb)[2 * n];
+      const float4 n1 = nz_aliased ? nz_b : reinterpret_cast<const float4*>(cx.nzb)[2 * n + 1];
       z[0] = n0.x; z[1] = n0.y; z[2] = n0.z; chi2 = n0.w;
       g[0] = n1.x; g[1] = n1.y; g[2] = n1.z; g[3] = n1.w;
     } else {

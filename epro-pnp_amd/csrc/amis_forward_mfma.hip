@@ -139,7 +139,8 @@ __global__ __launch_bounds__(512, ((NPT <= 8 && DOF == 6) ? PNP_FWD_MINW : 2)) v
   float* cpart = lgw + S;             // [WPs][s16]
   float* prop = cpart + WPs * s16;    // [K][kPropStride]
   float* red = prop + K * kPropStride;   // [256]
-  float* nzb = red + 256;                // [s][8]  (only when the draws come from Philox and W > 1)
+  float* nzb = (s <= T) ? ptab : red + 256;   // [s][8] base noise drawn ahead; shares the pose table's LDS when one
+                                              // sample per lane suffices (amis_draw separates the two uses)
 
   float Kc[9], delta;
   Bounds bd;
@@ -338,7 +339,8 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
   const size_t smem = sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (size_t)PL * S + 3 * (size_t)S +
-                                       (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256 + 8 * (size_t)s);
+                                       (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256 +
+                                       (s <= 64 * waves ? 0 : 8 * (size_t)s));
   if (smem > 160 * 1024) return fail(EPROPNP_EINVAL, "amis_forward: mc_samples %d needs %zu B of LDS (> 160 KiB)", S, smem);
   const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {

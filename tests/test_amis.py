@@ -181,6 +181,14 @@ def test_forward_kernel_variants_agree(backend, monkeypatch):
     s2, w2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     assert (s1 - s2).abs().max().item() < 5e-4
     assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3
+    # on-device Philox draws: the MFMA kernel pre-generates the base noise into LDS shared with its pose table, the VALU
+    # kernel draws inline -- same counters, same samples
+    monkeypatch.delenv('EPROPNP_FWD_IMPL')
+    p1, q1 = F.amis_forward(hp, pose_opt, pose_cov, S, K, seed=42, offset=7)
+    monkeypatch.setenv('EPROPNP_FWD_IMPL', 'valu')
+    p2, q2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, seed=42, offset=7)
+    assert (p1 - p2).abs().max().item() < 5e-4
+    assert (torch.logsumexp(q1, 0) - torch.logsumexp(q2, 0)).abs().max().item() < 1e-3
     # MFMA kernel, LDS-chunk mode (used for N > 2048), forced on this small problem with 2 waves
     monkeypatch.delenv('EPROPNP_FWD_IMPL')
     monkeypatch.setenv('EPROPNP_FWD_MFMA', '2,0')
