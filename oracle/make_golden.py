@@ -148,6 +148,10 @@ def main():
             with_pose_opt_plus=True, cam_kind='identity')
     case_mc('mc4_rslm', 4, 2, 48, 32, 4, 5, 35, rslm=dict(num_points=16, num_proposals=8, num_iter=3),
             with_pose_opt_plus=True, normalize=True, bounds='tensor')
+    case_mc('mc6_tight', 6, 3, 48, 64, 4, 3, 36, bounds='tight')
+    case_mc('mc6_k1', 6, 3, 40, 32, 1, 3, 38)
+    case_mc('mc4_det', 4, 2, 64, 32, 4, 5, 37, rslm=dict(num_points=16, num_proposals=64, num_iter=3), normalize=True,
+            bounds='tensor', with_pose_opt_plus=True)
     w = max(len(n) for n, *_ in REPORT)
     for n, k, d, tol in REPORT:
         print(f'{n:<{w}}  {k:<32} maxdiff {d:.3e}   tol {tol:.1e}')

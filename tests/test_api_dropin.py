@@ -70,7 +70,7 @@ def _demo_layer(g, dof, draws, normalize=False):
                solver=LMSolver(dof=dof, num_iter=int(g['lm_iter']), init_solver=init))
 
 
-@pytest.mark.parametrize('name', ['mc6_demo', 'mc4_rslm'])
+@pytest.mark.parametrize('name', ['mc6_demo', 'mc4_rslm', 'mc4_det'])
 def test_demo_config_with_rslm_and_pose_opt_plus(backend, name):
     """BASELINE config[0] (demo/fit_identity.ipynb shape): RSLM initialisation + LM + AMIS + derivative-regularisation
     output, force_init_solve=True, against the reference's outputs and input gradients."""

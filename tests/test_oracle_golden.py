@@ -36,7 +36,7 @@ def test_lm(name):
         assert torch.equal(torch.stack(hist).int(), g['accepts'].int())
 
 
-@pytest.mark.parametrize('name', ['mc6', 'mc4', 'mc4_norm', 'mc6_demo', 'mc4_rslm'])
+@pytest.mark.parametrize('name', ['mc6', 'mc4', 'mc4_norm', 'mc6_demo', 'mc4_rslm', 'mc6_tight', 'mc6_k1', 'mc4_det'])
 def test_monte_carlo(name):
     g = load_golden(name)
     dof, S, K = int(g['dof']), int(g['S']), int(g['K'])
