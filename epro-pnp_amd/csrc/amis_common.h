@@ -60,7 +60,7 @@ PNP_FIT_FN void fit_translation(double (&C)[3][3], const float* fallback_diag, f
   float sl = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    sl += logf((float)C[i][i]);
+    sl += fast_log((float)C[i][i]);
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
       rec[3 + tri(i, j)] = (float)C[i][j];
@@ -99,7 +99,7 @@ PNP_FIT_FN void fit_rotation_acg(double (&Rc)[4][4], float dispersion, float* re
   float sl = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    sl += logf((float)Rc[i][i]);
+    sl += fast_log((float)Rc[i][i]);
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
       rec[16 + tri(i, j)] = (float)Rc[i][j];
@@ -197,6 +197,17 @@ PNP_FN void sincos_half_pi(float u, float& s, float& c) {      // sin, cos of (p
 #endif
 }
 
+PNP_FN void sincos_rad(float x, float& s, float& c) {          // hardware sin / cos (argument in revolutions), |x| <~ 2 pi
+#ifndef EPROPNP_EMU
+  const float rev = x * 0.15915494309189535f;
+  s = __builtin_amdgcn_sinf(rev);
+  c = __builtin_amdgcn_cosf(rev);
+#else
+  s = sinf(x);
+  c = cosf(x);
+#endif
+}
+
 template <class Uniforms>
 PNP_FN float vm_sample_bounded(float loc, float kappa, Uniforms next) {
   const double k = fmax((double)kappa, 1e-12);
@@ -221,7 +232,7 @@ PNP_FN float vm_sample_bounded(float loc, float kappa, Uniforms next) {
     const float den = fmaf(2.0f * ch, ch, rm1f);          // r + z > 0
     const float c = kqf / den;
     const float m1 = c * (2.0f - c) - u2;
-    const float m2 = logf(c / fmaxf(u2, 1e-30f)) + 1.0f - c;
+    const float m2 = fast_log(c / fmaxf(u2, 1e-30f)) + 1.0f - c;      // margins within 1e-4 (1 + c) go to fp64 below
     const float tol = 1e-4f * (1.0f + c);
     bool acc = (m1 > 0.0f) || (m2 >= 0.0f);
     const bool clear = (u2 >= 1e-30f) && ((m1 > tol) || (m2 > tol) || ((m1 < -tol) && (m2 < -tol)));
@@ -349,7 +360,7 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
     }
     float ps[PL];
     // translation: mode + L_t (z * rsqrt(chi2 / 3))
-    const float sc = 1.0f / sqrtf(chi2 / 3.0f);
+    const float sc = fast_rsqrt(chi2 * (1.0f / 3.0f));
     const float y0 = z[0] * sc, y1 = z[1] * sc, y2 = z[2] * sc;
     ps[0] = rec[0] + rec[3] * y0;
     ps[1] = rec[1] + (rec[4] * y0 + rec[5] * y1);
@@ -362,11 +373,12 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
       const float v1 = rec[17] * g[0] + rec[18] * g[1];
       const float v2 = rec[19] * g[0] + rec[20] * g[1] + rec[21] * g[2];
       const float v3 = rec[22] * g[0] + rec[23] * g[1] + rec[24] * g[2] + rec[25] * g[3];
-      const float nr = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3);
-      if (nr < 1e-6f) {
+      const float n2 = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+      if (n2 < 1e-12f) {            // |L g| < 1e-6
         ps[3] = 1.f; ps[4] = 0.f; ps[5] = 0.f; ps[6] = 0.f;
       } else {
-        ps[3] = v0 / nr; ps[4] = v1 / nr; ps[5] = v2 / nr; ps[6] = v3 / nr;
+        const float inr = rsqrt_newton(n2);      // unit norm to ~1e-7
+        ps[3] = v0 * inr; ps[4] = v1 * inr; ps[5] = v2 * inr; ps[6] = v3 * inr;
       }
     } else {          // first round(0.25 s) samples uniform, the rest von Mises  (distributions.py:65-71)
       const int n_u = (int)rintf(0.25f * (float)s);
@@ -492,7 +504,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     else
 #endif
     for (int m = tid; m < M; m += T) {
-      const float e = expf(lgw[m] - mx);
+      const float e = fast_exp(lgw[m] - mx);
       const float d0 = smp[m] - p0, d1 = smp[S + m] - p1, d2 = smp[2 * S + m] - p2;
       mom[0] += e;
       mom[1] += e * d0; mom[2] += e * d1; mom[3] += e * d2;
@@ -548,7 +560,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
 #pragma unroll
       for (int i = 0; i < 11; ++i) acc[i] = 0.f;
       for (int m = tid; m < M; m += T) {
-        const float e = expf(lgw[m] - mx);
+        const float e = fast_exp(lgw[m] - mx);
         const float q0 = smp[3 * S + m], q1 = smp[4 * S + m], q2 = smp[5 * S + m], q3 = smp[6 * S + m];
         const float Mq = Si[0] * q0 * q0 + Si[2] * q1 * q1 + Si[5] * q2 * q2 + Si[9] * q3 * q3 +
                          2.f * (Si[1] * q1 * q0 + Si[3] * q2 * q0 + Si[4] * q2 * q1 + Si[6] * q3 * q0 + Si[7] * q3 * q1 +
@@ -595,15 +607,17 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) mom[i] = 0.f;
     for (int m = tid; m < M; m += T) {
-      const float e = expf(lgw[m] - mx);
+      const float e = fast_exp(lgw[m] - mx);
       const float d0 = smp[m] - p0, d1 = smp[S + m] - p1, d2 = smp[2 * S + m] - p2;
       mom[0] += e;
       mom[1] += e * d0; mom[2] += e * d1; mom[3] += e * d2;
       mom[4] += e * d0 * d0; mom[5] += e * d1 * d0; mom[6] += e * d1 * d1;
       mom[7] += e * d2 * d0; mom[8] += e * d2 * d1; mom[9] += e * d2 * d2;
       const float yaw = smp[3 * S + m];
-      mom[10] += e * sinf(yaw);
-      mom[11] += e * cosf(yaw);
+      float sy, cy;
+      sincos_rad(yaw, sy, cy);
+      mom[10] += e * sy;
+      mom[11] += e * cy;
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) mom[i] = wave_sum(mom[i]);

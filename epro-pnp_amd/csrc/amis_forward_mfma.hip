@@ -108,7 +108,7 @@ struct MfmaShape {
 #define PNP_FWD_MINW 4
 #endif
 template <int DOF, bool BOUNDS, int NPT>
-__global__ __launch_bounds__(512, ((NPT <= 8 && DOF == 6) ? PNP_FWD_MINW : 2)) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
+__global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
                                                                   const float* __restrict__ noise,
@@ -322,6 +322,8 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       if (w * o >= ptiles) break;
     }
   }
+  // 4-DoF with 16 resident tiles does not fit 256 VGPRs next to the von Mises sampler: stream the points through LDS
+  if (prob->dof == 4 && npt == 16) npt = 0;
   // few objects (less than two waves per SIMD otherwise): spread an object over 8 waves (B = 32: 86 vs 93 us)
   if (d.B < 512 && waves == 4 && npt == 8) { waves = 8; npt = 4; }
   { int ov[2]; if (env_ints("EPROPNP_FWD_MFMA", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 0 || ov[0] * ov[1] >= ptiles)) { waves = ov[0]; npt = ov[1]; } }
