@@ -70,7 +70,14 @@ PNP_FN void quat_to_rot(float w, float x, float y, float z, float (&R)[9]) {
 }
 
 PNP_FN void yaw_to_rot(float yaw, float (&R)[9]) {
+#ifndef EPROPNP_EMU
+  // hardware sin / cos (argument in revolutions, ~2^-21 absolute error: 3e-5 px at 800 px focal length) instead of the
+  // ~80-instruction libm pair; every kernel builds R through this function, so forward and backward stay consistent
+  const float rev = yaw * 0.15915494309189535f;
+  const float c = __builtin_amdgcn_cosf(rev), s = __builtin_amdgcn_sinf(rev);
+#else
   const float c = cosf(yaw), s = sinf(yaw);
+#endif
   R[0] = c;   R[1] = 0.f; R[2] = s;
   R[3] = 0.f; R[4] = 1.f; R[5] = 0.f;
   R[6] = -s;  R[7] = 0.f; R[8] = c;
