@@ -100,7 +100,7 @@ def cpu_baseline(N, S, K, L, sample_objects, budget_s=25.0):
     for threads in sorted({min(host_cores, t) for t in (8, 16, 32)}):
         torch.set_num_threads(threads)
         times = []
-        for it in range(3):
+        for it in range(6):
             t0 = time.perf_counter()
             orc.run_mc(prob, noise, 6, S, K, L)
             times.append(time.perf_counter() - t0)
@@ -115,7 +115,7 @@ def cpu_baseline(N, S, K, L, sample_objects, budget_s=25.0):
     return dict(value=round(sample_objects / best, 2), unit='instances/s', cores=best_threads, kind='port',
                 host_cores=host_cores, tried_threads_inst_per_s=tried,
                 sample=f'{sample_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd, oracle = PyTorch-CPU restatement '
-                       f'with the reference op structure), best of 2 after 1 warm-up per thread count')
+                       f'with the reference op structure), best of 5 after 1 warm-up per thread count; larger CPU batches are slower per object (256 objects: 100/s)')
 
 
 def hipgraph_replay():
