@@ -137,8 +137,8 @@ def hipgraph_replay():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--objects', type=int, default=4096, help='objects per GPU')
     ap.add_argument('--points', type=int, default=512)
     ap.add_argument('--samples', type=int, default=512)
