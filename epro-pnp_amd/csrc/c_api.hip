@@ -71,12 +71,23 @@ int epropnp_rslm_draw(const float* w2d, int32_t num_obj, int32_t num_pts, int32_
 }
 
 int epropnp_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, void* stream) {
-  return pnp::launch_gn_step_forward(prob, eps, pose, step, (hipStream_t)stream);
+  return pnp::launch_gn_step_forward(prob, eps, pose, step, nullptr, (hipStream_t)stream);
 }
 
 int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
                              float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream) {
-  return pnp::launch_gn_step_backward(prob, eps, pose, grad_step, grad_x3d, grad_x2d, grad_w2d, grad_delta,
+  return pnp::launch_gn_step_backward(prob, eps, pose, grad_step, nullptr, grad_x3d, grad_x2d, grad_w2d, grad_delta,
+                                      (hipStream_t)stream);
+}
+
+int epropnp_pose_opt_plus_forward(const epropnp_problem* prob, float eps, const float* pose, float* pose_plus,
+                                  void* stream) {
+  return pnp::launch_gn_step_forward(prob, eps, pose, nullptr, pose_plus, (hipStream_t)stream);
+}
+
+int epropnp_pose_opt_plus_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_pose_plus,
+                                   float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream) {
+  return pnp::launch_gn_step_backward(prob, eps, pose, nullptr, grad_pose_plus, grad_x3d, grad_x2d, grad_w2d, grad_delta,
                                       (hipStream_t)stream);
 }
 

@@ -129,7 +129,8 @@ constexpr int kGnMaxThreads = 512;
 
 template <int DOF, bool BOUNDS>
 __global__ __launch_bounds__(kGnMaxThreads) void gn_step_forward_kernel(Problem p, float eps, const float* __restrict__ pose,
-                                                                      float* __restrict__ step_out) {
+                                                                      float* __restrict__ step_out,
+                                                                      float* __restrict__ pose_plus_out) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
   __shared__ float scratch[NV * 16];
@@ -160,8 +161,19 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_forward_kernel(Problem 
   scaled_cholesky<DOF>(H, fac);
   scaled_solve<DOF>(fac, g);
   if (threadIdx.x == 0) {
+    float st[DOF];
 #pragma unroll
-    for (int i = 0; i < DOF; ++i) step_out[(size_t)b * DOF + i] = -g[i];
+    for (int i = 0; i < DOF; ++i) st[i] = -g[i];
+    if (step_out != nullptr) {
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) step_out[(size_t)b * DOF + i] = st[i];
+    }
+    if (pose_plus_out != nullptr) {        // pose_opt_plus = pose (+) step  (LMSolver.forward, :70-72)
+      float pp[PL];
+      pose_add<DOF>(ps, st, pp);
+#pragma unroll
+      for (int i = 0; i < PL; ++i) pose_plus_out[(size_t)b * PL + i] = pp[i];
+    }
   }
 }
 
@@ -169,6 +181,7 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_forward_kernel(Problem 
 template <int DOF, bool BOUNDS>
 __global__ __launch_bounds__(kGnMaxThreads) void gn_step_backward_kernel(Problem p, float eps, const float* __restrict__ pose,
                                                                        const float* __restrict__ gstep,
+                                                                       const float* __restrict__ gplus,
                                                                        float* __restrict__ gx3d, float* __restrict__ gx2d,
                                                                        float* __restrict__ gw2d, float* __restrict__ gdelta) {
   constexpr int PL = PoseLen<DOF>::value;
@@ -201,14 +214,20 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_backward_kernel(Problem
   unpack_sym<DOF>(acc, eps, H);
   scaled_cholesky<DOF>(H, fac);
 #pragma unroll
-  for (int i = 0; i < DOF; ++i) {
-    step[i] = acc[NH + i];
-    lam[i] = gstep[(size_t)b * DOF + i];
-  }
+  for (int i = 0; i < DOF; ++i) step[i] = acc[NH + i];
   scaled_solve<DOF>(fac, step);
-  scaled_solve<DOF>(fac, lam);
 #pragma unroll
   for (int i = 0; i < DOF; ++i) step[i] = -step[i];
+  if (gplus != nullptr) {      // upstream gradient arrives at pose_opt_plus: pull it back through pose_add first
+    float gp[PL];
+#pragma unroll
+    for (int i = 0; i < PL; ++i) gp[i] = gplus[(size_t)b * PL + i];
+    pose_add_adjoint<DOF>(ps, step, gp, lam);
+  } else {
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) lam[i] = gstep[(size_t)b * DOF + i];
+  }
+  scaled_solve<DOF>(fac, lam);
 
   // sweep 2: per-point backward
   float gd = 0.f;
@@ -315,29 +334,30 @@ static int gn_block_threads(int N) {
   return t;
 }
 
-int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, hipStream_t st) {
+int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, float* pose_plus,
+                           hipStream_t st) {
   if (int rc = check_problem(prob)) return rc;
   if (prob->num_obj == 0) return EPROPNP_OK;
-  if (!pose || !step) return fail(EPROPNP_EINVAL, "gn_step_forward: NULL pointer");
+  if (!pose || (!step && !pose_plus)) return fail(EPROPNP_EINVAL, "gn_step_forward: NULL pointer");
   const Problem d = to_device_problem(prob);
   const dim3 grid(padded_object_grid(d.B)), block(gn_block_threads(d.N));
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
-    PNP_LAUNCH((gn_step_forward_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, 0, st, d, eps, pose, step);
+    PNP_LAUNCH((gn_step_forward_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, 0, st, d, eps, pose, step, pose_plus);
     return 0;
   });
   return check_launch("gn_step_forward_kernel");
 }
 
 int launch_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
-                            float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st) {
+                            const float* grad_pose_plus, float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st) {
   if (int rc = check_problem(prob)) return rc;
   if (prob->num_obj == 0) return EPROPNP_OK;
-  if (!pose || !grad_step || !grad_x3d || !grad_x2d || !grad_w2d || !grad_delta)
+  if (!pose || (!grad_step && !grad_pose_plus) || !grad_x3d || !grad_x2d || !grad_w2d || !grad_delta)
     return fail(EPROPNP_EINVAL, "gn_step_backward: NULL pointer");
   const Problem d = to_device_problem(prob);
   const dim3 grid(padded_object_grid(d.B)), block(gn_block_threads(d.N));
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
-    PNP_LAUNCH((gn_step_backward_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, 0, st, d, eps, pose, grad_step, grad_x3d, grad_x2d, grad_w2d, grad_delta);
+    PNP_LAUNCH((gn_step_backward_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, 0, st, d, eps, pose, grad_step, grad_pose_plus, grad_x3d, grad_x2d, grad_w2d, grad_delta);
     return 0;
   });
   return check_launch("gn_step_backward_kernel");

@@ -98,9 +98,10 @@ int launch_prepare_forward(const float* noc, const float* dim, const float* logi
 int launch_prepare_backward(const float* noc, const float* dim, const float* logits, const float* scale, const float* stats,
                             const float* gx3d, const float* gw2d, int B, int N, int mode, float* gnoc, float* gdim,
                             float* glogits, float* gscale, hipStream_t st);
-int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, hipStream_t st);
+int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, float* pose_plus,
+                           hipStream_t st);
 int launch_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
-                            float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);
+                            const float* grad_pose_plus, float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);
 int launch_rslm_draw(const float* w2d, int B, int N, int P, int n_pts, unsigned long long seed, unsigned long long offset,
                      long long* inds, hipStream_t st);
 int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, float rel, float* delta, float* stats,

@@ -119,6 +119,31 @@ PNP_FN void pose_add(const float* pose, const float* step, float* out) {
   }
 }
 
+// adjoint of pose_add w.r.t. the step (the pose itself is not differentiated, as in the reference's use):
+//   6-DoF: u = q + T(q) d, q+ = u / |u|  =>  dL/du = (g_q - q+ (q+ . g_q)) / |u|,  dL/dd = T(q)^T dL/du
+template <int DOF>
+PNP_FN void pose_add_adjoint(const float* pose, const float* step, const float* g_out, float* g_step) {
+  g_step[0] = g_out[0]; g_step[1] = g_out[1]; g_step[2] = g_out[2];
+  if (DOF == 4) {
+    g_step[3] = g_out[3];
+  } else {
+    const float w = pose[3], i = pose[4], j = pose[5], k = pose[6];
+    const float a = step[3], b = step[4], c = step[5];
+    const float u0 = w + (i * a + j * b + k * c);
+    const float u1 = i + (-w * a - k * b + j * c);
+    const float u2 = j + (k * a - w * b - i * c);
+    const float u3 = k + (-j * a + i * b - w * c);
+    const float n = fmaxf(sqrtf(u0 * u0 + u1 * u1 + u2 * u2 + u3 * u3), 1e-12f), inv = 1.0f / n;
+    const float p0 = u0 * inv, p1 = u1 * inv, p2 = u2 * inv, p3 = u3 * inv;
+    const float dot = p0 * g_out[3] + p1 * g_out[4] + p2 * g_out[5] + p3 * g_out[6];
+    const float h0 = (g_out[3] - p0 * dot) * inv, h1 = (g_out[4] - p1 * dot) * inv;
+    const float h2 = (g_out[5] - p2 * dot) * inv, h3 = (g_out[6] - p3 * dot) * inv;
+    g_step[3] = i * h0 - w * h1 + k * h2 - j * h3;       // columns of T(q): [i,-w,k,-j], [j,-k,-w,i], [k,j,-i,-w]
+    g_step[4] = j * h0 - k * h1 - w * h2 + i * h3;
+    g_step[5] = k * h0 + j * h1 - i * h2 - w * h3;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // one 2D-3D correspondence, as kept in registers
 // ---------------------------------------------------------------------------------------------------

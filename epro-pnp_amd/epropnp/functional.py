@@ -349,3 +349,40 @@ class _GnStep(torch.autograd.Function):
 
 def gn_step(x3d, x2d, w2d, delta, prob, pose, eps):
     return _GnStep.apply(x3d, x2d, w2d, delta, prob, pose, eps)
+
+
+class _PoseOptPlus(torch.autograd.Function):
+    """pose_opt_plus = pose (+) gn_step(pose): the Gauss-Newton step and LMSolver.pose_add in one kernel each way
+    (reference: levenberg_marquardt.py:70-72 -> :243-265 + autograd)."""
+
+    @staticmethod
+    def forward(ctx, x3d, x2d, w2d, delta, prob, pose, eps):
+        ps = _f32c(pose, 'pose')
+        plus = prob.new(prob.B, prob.pose_len)
+        _hip.call('epropnp_pose_opt_plus_forward', C.byref(prob.c), float(eps), _hip.ptr(ps), _hip.ptr(plus), prob.stream)
+        ctx.set_materialize_grads(False)
+        ctx.prob, ctx.eps = prob, float(eps)
+        ctx.save_for_backward(ps)
+        ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
+        return plus
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 7
+        (ps,) = ctx.saved_tensors
+        prob = ctx.prob
+        B, N = prob.B, prob.N
+        g = g.contiguous()
+        gx3d, gx2d, gw2d, gdel = prob.new(B, N, 3), prob.new(B, N, 2), prob.new(B, N, 2), prob.new(B)
+        _hip.call('epropnp_pose_opt_plus_backward', C.byref(prob.c), ctx.eps, _hip.ptr(ps), _hip.ptr(g), _hip.ptr(gx3d),
+                  _hip.ptr(gx2d), _hip.ptr(gw2d), _hip.ptr(gdel), prob.stream)
+        gdelta = None
+        if ctx.delta_shape is not None and ctx.needs_input_grad[3]:
+            gdelta = gdel.sum() if len(ctx.delta_shape) == 0 else gdel.reshape(ctx.delta_shape)
+        return (gx3d if ctx.needs_input_grad[0] else None, gx2d if ctx.needs_input_grad[1] else None,
+                gw2d if ctx.needs_input_grad[2] else None, gdelta, None, None, None)
+
+
+def pose_opt_plus(x3d, x2d, w2d, delta, prob, pose, eps):
+    return _PoseOptPlus.apply(x3d, x2d, w2d, delta, prob, pose, eps)

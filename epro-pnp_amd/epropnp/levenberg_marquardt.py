@@ -51,7 +51,15 @@ class LMSolver(nn.Module):
         pose_opt, pose_cov, cost = self.solve(x3d, x2d, w2d, camera, cost_fun, pose_init=pose_init, **kwargs)
         pose_opt_plus = None
         if with_pose_opt_plus:
-            pose_opt_plus = self.pose_add(pose_opt, self.gn_step(x3d, x2d, w2d, pose_opt, camera, cost_fun), camera)
+            from . import _hip
+            if x2d.dim() == 3 and x2d.size(0) > 0 and not pose_opt.requires_grad and \
+                    _hip.on_hip_path(x3d, x2d, w2d, pose_opt):
+                # Gauss-Newton step + pose_add in one kernel each way (csrc/gn_step_kernel.hip)
+                prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+                delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
+                pose_opt_plus = hip.pose_opt_plus(x3d, x2d, w2d, delta, prob, pose_opt, self.eps)
+            else:
+                pose_opt_plus = self.pose_add(pose_opt, self.gn_step(x3d, x2d, w2d, pose_opt, camera, cost_fun), camera)
         if normalize:
             pose_opt = pnp_denormalize(transform, pose_opt)
             if pose_cov is not None:

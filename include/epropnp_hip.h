@@ -143,6 +143,15 @@ int epropnp_gn_step_forward(const epropnp_problem* prob, float eps, const float*
 int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
                              float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream);
 
+/* The same step composed with LMSolver.pose_add (levenberg_marquardt.py:70-72,255-265):
+ *   pose_plus = pose (+) gn_step(pose)   (B,pose_len)   -- `pose_opt_plus` of LMSolver.forward in one launch,
+ * and its backward from grad_pose_plus (B,pose_len) (the adjoint of pose_add is applied inside the kernel). */
+int epropnp_pose_opt_plus_forward(const epropnp_problem* prob, float eps, const float* pose, float* pose_plus,
+                                  void* stream);
+int epropnp_pose_opt_plus_backward(const epropnp_problem* prob, float eps, const float* pose,
+                                   const float* grad_pose_plus, float* grad_x3d, float* grad_x2d, float* grad_w2d,
+                                   float* grad_delta, void* stream);
+
 /* Sub-sample indices of the RSLM initialiser (epropnp/levenberg_marquardt.py:305-308): for each of the P x B
  * (proposal, object) rows draw n_pts distinct point indices with probability proportional to mean(w2d[b,n,:]),
  * sequentially without replacement (exponential-race keys -log(u)/w, the n_pts smallest win; same law as

@@ -67,7 +67,7 @@ def test_lmsolver_gn_step_uses_fused_kernel(backend):
     x3d, x2d, w2d = (d[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
     pose_opt, _, cost, plus = solver(x3d, x2d, w2d, cam, cf, with_pose_opt_plus=True, pose_init=d['pose_init'],
                                      with_cost=True)
-    assert plus.requires_grad and _graph_has(plus.grad_fn, 'GnStep')
+    assert plus.requires_grad and _graph_has(plus.grad_fn, 'PoseOptPlus')
     plus.square().sum().backward()
     cam64 = orc.Cam(p['cam_mats'].double(), 0.1)
     leaves = [p[k].double().clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d')]
@@ -78,3 +78,34 @@ def test_lmsolver_gn_step_uses_fused_kernel(backend):
     for got, want in zip((x3d, x2d, w2d), leaves):
         den = want.grad.abs().max()
         assert ((got.grad.cpu() - want.grad).abs() / den).max() < 5e-3
+
+
+@pytest.mark.parametrize('dof,bounds', [(6, None), (6, 'tight'), (4, 'tensor')])
+def test_pose_opt_plus_kernel_matches_step_then_pose_add(backend, dof, bounds):
+    """The fused pose_opt_plus (step + pose_add, adjoint of pose_add inside the backward kernel) against the two-stage
+    path: gn_step kernel followed by the PyTorch LMSolver.pose_add, values and input gradients."""
+    from epropnp import functional as F
+    from epropnp.levenberg_marquardt import LMSolver
+    B, N = 4, 80
+    p = orc.make_problem(B, N, dof=dof, seed=60 + dof, bounds=bounds)
+    d, cam, cf = make_layer_objects(p, backend)
+    g = torch.Generator().manual_seed(2)
+    up = torch.randn(B, 7 if dof == 6 else 4, generator=g).to(backend)
+    pose = d['pose_init']
+    solver = LMSolver(dof=dof, num_iter=1)
+    outs = []
+    for fused in (True, False):
+        leaves = {k: d[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta')}
+        cf.delta = leaves['delta']
+        prob = F.PnPProblem(leaves['x3d'], leaves['x2d'], leaves['w2d'], cam, cf, dof)
+        if fused:
+            plus = F.pose_opt_plus(leaves['x3d'], leaves['x2d'], leaves['w2d'], leaves['delta'], prob, pose, 1e-5)
+        else:
+            step = F.gn_step(leaves['x3d'], leaves['x2d'], leaves['w2d'], leaves['delta'], prob, pose, 1e-5)
+            plus = solver.pose_add(pose, step, cam)
+        (plus * up).sum().backward()
+        outs.append((plus.detach(), {k: v.grad for k, v in leaves.items()}))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+    for k in ('x3d', 'x2d', 'w2d', 'delta'):
+        a, b = outs[0][1][k], outs[1][1][k]
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max()))
