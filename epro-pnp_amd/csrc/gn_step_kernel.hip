@@ -125,7 +125,7 @@ PNP_FN void unpack_sym(const float (&acc)[NormalEq<DOF>::NV], float eps, float (
 // ------------------------------------------------------------------------------------------------------------
 // Workgroup = one object; lanes stride over its points (the sweeps are L2/HBM-bound and launch-latency-sized, so the
 // points are simply re-read for the second backward sweep instead of being pinned in registers).
-constexpr int kGnMaxThreads = 512;
+constexpr int kGnMaxThreads = 256;
 
 template <int DOF, bool BOUNDS>
 __global__ __launch_bounds__(kGnMaxThreads) void gn_step_forward_kernel(Problem p, float eps, const float* __restrict__ pose,
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_forward_kernel(Problem 
                                                                       float* __restrict__ pose_plus_out) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
-  __shared__ float scratch[NV * 16];
+  PNP_DYN_SMEM(float, scratch);          // waves * kSumTStride<NV> floats (transposed reduction, <= 4 waves)
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
   float K[9], R[9], ps[PL], delta;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_forward_kernel(Problem 
     point_forward<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, bd, f);
     accumulate_normal_eq<DOF>(f, acc);
   }
-  block_sum<NV>(acc, scratch);
+  block_sum_t<NV>(acc, scratch);
   float H[DOF][DOF], g[DOF];
   ScaledFactor<DOF> fac;
   unpack_sym<DOF>(acc, eps, H);
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_backward_kernel(Problem
                                                                        float* __restrict__ gw2d, float* __restrict__ gdelta) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
-  __shared__ float scratch[NV * 16];
+  PNP_DYN_SMEM(float, scratch);          // waves * kSumTStride<NV> floats
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_backward_kernel(Problem
     point_forward<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, bd, f);
     accumulate_normal_eq<DOF>(f, acc);
   }
-  block_sum<NV>(acc, scratch);
+  block_sum_t<NV>(acc, scratch);
   float H[DOF][DOF], step[DOF], lam[DOF];
   ScaledFactor<DOF> fac;
   unpack_sym<DOF>(acc, eps, H);
@@ -327,11 +327,12 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_backward_kernel(Problem
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// fewest waves that keep the strided loop short (<= 8 points per lane up to 4 waves): as in the LM kernel, more waves
+// per object only add reduction + barrier latency
 static int gn_block_threads(int N) {
-  int t = 64;
-  while (t < N && t < 256) t *= 2;   // 256 lanes cover N=512 in two strides; more lanes only add reduction cost
-  if (N >= 2048) t = kGnMaxThreads;
-  return t;
+  int w = 1;
+  while (w < 4 && 64 * 8 * w < N) w *= 2;
+  return 64 * w;
 }
 
 int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, float* pose_plus,
@@ -342,7 +343,8 @@ int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* 
   const Problem d = to_device_problem(prob);
   const dim3 grid(padded_object_grid(d.B)), block(gn_block_threads(d.N));
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
-    PNP_LAUNCH((gn_step_forward_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, 0, st, d, eps, pose, step, pose_plus);
+    PNP_LAUNCH((gn_step_forward_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block,
+               sizeof(float) * (block.x / 64) * kSumTStride<NormalEq<decltype(DOF)::value>::NV>, st, d, eps, pose, step, pose_plus);
     return 0;
   });
   return check_launch("gn_step_forward_kernel");
@@ -357,7 +359,8 @@ int launch_gn_step_backward(const epropnp_problem* prob, float eps, const float*
   const Problem d = to_device_problem(prob);
   const dim3 grid(padded_object_grid(d.B)), block(gn_block_threads(d.N));
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
-    PNP_LAUNCH((gn_step_backward_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, 0, st, d, eps, pose, grad_step, grad_pose_plus, grad_x3d, grad_x2d, grad_w2d, grad_delta);
+    PNP_LAUNCH((gn_step_backward_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block,
+               sizeof(float) * (block.x / 64) * kSumTStride<NormalEq<decltype(DOF)::value>::NV>, st, d, eps, pose, grad_step, grad_pose_plus, grad_x3d, grad_x2d, grad_w2d, grad_delta);
     return 0;
   });
   return check_launch("gn_step_backward_kernel");
