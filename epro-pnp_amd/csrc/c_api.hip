@@ -59,9 +59,10 @@ int epropnp_mc_loss_forward(const float* logweights, const float* cost_target, i
 }
 
 int epropnp_mc_loss_backward(const float* logweights, const float* lse, const float* loss, const float* grad_loss,
-                             int32_t mc_samples, int32_t num_obj, float* grad_logweights, void* stream) {
+                             int32_t mc_samples, int32_t num_obj, float* grad_logweights, float* grad_cost_target,
+                             void* stream) {
   return pnp::launch_mc_loss_backward(logweights, lse, loss, grad_loss, mc_samples, num_obj, grad_logweights,
-                                      (hipStream_t)stream);
+                                      grad_cost_target, (hipStream_t)stream);
 }
 
 int epropnp_rslm_draw(const float* w2d, int32_t num_obj, int32_t num_pts, int32_t num_proposals, int32_t n_pts,

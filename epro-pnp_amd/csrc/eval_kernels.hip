@@ -202,12 +202,13 @@ __global__ __launch_bounds__(512) void mc_loss_forward_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void mc_loss_backward_kernel(const float* __restrict__ logw, const float* __restrict__ lse,
                                                                 const float* __restrict__ g, int S, int B,
-                                                                float* __restrict__ glogw) {
+                                                                float* __restrict__ glogw, float* __restrict__ gct) {
   const size_t total = (size_t)S * B;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i % (size_t)B);
     const float l = lse[b];
     glogw[i] = (l != l) ? 0.f : g[b] * expf(logw[i] - l);
+    if (gct != nullptr && i < (size_t)B) gct[b] = (l != l) ? 0.f : g[b];      // the first B threads cover b = 0..B-1
   }
 }
 
@@ -508,7 +509,7 @@ int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, flo
 }
 
 int launch_mc_loss_backward(const float* logw, const float* lse, const float* loss, const float* g, int S, int B,
-                            float* glogw, hipStream_t st) {
+                            float* glogw, float* gct, hipStream_t st) {
   if (B <= 0) return EPROPNP_OK;
   if (!logw || !lse || !loss || !g || !glogw) return fail(EPROPNP_EINVAL, "mc_loss_backward: NULL pointer");
   (void)loss;
@@ -516,7 +517,7 @@ int launch_mc_loss_backward(const float* logw, const float* lse, const float* lo
     const size_t total = (size_t)S * B;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    PNP_LAUNCH(mc_loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logw, lse, g, S, B, glogw);
+    PNP_LAUNCH(mc_loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logw, lse, g, S, B, glogw, gct);
   }
   return check_launch("mc_loss_backward_kernel");
 }

@@ -108,7 +108,7 @@ int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, floa
                           hipStream_t st);
 int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, float* loss, float* lse, hipStream_t st);
 int launch_mc_loss_backward(const float* logw, const float* lse, const float* loss, const float* g, int S, int B,
-                            float* glogw, hipStream_t st);
+                            float* glogw, float* gct, hipStream_t st);
 int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
                     float* pose_cov, float* cost, int32_t* accept_mask, hipStream_t st);
 int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,

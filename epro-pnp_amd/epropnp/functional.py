@@ -238,9 +238,9 @@ class _McPoseLoss(torch.autograd.Function):
         S, B = lw.shape
         g = g.contiguous()
         glw = torch.empty_like(lw)
+        gct = torch.empty_like(g) if ctx.needs_input_grad[1] else None
         _hip.call('epropnp_mc_loss_backward', _hip.ptr(lw), _hip.ptr(lse), _hip.ptr(loss), _hip.ptr(g), S, B,
-                  _hip.ptr(glw), _hip.stream_of(lw))
-        gct = torch.where(torch.isnan(lse), torch.zeros_like(g), g) if ctx.needs_input_grad[1] else None
+                  _hip.ptr(glw), _hip.ptr(gct), _hip.stream_of(lw))
         return glw, gct
 
 

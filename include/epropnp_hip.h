@@ -131,9 +131,11 @@ int epropnp_adaptive_delta(const float* x2d, const float* w2d, int32_t num_obj, 
  * logweights (S,B), cost_target (B,) or NULL. */
 int epropnp_mc_loss_forward(const float* logweights, const float* cost_target, int32_t mc_samples, int32_t num_obj,
                             float* loss, float* lse, void* stream);
-/* grad_logweights[j,b] = grad_loss[b] * exp(logweights[j,b] - lse[b])   (0 where the loss was NaN) */
+/* grad_logweights[j,b] = grad_loss[b] * exp(logweights[j,b] - lse[b])   (0 where the loss was NaN);
+ * grad_cost_target (B,) or NULL: grad_loss[b] (0 where the loss was NaN). */
 int epropnp_mc_loss_backward(const float* logweights, const float* lse, const float* loss, const float* grad_loss,
-                             int32_t mc_samples, int32_t num_obj, float* grad_logweights, void* stream);
+                             int32_t mc_samples, int32_t num_obj, float* grad_logweights, float* grad_cost_target,
+                             void* stream);
 
 /* LMSolver.gn_step (epropnp/levenberg_marquardt.py:243-253), the differentiable Gauss-Newton step behind
  * `pose_opt_plus`:  step = -(J^T J + eps I)^-1 J^T r  at `pose` (clip_jac on).   pose (B,pose_len) -> step (B,dof). */
