@@ -19,7 +19,6 @@ structure, pinned to the reference) timed on a bounded sample of the same worklo
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
