@@ -4,7 +4,6 @@ import os
 import sys
 
 import pytest
-import torch
 
 pytestmark = pytest.mark.gpu
 
