@@ -81,6 +81,12 @@ int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float
                                       (hipStream_t)stream);
 }
 
+int epropnp_shift_poses_backward(const float* pose, const float* offset, const float* grad_out, int32_t num_poses,
+                                 int32_t num_obj, int32_t dof, float sign, float* grad_pose, void* stream) {
+  return pnp::launch_shift_poses_backward(pose, offset, grad_out, num_poses, num_obj, dof, sign, grad_pose,
+                                          (hipStream_t)stream);
+}
+
 int epropnp_pose_opt_plus_forward(const epropnp_problem* prob, float eps, const float* pose, float* pose_plus,
                                   void* stream) {
   return pnp::launch_gn_step_forward(prob, eps, pose, nullptr, pose_plus, (hipStream_t)stream);

@@ -310,6 +310,57 @@ __global__ __launch_bounds__(256) void shift_poses_kernel(const float* __restric
   }
 }
 
+// backward of shift_poses w.r.t. the pose (the offset is a detached constant, as in pnp_normalize):
+//   out_t = t + sign * R(rot) o   =>   g_t passes through;  g_rot += sign * d(R o)/d(rot)^T g_t
+//   6-DoF, R o = (w^2 - v.v) o + 2 v (v.o) + 2 w (v x o)  (common.py:21-42, q not normalised):
+//     d/dw = 2 w o + 2 v x o,   grad_v = -2 (g.o) v + 2 (v.o) g + 2 (g.v) o + 2 w (o x g)
+//   4-DoF, R = Ry(yaw):  d(R o)/dyaw = (-s ox + c oz, 0, -c ox - s oz)
+template <int DOF>
+__global__ __launch_bounds__(256) void shift_poses_backward_kernel(const float* __restrict__ pose, const float* __restrict__ offset,
+                                                                    const float* __restrict__ gout, int P, int B, float sign,
+                                                                    float* __restrict__ gpose) {
+  constexpr int PL = PoseLen<DOF>::value;
+  const size_t total = (size_t)P * B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % (size_t)B);
+    float ps[PL], go[PL];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) { ps[k] = pose[i * PL + k]; go[k] = gout[i * PL + k]; }
+    const float ox = offset[(size_t)b * 3], oy = offset[(size_t)b * 3 + 1], oz = offset[(size_t)b * 3 + 2];
+    const float gx = sign * go[0], gy = sign * go[1], gz = sign * go[2];
+    float gp[PL];
+    gp[0] = go[0]; gp[1] = go[1]; gp[2] = go[2];
+    if (DOF == 4) {
+      const float c = cosf(ps[3]), s = sinf(ps[3]);
+      gp[3] = go[3] + gx * (-s * ox + c * oz) + gz * (-c * ox - s * oz);
+    } else {
+      const float w = ps[3], vx = ps[4], vy = ps[5], vz = ps[6];
+      const float cx = vy * oz - vz * oy, cy = vz * ox - vx * oz, cz = vx * oy - vy * ox;      // v x o
+      const float g_o = gx * ox + gy * oy + gz * oz, v_o = vx * ox + vy * oy + vz * oz, g_v = gx * vx + gy * vy + gz * vz;
+      const float ogx = oy * gz - oz * gy, ogy = oz * gx - ox * gz, ogz = ox * gy - oy * gx;   // o x g
+      gp[3] = go[3] + 2.f * (w * g_o + (gx * cx + gy * cy + gz * cz));
+      gp[4] = go[4] + 2.f * (-g_o * vx + v_o * gx + g_v * ox + w * ogx);
+      gp[5] = go[5] + 2.f * (-g_o * vy + v_o * gy + g_v * oy + w * ogy);
+      gp[6] = go[6] + 2.f * (-g_o * vz + v_o * gz + g_v * oz + w * ogz);
+    }
+#pragma unroll
+    for (int k = 0; k < PL; ++k) gpose[i * PL + k] = gp[k];
+  }
+}
+
+int launch_shift_poses_backward(const float* pose, const float* offset, const float* gout, int P, int B, int dof, float sign,
+                                float* gpose, hipStream_t st) {
+  if (B <= 0 || P <= 0) return EPROPNP_OK;
+  if (!pose || !offset || !gout || !gpose || (dof != 4 && dof != 6))
+    return fail(EPROPNP_EINVAL, "shift_poses_backward: bad argument");
+  const size_t total = (size_t)P * B;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dof == 6) PNP_LAUNCH(shift_poses_backward_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, pose, offset, gout, P, B, sign, gpose);
+  else PNP_LAUNCH(shift_poses_backward_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, pose, offset, gout, P, B, sign, gpose);
+  return check_launch("shift_poses_backward_kernel");
+}
+
 int launch_center_points(const float* x3d, int B, int N, float* offset, float* out, hipStream_t st) {
   if (B <= 0) return EPROPNP_OK;
   if (!x3d || !offset || !out || N < 1) return fail(EPROPNP_EINVAL, "center_points: bad argument");

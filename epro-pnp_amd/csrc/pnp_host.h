@@ -98,6 +98,8 @@ int launch_prepare_forward(const float* noc, const float* dim, const float* logi
 int launch_prepare_backward(const float* noc, const float* dim, const float* logits, const float* scale, const float* stats,
                             const float* gx3d, const float* gw2d, int B, int N, int mode, float* gnoc, float* gdim,
                             float* glogits, float* gscale, hipStream_t st);
+int launch_shift_poses_backward(const float* pose, const float* offset, const float* gout, int P, int B, int dof, float sign,
+                                float* gpose, hipStream_t st);
 int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, float* pose_plus,
                            hipStream_t st);
 int launch_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,

@@ -104,8 +104,9 @@ def _fused(*tensors):
 
 
 def _can_shift(pose, offset):
-    """The fused pose shift has no autograd: use it for plain tensors of shape (...,B,pose_len) with offset (B,3)."""
-    return (not pose.requires_grad and not offset.requires_grad and offset.dim() == 2 and pose.dim() >= 2
+    """The fused pose shift (differentiable w.r.t. the pose, offset constant): tensors of shape (...,B,pose_len) with
+    offset (B,3)."""
+    return (not offset.requires_grad and offset.dim() == 2 and pose.dim() >= 2
             and pose.size(-2) == offset.size(0) and pose.numel() > 0 and _fused(pose, offset))
 
 

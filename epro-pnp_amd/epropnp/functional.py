@@ -280,8 +280,38 @@ def center_points(x3d):
     return _CenterPoints.apply(x3d)
 
 
+class _ShiftPoses(torch.autograd.Function):
+    """pose translation += sign * R(pose) offset, differentiable w.r.t. the pose (offset is a constant)."""
+
+    @staticmethod
+    def forward(ctx, pose, offset, sign):
+        ps, off = _f32c(pose.detach(), 'pose'), _f32c(offset.detach(), 'offset')
+        B, pl = ps.shape[-2], ps.shape[-1]
+        out = torch.empty_like(ps)
+        _hip.call('epropnp_shift_poses', _hip.ptr(ps), _hip.ptr(off), ps.numel() // (B * pl), B, 6 if pl == 7 else 4,
+                  float(sign), _hip.ptr(out), _hip.stream_of(ps))
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(ps, off)
+        ctx.sign = float(sign)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        ps, off = ctx.saved_tensors
+        B, pl = ps.shape[-2], ps.shape[-1]
+        g = g.contiguous()
+        gp = torch.empty_like(ps)
+        _hip.call('epropnp_shift_poses_backward', _hip.ptr(ps), _hip.ptr(off), _hip.ptr(g), ps.numel() // (B * pl), B,
+                  6 if pl == 7 else 4, ctx.sign, _hip.ptr(gp), _hip.stream_of(ps))
+        return gp, None, None
+
+
 def shift_poses(pose, offset, sign):
-    """pose (...,B,pose_len) translation += sign * R(pose) offset (B,3); no autograd."""
+    """pose (...,B,pose_len) translation += sign * R(pose) offset (B,3); differentiable w.r.t. the pose."""
+    if pose.requires_grad and torch.is_grad_enabled():
+        return _ShiftPoses.apply(pose, offset, sign)
     ps, off = _f32c(pose.detach(), 'pose'), _f32c(offset.detach(), 'offset')
     B, pl = ps.shape[-2], ps.shape[-1]
     out = torch.empty_like(ps)

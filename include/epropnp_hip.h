@@ -189,6 +189,11 @@ int epropnp_prepare_backward(const float* noc, const float* dim, const float* lo
                              int32_t num_pts, int32_t mode, float* grad_noc, float* grad_dim, float* grad_logits,
                              float* grad_scale, void* stream);
 
+/* Backward of epropnp_shift_poses w.r.t. the pose (the offset is a constant, pnp_normalize detaches it):
+ * grad_out (P,B,pose_len) -> grad_pose (P,B,pose_len). */
+int epropnp_shift_poses_backward(const float* pose, const float* offset, const float* grad_out, int32_t num_poses,
+                                 int32_t num_obj, int32_t dof, float sign, float* grad_pose, void* stream);
+
 /* RSLMSolver.solve (epropnp/levenberg_marquardt.py:283-353) in one launch: center_based_init, weighted sub-sampling
  * of `num_points` (<= 16) correspondences per proposal, random initial rotations, `num_proposals` LM/GN solves per
  * object on the sub-samples (parameters `lm`, as LMSolver.solve), full-set cost of every proposal, argmin.

@@ -53,3 +53,26 @@ def test_normalize_kernels_match_composite(backend, dof):
     back = pnp_denormalize(offset, samples)
     torch.testing.assert_close(back, pose.unsqueeze(0).expand(S, -1, -1), rtol=1e-5, atol=1e-5)
     assert F.shift_poses(samples, offset, -1.0).shape == samples.shape
+
+
+@pytest.mark.parametrize('dof', [4, 6])
+def test_shift_poses_is_differentiable_in_the_pose(backend, dof):
+    """pnp_denormalize of a pose that carries autograd (pose_opt_plus under normalize=True) runs the fused kernel pair;
+    values and pose gradients equal the PyTorch definition (reference: epropnp/common.py:127-136)."""
+    from epropnp.common import pnp_denormalize, rotate_offset
+    g = torch.Generator().manual_seed(dof)
+    B = 6
+    pose = torch.randn(B, 7 if dof == 6 else 4, generator=g)
+    if dof == 6:
+        pose[:, 3:] = torch.nn.functional.normalize(pose[:, 3:], dim=-1) * 1.01      # R(q) is not normalised: keep |q| != 1
+    offset = torch.randn(B, 3, generator=g)
+    up = torch.randn(B, pose.shape[-1], generator=g)
+    a = pose.clone().to(backend).requires_grad_(True)
+    out = pnp_denormalize(offset.to(backend), a)
+    assert 'ShiftPoses' in type(out.grad_fn).__name__
+    (out * up.to(backend)).sum().backward()
+    b = pose.clone().double().requires_grad_(True)
+    ref = torch.cat((b[..., :3] - rotate_offset(b, offset.double()), b[..., 3:]), dim=-1)
+    (ref * up.double()).sum().backward()
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=1e-5, atol=1e-6)

@@ -44,10 +44,15 @@ def build(name, dev):
     layer.enable_graph_safe_rng(dev)
     out = {}
 
+    plus = os.environ.get('GRAPH_STEP_PLUS', '0') == '1'      # derivative regularisation through pose_opt_plus as well
+
     def step():
         cf.set_param(leaves[1].detach(), leaves[2])
-        o = layer.monte_carlo_forward(*leaves, cam, cf, pose_init=p['pose_init'], force_init_solve=force)
+        o = layer.monte_carlo_forward(*leaves, cam, cf, pose_init=p['pose_init'], force_init_solve=force,
+                                      with_pose_opt_plus=plus)
         loss = monte_carlo_pose_loss(o[4], o[5]).mean()
+        if plus:
+            loss = loss + 0.1 * (o[2][:, :3] - p['pose_init'][:, :3]).norm(dim=-1).mean()
         loss.backward()
         out['loss'], out['samples'] = loss.detach(), o[3]
     return B, leaves, step, out, layer

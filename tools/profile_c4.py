@@ -20,8 +20,13 @@ for it in range(8):
     for tt in (x3d, x2d, w2d):
         tt.grad = None
     cf4.set_param(x2d.detach(), w2d)
-    o = layer4.monte_carlo_forward(x3d, x2d, w2d, cam, cf4, pose_init=p['pose_init'], force_init_solve=True)
-    monte_carlo_pose_loss(o[4], o[5]).mean().backward()
+    plus = os.environ.get('C4_PLUS', '0') == '1'
+    o = layer4.monte_carlo_forward(x3d, x2d, w2d, cam, cf4, pose_init=p['pose_init'], force_init_solve=True,
+                                   with_pose_opt_plus=plus)
+    loss = monte_carlo_pose_loss(o[4], o[5]).mean()
+    if plus:
+        loss = loss + 0.1 * (o[2][:, :3] - p['pose_init'][:, :3]).norm(dim=-1).mean()
+    loss.backward()
 torch.cuda.synchronize()
 try:      # tuning builds (build.py -D PNP_TUNING, EPROPNP_LIB=...): per-phase cycle shares of the forward kernel
     import ctypes
