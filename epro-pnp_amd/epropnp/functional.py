@@ -35,15 +35,28 @@ class PnPProblem:
         eps = getattr(cost_fun, 'eps', 1e-10)
         if abs(eps - 1e-10) > 1e-16:
             raise NotImplementedError('HuberPnPCost.eps other than 1e-10 is not supported by the HIP kernels')
-        cam = camera.cam_mats
-        self.cam = _f32c(cam.to(dev).expand(B, 3, 3), 'cam_mats')
         self.z_min = float(camera.z_min)
-        lb, ub = camera.lb, camera.ub
-        if lb is not None and ub is not None:
-            self.lb = self._bound(lb, B, dev)
-            self.ub = self._bound(ub, B, dev)
-        else:
-            self.lb = self.ub = None
+        # contiguous (B,3,3) intrinsics and (B,2) bounds: callers pass an expanded view of one matrix / plain floats, and
+        # a step builds several PnPProblems from the same camera object -- materialise them once per camera state
+        srcs = (camera.cam_mats, camera.lb, camera.ub)
+        vers = tuple(v._version if isinstance(v, torch.Tensor) else None for v in srcs)
+        cached = getattr(camera, '_hip_views', None)
+        # hit = the very same source objects (held alive by the cache, so their storage cannot be recycled), unmodified
+        hit = (cached is not None and cached[0] == (B, dev) and cached[2] == vers
+               and all((a is b) or (not isinstance(a, torch.Tensor) and a == b) for a, b in zip(cached[1], srcs)))
+        if not hit:
+            cam_c = _f32c(camera.cam_mats.to(dev).expand(B, 3, 3), 'cam_mats')
+            lb, ub = camera.lb, camera.ub
+            if lb is not None and ub is not None:
+                lb_c, ub_c = self._bound(lb, B, dev), self._bound(ub, B, dev)
+            else:
+                lb_c = ub_c = None
+            cached = ((B, dev), srcs, vers, (cam_c, lb_c, ub_c))
+            try:
+                camera._hip_views = cached
+            except AttributeError:      # objects without a __dict__: just do not cache
+                pass
+        self.cam, self.lb, self.ub = cached[3]
         delta = cost_fun.delta
         if not isinstance(delta, torch.Tensor):
             delta = torch.full((B,), float(delta), dtype=torch.float32, device=dev)

@@ -281,3 +281,33 @@ def test_evaluate_pnp_cost_only_uses_the_sweep_kernel(backend):
     c = evaluate_pnp(x3d, p['x2d'], p['w2d'], g['pose'].to(backend), cam, cf, out_cost=True)[1]
     c.sum().backward()
     assert torch.isfinite(x3d.grad).all()
+
+
+def test_camera_view_cache_tracks_the_camera_state(backend):
+    """PnPProblem materialises contiguous intrinsics / bounds once per camera state: replacing or modifying the
+    camera's tensors must be seen by the next call."""
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    p = orc.make_problem(3, 40, 6, seed=1)
+    d, cam, cf = make_layer_objects(p, backend)
+    pose = d['pose_init']
+
+    def cost():
+        return F.evaluate_cost(F.PnPProblem(d['x3d'], d['x2d'], d['w2d'], cam, cf, 6), pose).clone()
+    c0 = cost()
+    torch.testing.assert_close(cost(), c0, rtol=0, atol=0)                     # cached views, same result
+    k2 = d['cam_mats'].clone()
+    k2[:, 0, 0] *= 1.1
+    cam.set_param(k2)                                                          # new tensor object
+    c1 = cost()
+    assert (c1 - c0).abs().max() > 1e-3
+    with torch.no_grad():
+        cam.cam_mats[:, 1, 1] *= 0.9                                           # in-place edit of the same object
+    assert (cost() - c1).abs().max() > 1e-3
+    cam.set_param(d['cam_mats'][:1].expand(3, 3, 3))                           # expanded view of one matrix
+    torch.testing.assert_close(cost(), c0, rtol=1e-6, atol=1e-6)
+    cam2 = PerspectiveCamera(cam_mats=d['cam_mats'], lb=-50.0, ub=700.0)       # float bounds
+    c_b = F.evaluate_cost(F.PnPProblem(d['x3d'], d['x2d'], d['w2d'], cam2, cf, 6), pose)
+    cam2.ub = 300.0
+    c_b2 = F.evaluate_cost(F.PnPProblem(d['x3d'], d['x2d'], d['w2d'], cam2, cf, 6), pose)
+    assert torch.isfinite(c_b).all() and (c_b2 - c_b).abs().max() > 0
