@@ -63,3 +63,17 @@ def test_product_path_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match='HIP device'):
         LMSolver(dof=6, num_iter=1).solve(z(2, 8, 3), z(2, 8, 2), z(2, 8, 2), PerspectiveCamera(cam_mats=torch.eye(3).expand(2, 3, 3)),
                                           HuberPnPCost(), pose_init=z(2, 7))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/epropnp_hip.h is the drop-in boundary: it must compile as C99 (and C++) with nothing but <stdint.h>."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 'abi.c'
+    src.write_text('#include "epropnp_hip.h"\nint main(void) { return epropnp_abi_version() == EPROPNP_ABI_VERSION ? 0 : 1; }\n')
+    for cmd in (['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror'], ['g++', '-std=c++11', '-Wall', '-Werror', '-x', 'c++']):
+        r = subprocess.run(cmd + ['-I', os.path.join(root, 'include'), '-fsyntax-only', str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
