@@ -77,3 +77,25 @@ def test_header_is_plain_c(tmp_path):
     for cmd in (['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror'], ['g++', '-std=c++11', '-Wall', '-Werror', '-x', 'c++']):
         r = subprocess.run(cmd + ['-I', os.path.join(root, 'include'), '-fsyntax-only', str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_c_program_links_and_runs(tmp_path, lib):
+    """A C caller: include the header, link -lepropnp_hip, call the two entry points that need no device."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, 'epro-pnp_amd', 'lib')
+    src = tmp_path / 'caller.c'
+    src.write_text('#include <stdio.h>\n#include "epropnp_hip.h"\n'
+                   'int main(void) { printf("%d %d %d\\n", epropnp_abi_version(), epropnp_noise_stride(6), epropnp_noise_stride(4));'
+                   ' return 0; }\n')
+    exe = tmp_path / 'caller'
+    r = subprocess.run(['gcc', '-std=c99', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe), '-L', libdir,
+                        '-lepropnp_hip', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-L', '/opt/rocm/lib'],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['2', '8', '52']
