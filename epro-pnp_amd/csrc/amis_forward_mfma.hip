@@ -69,9 +69,12 @@ __device__ __forceinline__ float clamp_below(float x, float lo) {
 }
 
 // Huber costs of the 4 poses a lane holds for one point (MFMA outputs hx, hy, hz) added to acc2 = {poses 0,1}, {2,3}
-template <bool BOUNDS>
+// FOLDED: hx, hy are the MFMA results against the point's B operand pre-scaled by wu / wv (register mode without a
+// projection clamp), so the residual is ONE fma per coordinate: r = (wu h_x) / z - u wu.
+template <bool BOUNDS, bool FOLDED = false>
 __device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& hy, const floatx4& hz, const float4& w4,
                                              float zmin_v, float delta_v, const Bounds& bd, f32x2 (&acc2)[2]) {
+  static_assert(!(BOUNDS && FOLDED), "the clamp acts on the un-weighted projection");
   const f32x2 wu2 = {w4.x, w4.x}, wv2 = {w4.y, w4.y}, cu2 = {w4.z, w4.z}, cv2 = {w4.w, w4.w};
   const f32x2 mhalf = {-0.5f, -0.5f};
 #pragma unroll
@@ -81,12 +84,19 @@ __device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& h
     const float z0 = clamp_below(hz[2 * h], zmin_v), z1 = clamp_below(hz[2 * h + 1], zmin_v);
     const f32x2 rz2 = {fast_rcp(z0), fast_rcp(z1)};
     const f32x2 hx2 = {hx[2 * h], hx[2 * h + 1]}, hy2 = {hy[2 * h], hy[2 * h + 1]};
-    f32x2 px2 = hx2 * rz2, py2 = hy2 * rz2;
-    if (BOUNDS) {
-      px2 = f32x2{fminf(fmaxf(px2[0], bd.lbx), bd.ubx), fminf(fmaxf(px2[1], bd.lbx), bd.ubx)};
-      py2 = f32x2{fminf(fmaxf(py2[0], bd.lby), bd.uby), fminf(fmaxf(py2[1], bd.lby), bd.uby)};
+    f32x2 rx2, ry2;
+    if (FOLDED) {
+      rx2 = fma2(hx2, rz2, cu2);
+      ry2 = fma2(hy2, rz2, cv2);
+    } else {
+      f32x2 px2 = hx2 * rz2, py2 = hy2 * rz2;
+      if (BOUNDS) {
+        px2 = f32x2{fminf(fmaxf(px2[0], bd.lbx), bd.ubx), fminf(fmaxf(px2[1], bd.lbx), bd.ubx)};
+        py2 = f32x2{fminf(fmaxf(py2[0], bd.lby), bd.uby), fminf(fmaxf(py2[1], bd.lby), bd.uby)};
+      }
+      rx2 = fma2(px2, wu2, cu2);
+      ry2 = fma2(py2, wv2, cv2);
     }
-    const f32x2 rx2 = fma2(px2, wu2, cu2), ry2 = fma2(py2, wv2, cv2);
     const f32x2 s2 = fma2(rx2, rx2, ry2 * ry2);
     const f32x2 rho2 = {fast_sqrt(s2[0]), fast_sqrt(s2[1])};
     const f32x2 m2 = {fminf(rho2[0], delta_v), fminf(rho2[1], delta_v)};
@@ -128,6 +138,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
 #endif
   PNP_DYN_SMEM(float, smem);
   constexpr bool kRegs = NPT > 0;
+  constexpr bool kFold = kRegs && !BOUNDS;
   const int WPs = kRegs ? W : 1;      // point slices whose partial costs are summed in amis_weights
   float* ptab = smem;                 // [s16][12]   x | y | z rows of (K R | K t)          (16-B aligned)
   float* pB = ptab + 12 * s16;        // [NC][4]     (X, Y, Z, 1)        (NC = 0 in register mode)
@@ -172,7 +183,9 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
       const Point q = load_point(p, b, (wv + W * i) * 16 + (lane & 15));      // zero weight beyond N
       const int k4 = lane >> 4;
       rB[i] = (k4 == 0) ? q.X : (k4 == 1) ? q.Y : (k4 == 2) ? q.Z : 1.0f;
-      rW[i] = make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
+      // without a projection clamp the weights are folded into the B operands of the x and y rows (same 5 VGPRs)
+      rW[i] = kFold ? make_float4(rB[i] * q.wu, rB[i] * q.wv, -q.u * q.wu, -q.v * q.wv)
+                    : make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
     }
   } else if (nchunk == 1) {
     load_chunk(0);
@@ -201,10 +214,10 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
         f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
         for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
-          const floatx4 hx = mfma_16x16x4(ax, rB[i], zero);
-          const floatx4 hy = mfma_16x16x4(ay, rB[i], zero);
+          const floatx4 hx = mfma_16x16x4(ax, kFold ? rW[i].x : rB[i], zero);
+          const floatx4 hy = mfma_16x16x4(ay, kFold ? rW[i].y : rB[i], zero);
           const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
-          huber_cost_4<BOUNDS>(hx, hy, hz, rW[i], zmin_v, delta_v, bd, acc2);
+          huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, delta_v, bd, acc2);
         }
         float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
 #pragma unroll

@@ -11,15 +11,23 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define X4(S) S S S S
 #define X8(S) S S S S S S S S
 
-template <bool VALU, bool MFMA, bool PACKED>
+template <bool VALU, int MFMA, bool PACKED>
 __global__ void k(float* out, int iters, float a, float b) {
   float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
   f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, p4 = {x1, x0}, p5 = {x3, x2}, p6 = {x5, x4}, p7 = {x7, x6};
   const f2 A = {a, a}, Bv = {b, b};
   f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0;
   float ma = a * threadIdx.x, mb = b;
+  const f4 wa = {ma, mb, ma, mb}, wb = {mb, ma, mb, ma};
+  const f2 ha = {ma, mb}, hb = {mb, ma};
   for (int i = 0; i < iters; ++i) {
-    if (MFMA)
+    if (MFMA == 2)      // gfx950 bf16 MFMA, K = 32: A and B are 8 bf16 (4 VGPRs) per lane
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n v_mfma_f32_16x16x32_bf16 %1, %3, %4, %1\n v_mfma_f32_16x16x32_bf16 %2, %3, %4, %2\n"
+                   : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(wa), "v"(wb));
+    if (MFMA == 3)      // bf16 MFMA, K = 16: 4 bf16 (2 VGPRs) per lane
+      asm volatile("v_mfma_f32_16x16x16_bf16 %0, %3, %4, %0\n v_mfma_f32_16x16x16_bf16 %1, %3, %4, %1\n v_mfma_f32_16x16x16_bf16 %2, %3, %4, %2\n"
+                   : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(ha), "v"(hb));
+    if (MFMA == 1)
       asm volatile("v_mfma_f32_16x16x4_f32 %0, %3, %4, %0\n v_mfma_f32_16x16x4_f32 %1, %3, %4, %1\n v_mfma_f32_16x16x4_f32 %2, %3, %4, %2\n"
                    : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(ma), "v"(mb));
     if (VALU && PACKED)
@@ -35,7 +43,7 @@ __global__ void k(float* out, int iters, float a, float b) {
                                                p7.y + c0.x + c1.y + c2.z;
 }
 
-template <bool VALU, bool MFMA, bool PACKED>
+template <bool VALU, int MFMA, bool PACKED>
 double run(int waves_per_simd) {
   float* out;
   const int blocks = 256 * waves_per_simd, threads = 256, iters = 4000;
@@ -53,12 +61,19 @@ double run(int waves_per_simd) {
 }
 
 int main() {
-  printf("ns per (3 MFMA 16x16x4 f32 + VALU block) per SIMD; 'sum' = no overlap, 'max' = perfect overlap\n");
+  printf("ns per (3 MFMA + VALU block) per SIMD; 'sum' = no overlap, 'max' = perfect overlap\n");
+  const char* names[4] = {"", "f32 16x16x4", "bf16 16x16x32", "bf16 16x16x16"};
   for (int w : {1, 2, 4}) {
-    const double v = run<true, false, true>(w), m = run<false, true, true>(w), both = run<true, true, true>(w);
-    const double vs = run<true, false, false>(w), boths = run<true, true, false>(w);
-    printf("w/SIMD=%d  32 v_pk_fma: valu %6.1f  mfma %6.1f  both %6.1f  (sum %6.1f, max %6.1f)\n", w, v, m, both, v + m, v > m ? v : m);
-    printf("w/SIMD=%d  64 v_fma   : valu %6.1f  mfma %6.1f  both %6.1f  (sum %6.1f, max %6.1f)\n", w, vs, m, boths, vs + m, vs > m ? vs : m);
+    const double v = run<true, 0, true>(w), vs = run<true, 0, false>(w);
+    const double m[4] = {0, run<false, 1, true>(w), run<false, 2, true>(w), run<false, 3, true>(w)};
+    const double both[4] = {0, run<true, 1, true>(w), run<true, 2, true>(w), run<true, 3, true>(w)};
+    const double boths[4] = {0, run<true, 1, false>(w), run<true, 2, false>(w), run<true, 3, false>(w)};
+    for (int i = 1; i < 4; ++i) {
+      printf("w/SIMD=%d  %-14s + 32 v_pk_fma: valu %6.1f  mfma %6.1f  both %6.1f  (sum %6.1f, max %6.1f)\n", w, names[i], v, m[i], both[i],
+             v + m[i], v > m[i] ? v : m[i]);
+      printf("w/SIMD=%d  %-14s + 64 v_fma   : valu %6.1f  mfma %6.1f  both %6.1f  (sum %6.1f, max %6.1f)\n", w, names[i], vs, m[i], boths[i],
+             vs + m[i], vs > m[i] ? vs : m[i]);
+    }
   }
   return 0;
 }
