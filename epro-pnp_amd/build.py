@@ -38,7 +38,7 @@ def _run(cmd):
     return r.stdout + r.stderr
 
 
-def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=()):
+def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=(), file_flags=()):
     deps_common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, 'include', 'epropnp_hip.h')]
     if emu:
         out_dir = os.path.join(ROOT, 'tests', 'emu', '_build')
@@ -54,13 +54,17 @@ def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=())
         cc = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value']
         cc += ['-D' + d for d in defines] + list(flags)
     os.makedirs(out_dir, exist_ok=True)
+    per_file = {k: list(v) for k, v in FILE_FLAGS.items()}
+    for spec in file_flags:          # tuning variants: "--file-flag lm_kernel.hip=-fslp-vectorize"
+        name, flag = spec.split('=', 1)
+        per_file.setdefault(name, []).append(flag)
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(out_dir, src.replace('.hip', '.emu.o' if emu else '.o'))
         objs.append(obj)
         if force or _stale(obj, [sp] + deps_common):
-            jobs.append(cc + ([] if emu else FILE_FLAGS.get(src, [])) + ['-c', sp, '-o', obj])
+            jobs.append(cc + ([] if emu else per_file.get(src, [])) + ['-c', sp, '-o', obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             for out in ex.map(_run, jobs):
@@ -80,5 +84,6 @@ if __name__ == '__main__':
     ap.add_argument('-D', dest='defines', action='append', default=[], help='extra -D for a tuning variant')
     ap.add_argument('--tag', default=None, help='build into lib/variants/<tag>/ (tuning variants)')
     ap.add_argument('--flag', dest='flags', action='append', default=[], help='extra compiler flag for a tuning variant')
+    ap.add_argument('--file-flag', dest='file_flags', action='append', default=[], help='<source>=<flag> for a tuning variant')
     a = ap.parse_args()
-    print(build(a.emu, a.force, a.verbose, a.defines, a.tag, a.flags))
+    print(build(a.emu, a.force, a.verbose, a.defines, a.tag, a.flags, a.file_flags))
