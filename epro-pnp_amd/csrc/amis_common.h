@@ -268,8 +268,8 @@ struct AmisCtx {
   int cstride;    // row stride of cpart (s, or s rounded up to 16 for the MFMA kernel)
 };
 
-#ifdef PNP_TUNING
-// tuning builds: cycles spent by the fitting lane in [moment pass + reductions | ACG fixed-point iterations | final fits]
+#ifdef PNP_TUNING_REFIT
+// -DPNP_TUNING -DPNP_TUNING_REFIT builds (the per-phase atomics perturb the kernel): cycles spent by the fitting lane in [moment pass + reductions | ACG fixed-point iterations | final fits]
 __device__ unsigned long long g_refit_phase[4];
 #define PNP_REFIT_PHASE(i)                                                   \
   do {                                                                       \
@@ -365,7 +365,7 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
     ps[0] = rec[0] + rec[3] * y0;
     ps[1] = rec[1] + (rec[4] * y0 + rec[5] * y1);
     ps[2] = rec[2] + (rec[6] * y0 + rec[7] * y1 + rec[8] * y2);
-#ifdef PNP_TUNING
+#ifdef PNP_TUNING_REFIT
     const long long rot_t0_ = clock64();
 #endif
     if (DOF == 6) {   // ACG: L_r g / |L_r g|   (distributions.py:42-52)
@@ -404,7 +404,7 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
         ps[3] = vm_sample_bounded(rec[16], rec[17], uniforms);
       }
     }
-#ifdef PNP_TUNING
+#ifdef PNP_TUNING_REFIT
     if (tid == 0) atomicAdd(&g_refit_phase[3], (unsigned long long)(clock64() - rot_t0_));
 #endif
 #pragma unroll
@@ -480,8 +480,10 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     return;
   }
   const int T = 64, tid = lane_id();
-#ifdef PNP_TUNING
+#ifdef PNP_TUNING_REFIT
   long long refit_t0_ = clock64();
+#endif
+#ifdef PNP_TUNING
   if (a.ablate & 2) {
     for (int i = tid; i < kPropStride; i += T) nrec[i] = rec[i];
     __syncthreads();

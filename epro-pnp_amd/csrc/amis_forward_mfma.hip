@@ -34,10 +34,10 @@ __device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
 // workgroups by thread 0 of each; read back through epropnp_tuning_phase_cycles (c_api.hip).
 __device__ unsigned long long g_fwd_phase[8];
 #define PNP_PHASE(i)                                                        \
-  do {                                                                      \
+  do {       /* accumulated in registers, flushed once at the end: per-phase atomics on one address serialise */ \
     if (tid == 0) {                                                         \
       const long long now_ = clock64();                                     \
-      atomicAdd(&g_fwd_phase[i], (unsigned long long)(now_ - phase_t0_));   \
+      phase_acc_[i] += (unsigned long long)(now_ - phase_t0_);              \
       phase_t0_ = now_;                                                     \
     }                                                                       \
   } while (0)
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
 
 #ifdef PNP_TUNING
   long long phase_t0_ = clock64();
+  unsigned long long phase_acc_[6] = {0, 0, 0, 0, 0, 0};
 #endif
   PNP_DYN_SMEM(float, smem);
   constexpr bool kRegs = NPT > 0;
@@ -283,19 +284,27 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   if (proposals != nullptr)
     for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
   PNP_PHASE(5);
+#ifdef PNP_TUNING
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_fwd_phase[i], phase_acc_[i]);
+  }
+#endif
 }
 
 #ifdef PNP_TUNING
 int tuning_phase_cycles(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-  if (out) {    // slots 6, 7 are unused by the kernel phases: cycles of the refit's [ACG fixed-point iterations | final fp64 fits]
+#ifdef PNP_TUNING_REFIT
+  if (out) {    // slots 6, 7 are unused by the kernel phases: cycles of the refit's ACG fixed-point iterations | final fp64 fits
     unsigned long long rf[4];
     if (hipMemcpyFromSymbol(rf, HIP_SYMBOL(g_refit_phase), sizeof(rf)) != hipSuccess) return -1;
-    out[6] = rf[1] + rf[2];
-    out[7] = rf[3];      // rotation sampling inside the draw phase (ACG / von Mises)
+    out[6] = rf[1];      // ACG fixed-point iterations (fp64 inverse on one lane + sample passes)
+    out[7] = rf[2];      // final fits (translation, rotation) on one lane; the moment pass is phase 4 minus these two
     const unsigned long long z4[4] = {0, 0, 0, 0};
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_refit_phase), z4, sizeof(z4)) != hipSuccess) return -1;
   }
+#endif
   if (reset) {
     const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_phase), z, sizeof(z)) != hipSuccess) return -1;
