@@ -129,6 +129,24 @@ int epropnp_prepare_backward(const float* noc, const float* dim, const float* lo
                                       grad_dim, grad_logits, grad_scale, (hipStream_t)stream);
 }
 
+int epropnp_prepare_dense_forward(const float* noc_map, const float* dim, const float* logit_map, const float* scale,
+                                  const float* box, const int64_t* inds, int32_t num_obj, int32_t num_pts, int32_t height,
+                                  int32_t width, int32_t mode, float* x3d, float* x2d, float* w2d, float* stats,
+                                  void* stream) {
+  return pnp::launch_prepare_dense_forward(noc_map, dim, logit_map, scale, box, (const long long*)inds, num_obj, num_pts,
+                                           height, width, mode, x3d, x2d, w2d, stats, (hipStream_t)stream);
+}
+
+int epropnp_prepare_dense_backward(const float* noc_map, const float* dim, const float* logit_map, const float* scale,
+                                   const int64_t* inds, const float* stats, const float* grad_x3d, const float* grad_w2d,
+                                   int32_t num_obj, int32_t num_pts, int32_t height, int32_t width, int32_t mode,
+                                   float* grad_noc_map, float* grad_dim, float* grad_logit_map, float* grad_scale,
+                                   void* stream) {
+  return pnp::launch_prepare_dense_backward(noc_map, dim, logit_map, scale, (const long long*)inds, stats, grad_x3d, grad_w2d,
+                                            num_obj, num_pts, height, width, mode, grad_noc_map, grad_dim, grad_logit_map,
+                                            grad_scale, (hipStream_t)stream);
+}
+
 #ifdef PNP_TUNING
 // tuning builds only (not part of the ABI): per-phase shader-clock totals of amis_forward_mfma_kernel
 int epropnp_tuning_phase_cycles(unsigned long long* out, int reset) { return pnp::tuning_phase_cycles(out, reset); }

@@ -387,21 +387,77 @@ int launch_shift_poses(const float* pose, const float* offset, int P, int B, int
 //   mode 0: w2d = softmax_N(logits) * scale           (Det deform_pnp_head.py:418-423,874)
 //   mode 1: w2d = exp(logits - mean_N(logits) - log N) * scale     ("mean-normalised exp", lib/train.py:163-166)
 // One workgroup per object; stats[b] = {max or mean (x, y), sum of exponentials (x, y)} is kept for the backward.
+//
+// Two input layouts.  Point-major: noc (B,N,3), logits (B,N,2).  Dense (lib/train.py:143-162): the network's maps
+// noc (B,3,H*W), logits (B,2,H*W) gathered at inds (B,N) -- `x.flatten(2).transpose(-1,-2)[batch_inds, sample_inds]`
+// without materialising the transposed maps -- plus the pixel grid x2d = wh_begin + (col, row) * wh_unit of the sampled
+// pixels (box = [begin_x, begin_y, unit] per object).
+struct PrepLayout {
+  const long long* inds;   // (B,N) pixel index row * W + col, or nullptr (point-major)
+  int HW, W;
+};
+
+// begin + index * unit with TWO roundings, as the reference's separate torch mul and add (HIP's __fmul_rn is a plain `*`
+// that -ffp-contract=fast fuses with the add)
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#ifndef EPROPNP_EMU
+#pragma clang fp contract(off)
+  const float m = a * b;
+  return c + m;
+#else
+  volatile float m = a * b;
+  return c + m;
+#endif
+}
+
+__device__ __forceinline__ float2 prep_ld2(const float* src, int b, int n, int N, const PrepLayout& L) {
+  if (L.inds == nullptr) return reinterpret_cast<const float2*>(src)[(size_t)b * N + n];
+  const size_t o = (size_t)b * 2 * L.HW + (size_t)L.inds[(size_t)b * N + n];
+  return make_float2(src[o], src[o + L.HW]);
+}
+__device__ __forceinline__ void prep_ld3(const float* src, int b, int n, int N, const PrepLayout& L, float (&v)[3]) {
+  if (L.inds == nullptr) {
+    const size_t o = ((size_t)b * N + n) * 3;
+    v[0] = src[o]; v[1] = src[o + 1]; v[2] = src[o + 2];
+  } else {
+    const size_t o = (size_t)b * 3 * L.HW + (size_t)L.inds[(size_t)b * N + n];
+    v[0] = src[o]; v[1] = src[o + L.HW]; v[2] = src[o + 2 * (size_t)L.HW];
+  }
+}
+// gradients of the dense maps are scattered into zero-filled buffers (atomics: `inds` may repeat a pixel)
+__device__ __forceinline__ void prep_st2(float* dst, int b, int n, int N, const PrepLayout& L, float x, float y) {
+  if (L.inds == nullptr) {
+    reinterpret_cast<float2*>(dst)[(size_t)b * N + n] = make_float2(x, y);
+  } else {
+    const size_t o = (size_t)b * 2 * L.HW + (size_t)L.inds[(size_t)b * N + n];
+    atomicAdd(dst + o, x); atomicAdd(dst + o + L.HW, y);
+  }
+}
+__device__ __forceinline__ void prep_st3(float* dst, int b, int n, int N, const PrepLayout& L, float x, float y, float z) {
+  if (L.inds == nullptr) {
+    const size_t o = ((size_t)b * N + n) * 3;
+    dst[o] = x; dst[o + 1] = y; dst[o + 2] = z;
+  } else {
+    const size_t o = (size_t)b * 3 * L.HW + (size_t)L.inds[(size_t)b * N + n];
+    atomicAdd(dst + o, x); atomicAdd(dst + o + L.HW, y); atomicAdd(dst + o + 2 * (size_t)L.HW, z);
+  }
+}
+
 __global__ __launch_bounds__(256) void prepare_forward_kernel(const float* __restrict__ noc, const float* __restrict__ dim,
                                                                const float* __restrict__ logits,
-                                                               const float* __restrict__ scale, int B, int N, int mode,
-                                                               float* __restrict__ x3d, float* __restrict__ w2d,
-                                                               float* __restrict__ stats) {
+                                                               const float* __restrict__ scale, PrepLayout L,
+                                                               const float* __restrict__ box, int B, int N, int mode,
+                                                               float* __restrict__ x3d, float* __restrict__ x2d,
+                                                               float* __restrict__ w2d, float* __restrict__ stats) {
   __shared__ float scratch[4 * 4];
   const int b = object_of_block(B);
   if (b >= B) return;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x;
-  const float2* lg = reinterpret_cast<const float2*>(logits) + (size_t)b * N;
   float ref[2];
   if (mode == 0) {
     float mx = -INFINITY, my = -INFINITY;
     for (int n = tid; n < N; n += T) {
-      const float2 v = lg[n];
+      const float2 v = prep_ld2(logits, b, n, N, L);
       mx = fmaxf(mx, v.x); my = fmaxf(my, v.y);
     }
     ref[0] = block_max(mx, scratch);
@@ -409,7 +465,7 @@ __global__ __launch_bounds__(256) void prepare_forward_kernel(const float* __res
   } else {
     float s[2] = {0.f, 0.f};
     for (int n = tid; n < N; n += T) {
-      const float2 v = lg[n];
+      const float2 v = prep_ld2(logits, b, n, N, L);
       s[0] += v.x; s[1] += v.y;
     }
     block_sum<2>(s, scratch);
@@ -418,7 +474,7 @@ __global__ __launch_bounds__(256) void prepare_forward_kernel(const float* __res
   float se[2] = {0.f, 0.f};
   if (mode == 0) {
     for (int n = tid; n < N; n += T) {
-      const float2 v = lg[n];
+      const float2 v = prep_ld2(logits, b, n, N, L);
       se[0] += expf(v.x - ref[0]); se[1] += expf(v.y - ref[1]);
     }
     block_sum<2>(se, scratch);
@@ -429,15 +485,25 @@ __global__ __launch_bounds__(256) void prepare_forward_kernel(const float* __res
   const float kx = sx / se[0], ky = sy / se[1];
   float2* wo = reinterpret_cast<float2*>(w2d) + (size_t)b * N;
   for (int n = tid; n < N; n += T) {
-    const float2 v = lg[n];
+    const float2 v = prep_ld2(logits, b, n, N, L);
     wo[n] = make_float2(expf(v.x - ref[0]) * kx, expf(v.y - ref[1]) * ky);
   }
   if (x3d != nullptr) {
     const float d0 = dim[(size_t)b * 3], d1 = dim[(size_t)b * 3 + 1], d2 = dim[(size_t)b * 3 + 2];
-    const float* src = noc + (size_t)b * N * 3;
     float* dst = x3d + (size_t)b * N * 3;
     for (int n = tid; n < N; n += T) {
-      dst[3 * n] = src[3 * n] * d0; dst[3 * n + 1] = src[3 * n + 1] * d1; dst[3 * n + 2] = src[3 * n + 2] * d2;
+      float v[3];
+      prep_ld3(noc, b, n, N, L, v);
+      dst[3 * n] = v[0] * d0; dst[3 * n + 1] = v[1] * d1; dst[3 * n + 2] = v[2] * d2;
+    }
+  }
+  if (x2d != nullptr) {     // pixel grid of the sampled pixels: begin + index * unit, rounded as the reference's mul, add
+    const float bx = box[(size_t)b * 3], by = box[(size_t)b * 3 + 1], unit = box[(size_t)b * 3 + 2];
+    float2* xo = reinterpret_cast<float2*>(x2d) + (size_t)b * N;
+    for (int n = tid; n < N; n += T) {
+      const int idx = (int)L.inds[(size_t)b * N + n];          // < H * W: 32-bit divide
+      const float col = (float)(idx % L.W), row = (float)(idx / L.W);
+      xo[n] = make_float2(mul_then_add(col, unit, bx), mul_then_add(row, unit, by));
     }
   }
   if (tid == 0) {
@@ -446,10 +512,11 @@ __global__ __launch_bounds__(256) void prepare_forward_kernel(const float* __res
   }
 }
 
-// grad_x3d (B,N,3) | NULL, grad_w2d (B,N,2) -> grad_noc, grad_dim (B,3), grad_logits (B,N,2), grad_scale (B,2)
+// grad_x3d (B,N,3) | NULL, grad_w2d (B,N,2) -> grad_noc, grad_dim (B,3), grad_logits, grad_scale (B,2); grad_noc and
+// grad_logits have the layout of the forward's inputs (dense: zero-filled by the launcher, scattered here).
 __global__ __launch_bounds__(256) void prepare_backward_kernel(const float* __restrict__ noc, const float* __restrict__ dim,
                                                                 const float* __restrict__ logits,
-                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ scale, PrepLayout L,
                                                                 const float* __restrict__ stats,
                                                                 const float* __restrict__ gx3d,
                                                                 const float* __restrict__ gw2d, int B, int N, int mode,
@@ -459,7 +526,6 @@ __global__ __launch_bounds__(256) void prepare_backward_kernel(const float* __re
   const int b = object_of_block(B);
   if (b >= B) return;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x;
-  const float2* lg = reinterpret_cast<const float2*>(logits) + (size_t)b * N;
   const float2* gw = reinterpret_cast<const float2*>(gw2d) + (size_t)b * N;
   const float r0 = stats[(size_t)b * 4], r1 = stats[(size_t)b * 4 + 1];
   const float ie0 = 1.0f / stats[(size_t)b * 4 + 2], ie1 = 1.0f / stats[(size_t)b * 4 + 3];
@@ -467,21 +533,22 @@ __global__ __launch_bounds__(256) void prepare_backward_kernel(const float* __re
   // sums: sum_n g_n p_n per channel (p = normalised exponential without the scale), sum_n gx3d_n * noc_n per axis
   float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int n = tid; n < N; n += T) {
-    const float2 v = lg[n], g = gw[n];
+    const float2 v = prep_ld2(logits, b, n, N, L), g = gw[n];
     s[0] = fmaf(g.x, expf(v.x - r0) * ie0, s[0]);
     s[1] = fmaf(g.y, expf(v.y - r1) * ie1, s[1]);
     if (gx3d != nullptr) {
       const size_t o = ((size_t)b * N + n) * 3;
-      s[2] = fmaf(gx3d[o], noc[o], s[2]); s[3] = fmaf(gx3d[o + 1], noc[o + 1], s[3]); s[4] = fmaf(gx3d[o + 2], noc[o + 2], s[4]);
+      float c[3];
+      prep_ld3(noc, b, n, N, L, c);
+      s[2] = fmaf(gx3d[o], c[0], s[2]); s[3] = fmaf(gx3d[o + 1], c[1], s[3]); s[4] = fmaf(gx3d[o + 2], c[2], s[4]);
     }
   }
   block_sum<5>(s, scratch);
   // softmax:          dL/dl_n = s p_n (g_n - sum_m g_m p_m)
   // mean-normalised:  dL/dl_n = s (g_n p_n - (1/N) sum_m g_m p_m)
-  float2* gl = reinterpret_cast<float2*>(glogits) + (size_t)b * N;
   const float invn = 1.0f / (float)N;
   for (int n = tid; n < N; n += T) {
-    const float2 v = lg[n], g = gw[n];
+    const float2 v = prep_ld2(logits, b, n, N, L), g = gw[n];
     const float px = expf(v.x - r0) * ie0, py = expf(v.y - r1) * ie1;
     float ox, oy;
     if (mode == 0) {
@@ -489,13 +556,13 @@ __global__ __launch_bounds__(256) void prepare_backward_kernel(const float* __re
     } else {
       ox = sx * (g.x * px - invn * s[0]); oy = sy * (g.y * py - invn * s[1]);
     }
-    gl[n] = make_float2(ox, oy);
+    prep_st2(glogits, b, n, N, L, ox, oy);
   }
   if (gx3d != nullptr) {
     const float d0 = dim[(size_t)b * 3], d1 = dim[(size_t)b * 3 + 1], d2 = dim[(size_t)b * 3 + 2];
     for (int n = tid; n < N; n += T) {
       const size_t o = ((size_t)b * N + n) * 3;
-      gnoc[o] = gx3d[o] * d0; gnoc[o + 1] = gx3d[o + 1] * d1; gnoc[o + 2] = gx3d[o + 2] * d2;
+      prep_st3(gnoc, b, n, N, L, gx3d[o] * d0, gx3d[o + 1] * d1, gx3d[o + 2] * d2);
     }
   }
   if (tid == 0) {
@@ -515,8 +582,9 @@ int launch_prepare_forward(const float* noc, const float* dim, const float* logi
   if (B <= 0) return EPROPNP_OK;
   if (!logits || !w2d || !stats || N < 1 || (mode != 0 && mode != 1) || ((x3d != nullptr) && (!noc || !dim)))
     return fail(EPROPNP_EINVAL, "prepare_forward: bad argument");
-  PNP_LAUNCH(prepare_forward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc, dim, logits, scale, B,
-             N, mode, x3d, w2d, stats);
+  const PrepLayout L = {nullptr, 0, 0};
+  PNP_LAUNCH(prepare_forward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc, dim, logits, scale, L,
+             (const float*)nullptr, B, N, mode, x3d, (float*)nullptr, w2d, stats);
   return check_launch("prepare_forward_kernel");
 }
 
@@ -527,9 +595,46 @@ int launch_prepare_backward(const float* noc, const float* dim, const float* log
   if (!logits || !stats || !gw2d || !glogits || N < 1 || (mode != 0 && mode != 1) ||
       ((gx3d != nullptr) && (!noc || !dim || !gnoc)))
     return fail(EPROPNP_EINVAL, "prepare_backward: bad argument");
-  PNP_LAUNCH(prepare_backward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc, dim, logits, scale,
+  const PrepLayout L = {nullptr, 0, 0};
+  PNP_LAUNCH(prepare_backward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc, dim, logits, scale, L,
              stats, gx3d, gw2d, B, N, mode, gnoc, gdim, glogits, gscale);
   return check_launch("prepare_backward_kernel");
+}
+
+int launch_prepare_dense_forward(const float* noc_map, const float* dim, const float* logit_map, const float* scale,
+                                 const float* box, const long long* inds, int B, int N, int H, int W, int mode, float* x3d,
+                                 float* x2d, float* w2d, float* stats, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!logit_map || !inds || !w2d || !stats || N < 1 || H < 1 || W < 1 || (mode != 0 && mode != 1) ||
+      ((x3d != nullptr) && (!noc_map || !dim)) || ((x2d != nullptr) && !box))
+    return fail(EPROPNP_EINVAL, "prepare_dense_forward: bad argument");
+  const PrepLayout L = {inds, H * W, W};
+  PNP_LAUNCH(prepare_forward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc_map, dim, logit_map,
+             scale, L, box, B, N, mode, x3d, x2d, w2d, stats);
+  return check_launch("prepare_forward_kernel (dense)");
+}
+
+int launch_prepare_dense_backward(const float* noc_map, const float* dim, const float* logit_map, const float* scale,
+                                  const long long* inds, const float* stats, const float* gx3d, const float* gw2d, int B,
+                                  int N, int H, int W, int mode, float* gnoc_map, float* gdim, float* glogit_map,
+                                  float* gscale, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!logit_map || !inds || !stats || !gw2d || !glogit_map || N < 1 || H < 1 || W < 1 || (mode != 0 && mode != 1) ||
+      ((gx3d != nullptr) && (!noc_map || !dim || !gnoc_map)))
+    return fail(EPROPNP_EINVAL, "prepare_dense_backward: bad argument");
+  const PrepLayout L = {inds, H * W, W};
+  const size_t plane = (size_t)H * W * sizeof(float);
+#ifndef EPROPNP_EMU
+  if (hipMemsetAsync(glogit_map, 0, (size_t)B * 2 * plane, st) != hipSuccess) return fail(EPROPNP_ELAUNCH, "prepare_dense_backward: memset");
+  if (gx3d != nullptr && hipMemsetAsync(gnoc_map, 0, (size_t)B * 3 * plane, st) != hipSuccess)
+    return fail(EPROPNP_ELAUNCH, "prepare_dense_backward: memset");
+#else
+  memset(glogit_map, 0, (size_t)B * 2 * plane);
+  if (gx3d != nullptr) memset(gnoc_map, 0, (size_t)B * 3 * plane);
+#endif
+  PNP_LAUNCH(prepare_backward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc_map, dim, logit_map,
+             scale, L, stats, gx3d, gw2d, B, N, mode, gnoc_map, gdim, glogit_map, gscale);
+  return check_launch("prepare_backward_kernel (dense)");
 }
 
 int launch_rslm_draw(const float* w2d, int B, int N, int P, int n_pts, unsigned long long seed, unsigned long long offset,

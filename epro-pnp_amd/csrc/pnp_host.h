@@ -98,6 +98,13 @@ int launch_prepare_forward(const float* noc, const float* dim, const float* logi
 int launch_prepare_backward(const float* noc, const float* dim, const float* logits, const float* scale, const float* stats,
                             const float* gx3d, const float* gw2d, int B, int N, int mode, float* gnoc, float* gdim,
                             float* glogits, float* gscale, hipStream_t st);
+int launch_prepare_dense_forward(const float* noc_map, const float* dim, const float* logit_map, const float* scale,
+                                 const float* box, const long long* inds, int B, int N, int H, int W, int mode, float* x3d,
+                                 float* x2d, float* w2d, float* stats, hipStream_t st);
+int launch_prepare_dense_backward(const float* noc_map, const float* dim, const float* logit_map, const float* scale,
+                                  const long long* inds, const float* stats, const float* gx3d, const float* gw2d, int B,
+                                  int N, int H, int W, int mode, float* gnoc_map, float* gdim, float* glogit_map,
+                                  float* gscale, hipStream_t st);
 int launch_shift_poses_backward(const float* pose, const float* offset, const float* gout, int P, int B, int dof, float sign,
                                 float* gpose, hipStream_t st);
 int launch_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, float* pose_plus,

@@ -60,13 +60,16 @@ def _declare(lib):
     lib.epropnp_shift_poses_backward.argtypes = [vp, vp, vp, i32, i32, i32, C.c_float, vp, vp]
     lib.epropnp_prepare_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.epropnp_prepare_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.epropnp_prepare_dense_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.epropnp_prepare_dense_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.epropnp_rslm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), i32, i32, C.c_uint64, C.c_uint64, vp, vp, vp,
                                        vp, vp, vp]
     lib.epropnp_adaptive_delta.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp]
     lib.epropnp_mc_loss_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.epropnp_mc_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     for name in ('evaluate_cost', 'normal_equations', 'lm_solve', 'amis_forward', 'amis_backward', 'adaptive_delta',
-                 'mc_loss_forward', 'mc_loss_backward', 'rslm_draw', 'gn_step_forward', 'gn_step_backward', 'rslm_solve', 'center_points', 'shift_poses', 'prepare_forward', 'prepare_backward', 'pose_opt_plus_forward', 'pose_opt_plus_backward', 'shift_poses_backward'):
+                 'mc_loss_forward', 'mc_loss_backward', 'rslm_draw', 'gn_step_forward', 'gn_step_backward', 'rslm_solve', 'center_points', 'shift_poses', 'prepare_forward', 'prepare_backward', 'pose_opt_plus_forward', 'pose_opt_plus_backward', 'shift_poses_backward', 'prepare_dense_forward',
+                 'prepare_dense_backward'):
         getattr(lib, 'epropnp_' + name).restype = C.c_int
     return lib
 
@@ -76,7 +79,8 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_adaptive_delta', 'epropnp_mc_loss_forward', 'epropnp_mc_loss_backward', 'epropnp_rslm_draw',
            'epropnp_gn_step_forward', 'epropnp_gn_step_backward', 'epropnp_rslm_solve',
            'epropnp_center_points', 'epropnp_shift_poses', 'epropnp_prepare_forward', 'epropnp_prepare_backward',
-           'epropnp_pose_opt_plus_forward', 'epropnp_pose_opt_plus_backward', 'epropnp_shift_poses_backward')
+           'epropnp_pose_opt_plus_forward', 'epropnp_pose_opt_plus_backward', 'epropnp_shift_poses_backward',
+           'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward')
 
 
 def lib():

@@ -4,6 +4,8 @@ The reference does this in its callers, not in `epropnp/`:
   * EPro-PnP-6DoF/lib/train.py:141,163-166   x3d = noc * dim;  w2d = exp(w2d - mean_N(w2d) - log N) * scale
     ("mean-normalised exp", the legacy alternative to softmax) -- mode='mean_exp'
   * EPro-PnP-Det/.../deform_pnp_head.py:418-423,873-875   w2d = softmax_N(w2d) * scale;  x3d = noc * dim -- mode='softmax'
+  * EPro-PnP-6DoF/lib/train.py:143-162   the dense variant: pixel-grid x2d of the cropped box and a random subset of
+    the out_res x out_res pixels gathered from the network's (bs, C, h, w) maps -- `prepare_dense_correspondences`
 Provided here because it is the data format on the input side of the layer; plain PyTorch for
 tensors that are not on the HIP path.
 """
@@ -79,6 +81,99 @@ def prepare_correspondences(noc, dim, w2d_logits, scale=None, mode='softmax'):
         out = _Prepare.apply(noc, dim, w2d_logits, scale, MODES[mode])
         return (None, out) if noc is None else out
     return _reference(noc, dim, w2d_logits, scale, mode)
+
+
+def box_grid_params(c_box, s_box, out_res):
+    """[wh_begin_x, wh_begin_y, wh_unit] per object from the crop centre / size, as EPro-PnP-6DoF/lib/train.py:143-145:
+    s = s_box.long(); wh_begin = c_box.long() - s / 2.; wh_unit = s.float() / out_res  ->  (B,3) float32."""
+    s = s_box.to(torch.int64)
+    wh_begin = c_box.to(torch.int64) - s[:, None] / 2.
+    wh_unit = s.to(torch.float32) / out_res
+    return torch.cat((wh_begin.to(torch.float32), wh_unit[:, None]), dim=1)
+
+
+def _reference_dense(noc_map, dim, logit_map, scale, box, inds, mode):
+    """Restates EPro-PnP-6DoF/lib/train.py:141-166 on dense maps (the PyTorch composite the fused op replaces)."""
+    B, _, H, W = logit_map.shape
+    ar_w = torch.arange(W, device=logit_map.device, dtype=torch.float32)
+    ar_h = torch.arange(H, device=logit_map.device, dtype=torch.float32)
+    y, x = torch.meshgrid(ar_h, ar_w, indexing='ij')
+    box = box.to(torch.float32)
+    x2d = torch.stack((box[:, 0, None, None] + x * box[:, 2, None, None],
+                       box[:, 1, None, None] + y * box[:, 2, None, None]), dim=1)             # (B,2,H,W)
+    bi = torch.arange(B, device=logit_map.device)[:, None]
+    pick = lambda m: m.flatten(2).transpose(-1, -2)[bi, inds]
+    x3d = None if noc_map is None else pick(noc_map * dim[..., None, None])
+    _, w2d = _reference(None, None, pick(logit_map), scale, mode)
+    return x3d, pick(x2d).to(logit_map.dtype), w2d
+
+
+class _PrepareDense(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, noc_map, dim, logit_map, scale, box, inds, mode):
+        from . import _hip
+        from .functional import _f32c
+        lg = _f32c(logit_map, 'w2d logit map')
+        B, _, H, W = lg.shape
+        N = inds.shape[1]
+        nc = None if noc_map is None else _f32c(noc_map, 'noc map')
+        dm = None if dim is None else _f32c(dim, 'dim')
+        sc = None if scale is None else _f32c(scale, 'scale')
+        bx = _f32c(box, 'box')
+        ix = inds.to(torch.int64).contiguous()
+        x3d = None if nc is None else torch.empty((B, N, 3), dtype=torch.float32, device=lg.device)
+        x2d = torch.empty((B, N, 2), dtype=torch.float32, device=lg.device)
+        w2d = torch.empty((B, N, 2), dtype=torch.float32, device=lg.device)
+        stats = torch.empty((B, 4), dtype=torch.float32, device=lg.device)
+        _hip.call('epropnp_prepare_dense_forward', _hip.ptr(nc), _hip.ptr(dm), _hip.ptr(lg), _hip.ptr(sc), _hip.ptr(bx),
+                  _hip.ptr(ix), B, N, H, W, int(mode), _hip.ptr(x3d), _hip.ptr(x2d), _hip.ptr(w2d), _hip.ptr(stats),
+                  _hip.stream_of(lg))
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(nc, dm, lg, sc, ix, stats)
+        ctx.mode = int(mode)
+        ctx.mark_non_differentiable(x2d)
+        if x3d is None:
+            return x2d, w2d
+        return x3d, x2d, w2d
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from . import _hip
+        nc, dm, lg, sc, ix, stats = ctx.saved_tensors
+        gx3d, gw2d = (None, grads[1]) if nc is None else (grads[0], grads[2])
+        if gx3d is None and gw2d is None:
+            return (None,) * 7
+        B, _, H, W = lg.shape
+        N = ix.shape[1]
+        gw2d = torch.zeros((B, N, 2), dtype=torch.float32, device=lg.device) if gw2d is None else gw2d.contiguous()
+        gx3d = None if gx3d is None else gx3d.contiguous()
+        gl = torch.empty_like(lg)
+        gnoc = None if gx3d is None else torch.empty_like(nc)
+        gdim = None if gx3d is None else torch.empty_like(dm)
+        gsc = None if sc is None else torch.empty_like(sc)
+        _hip.call('epropnp_prepare_dense_backward', _hip.ptr(nc), _hip.ptr(dm), _hip.ptr(lg), _hip.ptr(sc), _hip.ptr(ix),
+                  _hip.ptr(stats), _hip.ptr(gx3d), _hip.ptr(gw2d), B, N, H, W, ctx.mode, _hip.ptr(gnoc), _hip.ptr(gdim),
+                  _hip.ptr(gl), _hip.ptr(gsc), _hip.stream_of(lg))
+        return gnoc, gdim, gl, gsc, None, None, None
+
+
+def prepare_dense_correspondences(noc_map, dim, w2d_logit_map, scale, box, sample_inds, mode='mean_exp'):
+    """The 6-DoF training loop's correspondence set from the network's dense maps (EPro-PnP-6DoF/lib/train.py:141-166).
+
+    noc_map (B,3,H,W) | None, dim (B,3) | None, w2d_logit_map (B,2,H,W), scale (B,2) | None,
+    box (B,3) = `box_grid_params(c_box, s_box, out_res)`, sample_inds (B,N) int64 pixel indices (row * W + col; the
+    reference draws `np.random.choice(H*W, N, replace=False)` per object)
+      -> x3d (B,N,3) | None, x2d (B,N,2), w2d (B,N,2);  differentiable w.r.t. noc_map, dim, w2d_logit_map, scale."""
+    assert mode in MODES, f'mode must be one of {tuple(MODES)}'
+    assert (noc_map is None) == (dim is None)
+    from . import _hip
+    ts = [t for t in (noc_map, dim, w2d_logit_map, scale, box) if t is not None]
+    if (w2d_logit_map.dim() == 4 and w2d_logit_map.size(0) > 0 and sample_inds.size(1) > 0 and _hip.on_hip_path(*ts)
+            and sample_inds.device == w2d_logit_map.device):
+        out = _PrepareDense.apply(noc_map, dim, w2d_logit_map, scale, box, sample_inds, MODES[mode])
+        return (None,) + tuple(out) if noc_map is None else out
+    return _reference_dense(noc_map, dim, w2d_logit_map, scale, box, sample_inds, mode)
 
 
 def derivative_regularization_6dof(pose_opt_plus, pose_gt, beta=0.05):

@@ -189,6 +189,25 @@ int epropnp_prepare_backward(const float* noc, const float* dim, const float* lo
                              int32_t num_pts, int32_t mode, float* grad_noc, float* grad_dim, float* grad_logits,
                              float* grad_scale, void* stream);
 
+/* The same pre-processing reading the network's DENSE maps (EPro-PnP-6DoF/lib/train.py:141-166): the maps are gathered
+ * at `inds` (pixel index row * width + col; the reference draws them with np.random.choice, :157-162:
+ * `x.flatten(2).transpose(-1, -2)[batch_inds, sample_inds]`) without materialising the transposed maps, and the pixel
+ * grid of the sampled pixels is generated in place of the meshgrid of :147-152:
+ *   x2d[b,n] = (box[b,0] + col * box[b,2], box[b,1] + row * box[b,2])     box = [wh_begin_x, wh_begin_y, wh_unit]
+ * noc_map (B,3,H,W), dim (B,3) (both NULL with x3d NULL), logit_map (B,2,H,W), scale (B,2) or NULL, box (B,3) (NULL with
+ * x2d NULL), inds (B,N) int64 -> x3d (B,N,3), x2d (B,N,2), w2d (B,N,2), stats (B,4). */
+int epropnp_prepare_dense_forward(const float* noc_map, const float* dim, const float* logit_map, const float* scale,
+                                  const float* box, const int64_t* inds, int32_t num_obj, int32_t num_pts, int32_t height,
+                                  int32_t width, int32_t mode, float* x3d, float* x2d, float* w2d, float* stats,
+                                  void* stream);
+/* grad_x3d (B,N,3) or NULL, grad_w2d (B,N,2) -> grad_noc_map (B,3,H,W), grad_logit_map (B,2,H,W) (zero-filled here, then
+ * scattered at `inds`; repeated indices accumulate), grad_dim (B,3), grad_scale (B,2) or NULL. */
+int epropnp_prepare_dense_backward(const float* noc_map, const float* dim, const float* logit_map, const float* scale,
+                                   const int64_t* inds, const float* stats, const float* grad_x3d, const float* grad_w2d,
+                                   int32_t num_obj, int32_t num_pts, int32_t height, int32_t width, int32_t mode,
+                                   float* grad_noc_map, float* grad_dim, float* grad_logit_map, float* grad_scale,
+                                   void* stream);
+
 /* Backward of epropnp_shift_poses w.r.t. the pose (the offset is a constant, pnp_normalize detaches it):
  * grad_out (P,B,pose_len) -> grad_pose (P,B,pose_len). */
 int epropnp_shift_poses_backward(const float* pose, const float* offset, const float* grad_out, int32_t num_poses,

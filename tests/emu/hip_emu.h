@@ -116,6 +116,9 @@ inline void wave_sync() {
   }
 }
 
+// fibers of a block run one at a time on one thread: a plain read-modify-write is atomic
+inline float atomic_add(float* p, float v) { float o = *p; *p = o + v; return o; }
+
 template <class T>
 inline T shfl(T v, int src) {
   static_assert(sizeof(T) <= 8, "shfl payload");
@@ -184,6 +187,7 @@ inline void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> bod
 #define blockDim (emu::blk().bdim)
 #define gridDim (emu::blk().gdim)
 inline void __syncthreads() { emu::syncthreads(); }
+inline float atomicAdd(float* p, float v) { return emu::atomic_add(p, v); }
 
 #define PNP_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })

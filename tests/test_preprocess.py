@@ -52,3 +52,66 @@ def test_weights_sum_and_regularization_losses(backend):
     gt = torch.tensor([[0.1, 0.02, 5.0, 0.0, 1.0, 0.0, 0.0]])
     lt, lr = derivative_regularization_6dof(pose, gt)
     assert abs(lt.item() - 0.5 * 0.02 ** 2 / 0.05) < 1e-7 and abs(lr.item() - 2.0) < 1e-6
+
+
+@pytest.mark.parametrize('mode', ['mean_exp', 'softmax'])
+@pytest.mark.parametrize('with_x3d,with_scale,H,W,N', [(True, True, 16, 16, 32), (False, True, 8, 12, 96), (True, False, 64, 64, 512)])
+def test_prepare_dense_matches_reference_composite(backend, mode, with_x3d, with_scale, H, W, N):
+    """Dense maps + sampled pixels (EPro-PnP-6DoF/lib/train.py:141-166): the fused gather against the PyTorch composite
+    (meshgrid, flatten/transpose/index, mean-normalised exp) -- x2d bit-exact, the rest and all gradients to fp32 rounding."""
+    import numpy as np
+    from epropnp.preprocess import _reference_dense, box_grid_params, prepare_dense_correspondences
+    g = torch.Generator().manual_seed(H * W + N)
+    B = 3
+    noc = (torch.rand(B, 3, H, W, generator=g) - 0.5) if with_x3d else None
+    dim = (torch.rand(B, 3, generator=g) + 0.5) if with_x3d else None
+    logits = torch.randn(B, 2, H, W, generator=g) * 2
+    scale = (torch.rand(B, 2, generator=g) * 3 + 0.1) if with_scale else None
+    c_box = torch.tensor([[320.7, 240.2], [100.0, 400.9], [55.5, 60.5]])
+    s_box = torch.tensor([128.9, 77.0, 301.2])
+    box = box_grid_params(c_box, s_box, W)
+    rs = np.random.RandomState(N)
+    inds = torch.tensor(np.stack([rs.choice(H * W, size=N, replace=False) for _ in range(B)]), dtype=torch.int64)
+    up_w, up_x = torch.randn(B, N, 2, generator=g), torch.randn(B, N, 3, generator=g)
+
+    def run(fn, dev, dtype):
+        ins = [None if t is None else t.clone().to(dev, dtype).requires_grad_(True) for t in (noc, dim, logits, scale)]
+        x3d, x2d, w2d = fn(*ins, box.to(dev), inds.to(dev), mode)
+        loss = (w2d * up_w.to(dev, dtype)).sum()
+        if x3d is not None:
+            loss = loss + (x3d * up_x.to(dev, dtype)).sum()
+        loss.backward()
+        return x3d, x2d, w2d, [None if t is None else t.grad for t in ins]
+
+    x_ref, p_ref, w_ref, g_ref = run(_reference_dense, 'cpu', torch.float64)
+    _, p_ref32, _, _ = run(_reference_dense, 'cpu', torch.float32)
+    x, p, w, gr = run(prepare_dense_correspondences, backend, torch.float32)
+    assert not p.requires_grad
+    assert torch.equal(p.cpu(), p_ref32)                       # begin + index * unit, rounded as mul then add
+    torch.testing.assert_close(w.detach().cpu().double(), w_ref.detach(), rtol=2e-5, atol=1e-7)
+    if with_x3d:
+        torch.testing.assert_close(x.detach().cpu().double(), x_ref.detach(), rtol=1e-6, atol=1e-7)
+    for a, b in zip(gr, g_ref):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.shape == b.shape
+            torch.testing.assert_close(a.cpu().double(), b, rtol=2e-4, atol=2e-5 * float(b.abs().max()))
+
+
+def test_prepare_dense_repeated_pixels_accumulate(backend):
+    """`inds` may repeat a pixel (sampling with replacement): the map gradients accumulate like index_put_(accumulate=True)."""
+    from epropnp.preprocess import _reference_dense, prepare_dense_correspondences
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 2, 4, 4, generator=g)
+    box = torch.tensor([[0.0, 0.0, 1.0], [10.0, 20.0, 2.5]])
+    inds = torch.tensor([[0, 5, 5, 15, 0, 0], [3, 3, 3, 3, 7, 8]])
+    up = torch.randn(2, 6, 2, generator=g)
+    outs = []
+    for fn, dev in ((_reference_dense, 'cpu'), (prepare_dense_correspondences, backend)):
+        lg = logits.detach().clone().to(dev).requires_grad_(True)
+        _, x2d, w2d = fn(None, None, lg, None, box.to(dev), inds.to(dev), 'mean_exp')
+        (w2d * up.to(dev)).sum().backward()
+        outs.append((x2d.cpu(), w2d.detach().cpu(), lg.grad.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(outs[1][2], outs[0][2], rtol=1e-4, atol=1e-6)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Fused dense correspondence pre-processing vs the PyTorch composite of EPro-PnP-6DoF/lib/train.py:141-166 on the GPU
+(LineMOD shape: 32 objects, 64x64 maps, 512 sampled pixels), forward + backward."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'epro-pnp_amd'))
+from epropnp.preprocess import _reference_dense, box_grid_params, prepare_dense_correspondences  # noqa: E402
+
+
+def main():
+    dev = torch.device('cuda:0')
+    B, H, W, N = 32, 64, 64, 512
+    g = torch.Generator(device=dev).manual_seed(0)
+    noc = torch.rand(B, 3, H, W, generator=g, device=dev) - 0.5
+    dim = torch.rand(B, 3, generator=g, device=dev) + 0.5
+    logits = torch.randn(B, 2, H, W, generator=g, device=dev)
+    scale = torch.rand(B, 2, generator=g, device=dev) + 1
+    box = box_grid_params(torch.rand(B, 2, device=dev) * 400 + 100, torch.rand(B, device=dev) * 100 + 64, W)
+    rs = np.random.RandomState(0)
+    inds = torch.tensor(np.stack([rs.choice(H * W, size=N, replace=False) for _ in range(B)]), device=dev)
+    up_x, up_w = torch.randn(B, N, 3, device=dev), torch.randn(B, N, 2, device=dev)
+
+    def step(fn):
+        ins = [t.clone().requires_grad_(True) for t in (noc, dim, logits, scale)]
+        x3d, x2d, w2d = fn(*ins, box, inds, 'mean_exp')
+        ((x3d * up_x).sum() + (w2d * up_w).sum()).backward()
+        return x3d, x2d, w2d, [t.grad for t in ins]
+
+    out = {}
+    for name, fn in (('torch_composite', _reference_dense), ('fused', prepare_dense_correspondences)):
+        for _ in range(10):
+            res = step(fn)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            step(fn)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name + '_ms'] = round(e0.elapsed_time(e1) / 100, 4)
+        out[name] = res
+    a, b = out.pop('torch_composite'), out.pop('fused')
+    out['x2d_bit_exact'] = bool(torch.equal(a[1], b[1]))
+    out['max_abs_diff'] = max(float((p - q).abs().max()) for p, q in zip([a[0], a[2]] + a[3], [b[0], b[2]] + b[3]))
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
