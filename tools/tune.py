@@ -66,10 +66,10 @@ def worker(B, N, S, K, L, reps=8):
 VARIANTS = [
     ('default', {}),
 ]
-# TUNE_VARIANTS="name:KEY=VAL,KEY=VAL;name2:KEY=VAL" adds env variants without editing this file
+# TUNE_VARIANTS="name:KEY=VAL+KEY=VAL;name2:KEY=VAL" adds env variants without editing this file
 for _spec in filter(None, os.environ.get('TUNE_VARIANTS', '').split(';')):
     _name, _, _kv = _spec.partition(':')
-    VARIANTS.append((_name, dict(kv.split('=', 1) for kv in _kv.split(',') if kv)))
+    VARIANTS.append((_name, dict(kv.split('=', 1) for kv in _kv.split('+') if kv)))
 
 
 def main():
