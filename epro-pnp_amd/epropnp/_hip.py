@@ -129,15 +129,20 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)     # hipStream_t as an int, without a Stream object
+
+
 def stream_of(t):
     if _emulated:
         return None
-    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+    idx, cur = t.device.index, torch.cuda.current_device()
+    if idx is not None and idx != cur:
         # kernels are launched on the calling thread's current device: a foreign stream would fail inside HIP
-        raise RuntimeError(f'epropnp: tensors live on {t.device} but the current device is '
-                           f'cuda:{torch.cuda.current_device()}; call torch.cuda.set_device({t.device.index}) '
-                           f'(one process per GPU, as under torch.distributed)')
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        raise RuntimeError(f'epropnp: tensors live on {t.device} but the current device is cuda:{cur}; call '
+                           f'torch.cuda.set_device({idx}) (one process per GPU, as under torch.distributed)')
+    if _raw_stream is not None:
+        return _raw_stream(cur)
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def call(fn_name, *args):
