@@ -105,9 +105,10 @@ class EProPnPBase(torch.nn.Module):
         if pose_init is not None and num_obj > 0:
             cost_init_value = hip.evaluate_cost(prob, pose_init)
 
-        pose_opt, pose_cov, cost, pose_opt_plus = self.solver(
-            x3d, x2d, w2d, camera, cost_fun, pose_init=pose_init, cost_init=cost_init_value, with_pose_cov=True,
-            force_init_solve=force_init_solve, normalize_override=False, **kwargs)
+        with hip.share_problem(prob, x3d, x2d, w2d, camera, cost_fun):
+            pose_opt, pose_cov, cost, pose_opt_plus = self.solver(
+                x3d, x2d, w2d, camera, cost_fun, pose_init=pose_init, cost_init=cost_init_value, with_pose_cov=True,
+                force_init_solve=force_init_solve, normalize_override=False, **kwargs)
 
         if num_obj > 0:
             delta = cost_fun.delta

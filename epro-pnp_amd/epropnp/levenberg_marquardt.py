@@ -55,7 +55,7 @@ class LMSolver(nn.Module):
             if x2d.dim() == 3 and x2d.size(0) > 0 and not pose_opt.requires_grad and \
                     _hip.on_hip_path(x3d, x2d, w2d, pose_opt):
                 # Gauss-Newton step + pose_add in one kernel each way (csrc/gn_step_kernel.hip)
-                prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+                prob = hip.problem(x3d, x2d, w2d, camera, cost_fun, self.dof)
                 delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
                 pose_opt_plus = hip.pose_opt_plus(x3d, x2d, w2d, delta, prob, pose_opt, self.eps)
             else:
@@ -86,7 +86,7 @@ class LMSolver(nn.Module):
                 return (torch.empty((0, pose_len), **kw),
                         torch.empty((0, self.dof, self.dof), **kw) if with_pose_cov else None,
                         torch.empty((0,), **kw) if with_cost else None)
-            prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+            prob = hip.problem(x3d, x2d, w2d, camera, cost_fun, self.dof)
             if pose_init is None or force_init_solve:
                 assert self.init_solver is not None
                 if pose_init is None:
@@ -108,7 +108,7 @@ class LMSolver(nn.Module):
         On HIP tensors: fused forward / backward kernels (csrc/gn_step_kernel.hip); otherwise the PyTorch composite."""
         from . import _hip
         if x2d.dim() == 3 and x2d.size(0) > 0 and not pose.requires_grad and _hip.on_hip_path(x3d, x2d, w2d, pose):
-            prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+            prob = hip.problem(x3d, x2d, w2d, camera, cost_fun, self.dof)
             delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
             return hip.gn_step(x3d, x2d, w2d, delta, prob, pose, self.eps)
         residual, _, jac = evaluate_pnp(x3d, x2d, w2d, pose, camera, cost_fun, out_jacobian=True, out_residual=True)
@@ -184,7 +184,7 @@ class RSLMSolver(LMSolver):
             if n <= 16 and 2 <= pn <= hip.RSLM_MAX_POINTS and _hip.on_hip_path(x3d, x2d, w2d) \
                     and not os.environ.get('EPROPNP_RSLM_COMPOSITE'):
                 # one kernel: init translation, sub-sampling, P x B solves, scoring, argmin (csrc/rslm_kernel.hip)
-                prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+                prob = hip.problem(x3d, x2d, w2d, camera, cost_fun, self.dof)
                 if getattr(self.draw, '__func__', None) is RSLMSolver.draw:   # default sampler: device Philox
                     inds, rot = None, None
                 else:                                       # overridden (reproducibility hooks): inject its draws
@@ -215,7 +215,7 @@ class RSLMSolver(LMSolver):
                                         pose_init=pose0.reshape(P * bs, pose_len), **solve_kw)
             pose = pose.reshape(P, bs, pose_len)
             # score every proposal on the full correspondence set (cost-only sweep kernel)
-            prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+            prob = hip.problem(x3d, x2d, w2d, camera, cost_fun, self.dof)
             cost = hip.evaluate_cost(prob, pose)
             min_cost, best = cost.min(dim=0)
             return pose[best, torch.arange(bs, device=pose.device)], None, min_cost

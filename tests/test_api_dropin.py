@@ -311,3 +311,36 @@ def test_camera_view_cache_tracks_the_camera_state(backend):
     cam2.ub = 300.0
     c_b2 = F.evaluate_cost(F.PnPProblem(d['x3d'], d['x2d'], d['w2d'], cam2, cf, 6), pose)
     assert torch.isfinite(c_b).all() and (c_b2 - c_b).abs().max() > 0
+
+
+@pytest.mark.parametrize('dof,rslm,plus', [(6, False, True), (4, True, False), (4, True, True)])
+def test_one_problem_per_monte_carlo_forward(backend, monkeypatch, dof, rslm, plus):
+    """The solver calls under monte_carlo_forward (LM, RSLM initialiser, pose_opt_plus) reuse its PnPProblem; outside of
+    it (or with different objects) they build their own."""
+    from epropnp import functional as F
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+    p = orc.make_problem(5, 40, dof, seed=21)
+    d, cam, cf = make_layer_objects(p, backend, relative_delta=0.5)
+    cf.set_param(d['x2d'], d['w2d'])
+    init = RSLMSolver(dof=dof, num_points=8, num_proposals=4, num_iter=2) if rslm else None
+    layer = (EProPnP6DoF if dof == 6 else EProPnP4DoF)(mc_samples=32, num_iter=4, normalize=(dof == 4),
+                                                       solver=LMSolver(dof=dof, num_iter=3, init_solver=init))
+    built = []
+    real_init = F.PnPProblem.__init__
+
+    def counting_init(self, *a, **k):
+        built.append(1)
+        real_init(self, *a, **k)
+    monkeypatch.setattr(F.PnPProblem, '__init__', counting_init)
+    x3d = d['x3d'].clone().requires_grad_(True)
+    out = layer.monte_carlo_forward(x3d, d['x2d'], d['w2d'], cam, cf, pose_init=d['pose_init'], force_init_solve=rslm,
+                                    with_pose_opt_plus=plus)
+    assert len(built) == 1
+    assert getattr(F._shared, 'entry', None) is None               # nothing outlives the call
+    if plus:
+        out[2].sum().backward()
+        assert bool(torch.isfinite(x3d.grad).all())
+    built.clear()
+    layer.solver.solve(d['x3d'], d['x2d'], d['w2d'], cam, cf, pose_init=d['pose_init'])       # stand-alone: its own
+    assert len(built) == 1
