@@ -39,10 +39,14 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
                                                                      const float* __restrict__ pose_init,
                                                                      const float* __restrict__ g_init, int P16,
                                                                      float* __restrict__ gx3d, float* __restrict__ gx2d,
-                                                                     float* __restrict__ gw2d, float* __restrict__ gdelta) {
+                                                                     float* __restrict__ gw2d, float* __restrict__ gdelta,
+                                                                     int nsplit) {
   constexpr int PL = PoseLen<DOF>::value;
-  const int b = object_of_block(p.B);
-  if (b >= p.B) return;
+  // nsplit > 1 (few objects): an object's point chunks are dealt to nsplit workgroups (v = b * nsplit + part), each with
+  // its own copy of the pose table; per-point gradients are disjoint, grad_delta comes out as nsplit partials per object
+  const int v = object_of_block(p.B * nsplit);
+  if (v >= p.B * nsplit) return;
+  const int b = v / nsplit, part = v - b * nsplit;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), W = T >> 6;
 
   PNP_DYN_SMEM(float, smem);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
               ind3 = (col == 3) ? 1.f : 0.f;
   float gd = 0.f;
   const int chunk_pts = W * NPT * 16;
-  for (int c0 = 0; c0 < p.N; c0 += chunk_pts) {
+  for (int c0 = part * chunk_pts; c0 < p.N; c0 += nsplit * chunk_pts) {
     // this wave's point tiles q = wv + W * i of the chunk; lane = (point column, k)
     float rB[NPT];
     float4 rW[NPT];
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   }
   float one[1] = {gd};
   block_sum<1>(one, red);
-  if (tid == 0) gdelta[b] = one[0];
+  if (tid == 0) gdelta[v] = one[0];
 }
 
 template <class F>
@@ -235,7 +239,7 @@ static int dispatch_bwd_npt(int npt, F&& f) {
 // returns 1 when the shape is not supported (caller falls back to amis_backward_kernel)
 int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
                               int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
-                              float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st) {
+                              float* grad_x2d, float* grad_w2d, float* grad_delta, int nsplit, hipStream_t st) {
   const Problem d = to_device_problem(prob);
   const int P = mc_samples + ((pose_init && grad_cost_init) ? 1 : 0);
   const int P16 = ((P + 15) / 16) * 16 + 16;
@@ -247,8 +251,12 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
   const int ptiles = (d.N + 15) / 16;
   int waves = (d.B < 512 && ptiles > 16) ? 8 : 4, npt = 1;
   while (npt < 4 && waves * npt < ptiles) npt *= 2;
+  if (nsplit > 1) {      // 4 waves x the fewest tiles that still cover N with nsplit chunks in flight
+    waves = 4; npt = 1;
+    while (npt < 4 && waves * npt * nsplit < ptiles) npt *= 2;
+  }
   { int ov[2]; if (env_ints("EPROPNP_BWD_MFMA", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8)) { waves = ov[0]; npt = ov[1]; } }
-  const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
+  const dim3 grid(padded_object_grid(d.B * nsplit)), block(64 * waves);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     return dispatch_bwd_npt(npt, [&](auto NPT) -> int {
       auto kern = amis_backward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
@@ -257,7 +265,7 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
       PNP_LAUNCH(kern, grid, block, smem, st, d, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init, P16,
-                 grad_x3d, grad_x2d, grad_w2d, grad_delta);
+                 grad_x3d, grad_x2d, grad_w2d, grad_delta, nsplit);
       return 0;
     });
   });

@@ -375,6 +375,26 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   return check_launch("amis_forward_kernel");
 }
 
+// Few objects: one object's S x N point-poses keep a single CU busy for ~70 us at 512 x 512 whatever the wave count, so
+// the point chunks of an object are dealt to `nsplit` workgroups (each builds the pose table for itself).  The per-point
+// gradients are disjoint and bit-identical to the unsplit kernel; grad_delta comes back as (B, nsplit) partials for the
+// caller to add in a fixed order (no atomics: results stay reproducible).
+int launch_amis_backward_split(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                               int mc_samples, const float* pose_init, const float* grad_cost_init, int nsplit,
+                               float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta_parts, hipStream_t st) {
+  if (int rc = check_problem(prob)) return rc;
+  if (prob->num_obj == 0 || prob->num_pts == 0) return EPROPNP_OK;
+  if (mc_samples < 0) return fail(EPROPNP_EINVAL, "amis_backward_split: negative mc_samples");
+  if ((mc_samples > 0 && (!pose_samples || !grad_logweights)) || !grad_x3d || !grad_x2d || !grad_w2d || !grad_delta_parts)
+    return fail(EPROPNP_EINVAL, "amis_backward_split: NULL pointer");
+  if (nsplit < 1 || nsplit > 16 || (long long)nsplit * 64 > (long long)((prob->num_pts + 63) / 64) * 64)
+    return fail(EPROPNP_EINVAL, "amis_backward_split: nsplit %d not in [1, min(16, ceil(num_pts / 64))]", nsplit);
+  const int rc = launch_amis_backward_mfma(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init,
+                                           grad_x3d, grad_x2d, grad_w2d, grad_delta_parts, nsplit, st);
+  if (rc == 1) return fail(EPROPNP_EINVAL, "amis_backward_split: mc_samples %d does not fit the LDS pose table", mc_samples);
+  return rc;
+}
+
 int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
                          int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
                          float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st) {
@@ -388,7 +408,7 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
     const char* impl = getenv("EPROPNP_BWD_IMPL");
     if (!(impl && impl[0] == 'v')) {
       const int rc = launch_amis_backward_mfma(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init,
-                                               grad_x3d, grad_x2d, grad_w2d, grad_delta, st);
+                                               grad_x3d, grad_x2d, grad_w2d, grad_delta, 1, st);
       if (rc <= 0) return rc;     // 1 = shape not supported there (pose table larger than LDS)
     }
   }

@@ -48,6 +48,14 @@ int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples
                                    grad_x2d, grad_w2d, grad_delta, (hipStream_t)stream);
 }
 
+int epropnp_amis_backward_split(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                                int32_t mc_samples, const float* pose_init, const float* grad_cost_init, int32_t num_split,
+                                float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta_parts, void* stream) {
+  return pnp::launch_amis_backward_split(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init,
+                                         num_split, grad_x3d, grad_x2d, grad_w2d, grad_delta_parts, (hipStream_t)stream);
+}
+
+
 int epropnp_adaptive_delta(const float* x2d, const float* w2d, int32_t num_obj, int32_t num_pts, float relative_delta,
                            float* delta, float* stats, void* stream) {
   return pnp::launch_adaptive_delta(x2d, w2d, num_obj, num_pts, relative_delta, delta, stats, (hipStream_t)stream);

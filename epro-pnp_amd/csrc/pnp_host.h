@@ -86,7 +86,7 @@ int launch_normal_equations(const epropnp_problem* prob, const float* pose, int 
                             float* cost, hipStream_t st);
 int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
                               int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
-                              float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);
+                              float* grad_x2d, float* grad_w2d, float* grad_delta, int nsplit, hipStream_t st);
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
                       unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
                       float* pose_out, float* cost_out, hipStream_t st);
@@ -126,6 +126,9 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
 int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
                              const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
                              float* proposals, hipStream_t st);
+int launch_amis_backward_split(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                               int mc_samples, const float* pose_init, const float* grad_cost_init, int nsplit,
+                               float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta_parts, hipStream_t st);
 int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
                          int mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
                          float* grad_x2d, float* grad_w2d, float* grad_delta, hipStream_t st);

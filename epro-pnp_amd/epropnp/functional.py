@@ -3,6 +3,7 @@
 Everything here runs on the current HIP stream of the input tensors' device; nothing synchronises.
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -168,7 +169,25 @@ def amis_forward(prob, pose_opt, pose_cov, mc_samples, num_iter, eps=1e-5, acg_m
     return (samples, logw, props) if with_proposals else (samples, logw)
 
 
-def amis_backward(prob, pose_samples, grad_logweights, pose_init=None, grad_cost_init=None):
+BWD_SPLIT_MAX_SAMPLES = 2600     # the split kernel needs the LDS-resident pose table (csrc/amis_backward_mfma.hip)
+
+
+def backward_split(B, N, S):
+    """Workgroups per object for the backward sweep.  One object's S x N point-poses occupy a single CU (~70 us at
+    512 x 512); below ~256 objects the point chunks of an object are dealt to several workgroups so the whole chip works
+    (B = 32, N = 512: 8 workgroups of 64 points).  1 = the ordinary kernel."""
+    env = os.environ.get('EPROPNP_BWD_SPLIT')
+    if env is not None:
+        return max(1, int(env))
+    if S > BWD_SPLIT_MAX_SAMPLES or B >= 256 or os.environ.get('EPROPNP_BWD_IMPL', '')[:1] == 'v':
+        return 1
+    n = 1
+    while n < 8 and 2 * n * B <= 512 and 2 * n * 64 <= N:
+        n *= 2
+    return n
+
+
+def amis_backward(prob, pose_samples, grad_logweights, pose_init=None, grad_cost_init=None, nsplit=None):
     """-> grad_x3d (B,N,3), grad_x2d (B,N,2), grad_w2d (B,N,2), grad_delta (B,)."""
     B, N = prob.B, prob.N
     S = 0 if pose_samples is None else pose_samples.shape[0]
@@ -177,7 +196,14 @@ def amis_backward(prob, pose_samples, grad_logweights, pose_init=None, grad_cost
     pin = gin = None
     if pose_init is not None and grad_cost_init is not None:
         pin, gin = _f32c(pose_init, 'pose_init'), _f32c(grad_cost_init, 'grad_cost_init')
-    gx3d, gx2d, gw2d, gdel = prob.new(B, N, 3), prob.new(B, N, 2), prob.new(B, N, 2), prob.new(B)
+    gx3d, gx2d, gw2d = prob.new(B, N, 3), prob.new(B, N, 2), prob.new(B, N, 2)
+    nsplit = backward_split(B, N, S) if nsplit is None else int(nsplit)
+    if nsplit > 1:
+        parts = prob.new(B, nsplit)
+        _hip.call('epropnp_amis_backward_split', C.byref(prob.c), _hip.ptr(smp), _hip.ptr(glw), S, _hip.ptr(pin),
+                  _hip.ptr(gin), nsplit, _hip.ptr(gx3d), _hip.ptr(gx2d), _hip.ptr(gw2d), _hip.ptr(parts), prob.stream)
+        return gx3d, gx2d, gw2d, parts.sum(dim=1)
+    gdel = prob.new(B)
     _hip.call('epropnp_amis_backward', C.byref(prob.c), _hip.ptr(smp), _hip.ptr(glw), S, _hip.ptr(pin), _hip.ptr(gin),
               _hip.ptr(gx3d), _hip.ptr(gx2d), _hip.ptr(gw2d), _hip.ptr(gdel), prob.stream)
     return gx3d, gx2d, gw2d, gdel

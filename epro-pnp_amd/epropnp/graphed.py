@@ -4,8 +4,8 @@ The launch-bound shapes of the reference (EPro-PnP-6DoF trains on 32 objects per
 in the Python / dispatcher path than on the GPU: ~25 launches of 5-150 us each.  The step has no host round trip, so the
 whole segment -- `cost_fun.set_param` -> `monte_carlo_forward` -> loss -> backward to the layer inputs -- can be recorded
 into a hipGraph (`torch.cuda.CUDAGraph` on ROCm) and replayed in one submission.  `GraphedLoss` packages that recipe as
-a differentiable op; with new input tensors copied in on every call it takes 0.31 -> 0.24 ms at 32 x 512 points and
-0.44 -> 0.22 ms at 600 x 128 (4-DoF, RSLM) (`tools/bench_graphed.py`).  It does not pay where the GPU is the bottleneck
+a differentiable op; with new input tensors copied in on every call it takes 0.38 -> 0.18 ms at 32 x 512 points and
+0.57 -> 0.22 ms at 600 x 128 (4-DoF, RSLM) (`tools/bench_graphed.py`).  It does not pay where the GPU is the bottleneck
 (4096 x 512: the input copies cost more than the launches saved):
 
     layer = EProPnP6DoF(...)

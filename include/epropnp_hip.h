@@ -119,6 +119,16 @@ int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples
                           int32_t mc_samples, const float* pose_init, const float* grad_cost_init,
                           float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream);
 
+/* The same backward for FEW objects (a single CU is busy ~70 us with one object's 512 x 512 point-poses): the point
+ * chunks of an object are dealt to `num_split` workgroups.  grad_x3d / grad_x2d / grad_w2d are bit-identical to
+ * epropnp_amis_backward; grad_delta comes back as partials
+ *   grad_delta_parts (B, num_split)   with   grad_delta[b] = sum_c grad_delta_parts[b, c]
+ * for the caller to add in a fixed order (no atomics).  1 <= num_split <= min(16, ceil(num_pts / 64)); needs the
+ * LDS-resident pose table (mc_samples <~ 2700), EPROPNP_EINVAL otherwise. */
+int epropnp_amis_backward_split(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
+                                int32_t mc_samples, const float* pose_init, const float* grad_cost_init, int32_t num_split,
+                                float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta_parts, void* stream);
+
 /* AdaptiveHuberPnPCost.set_param (epropnp/cost_fun.py:123-126):
  *   delta[b] = mean(w2d[b]) * sqrt(sum_xy var_N(x2d[b])) * relative_delta      (unbiased variance)
  * x2d (B,N,2), w2d (B,N,2) -> delta (B,), stats (B,4) = [mean_w, x2d_std, mean_x, mean_y] (kept for the backward,

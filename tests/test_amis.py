@@ -147,6 +147,37 @@ def test_backward_matches_autograd_of_oracle_at_fixed_samples(backend, monkeypat
             assert _rel(mine.cpu(), ref) <= 2e-4, (dof, bounds, _rel(mine.cpu(), ref))
 
 
+@pytest.mark.parametrize('dof,bounds,N,S', [(6, None, 300, 70), (4, 'tight', 128, 33), (6, 'tight', 512, 40)])
+def test_backward_split_over_workgroups(backend, dof, bounds, N, S):
+    """Few objects: the point chunks of an object dealt to several workgroups (epropnp_amis_backward_split).  Per-point
+    gradients are bit-identical to the one-workgroup kernel, grad_delta (added from per-workgroup partials) to rounding."""
+    from epropnp import functional as F
+    B = 3
+    prob = orc.make_problem(B, N, dof, seed=13, bounds=bounds)
+    g = torch.Generator().manual_seed(6)
+    poses = prob['pose_gt'].unsqueeze(0).repeat(S, 1, 1)
+    poses[..., :3] += 0.2 * torch.randn(S, B, 3, generator=g)
+    if dof == 6:
+        q = poses[..., 3:] + 0.1 * torch.randn(S, B, 4, generator=g)
+        poses[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+    else:
+        poses[..., 3] += 0.3 * torch.randn(S, B, generator=g)
+    g_logw, g_init = torch.randn(S, B, generator=g), torch.randn(B, generator=g)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    args = (hp, poses.to(backend), g_logw.to(backend), p['pose_init'], g_init.to(backend))
+    one = F.amis_backward(*args, nsplit=1)
+    assert F.backward_split(32, 512, 512) == 8 and F.backward_split(600, 128, 128) == 1 and F.backward_split(4096, 512, 512) == 1
+    assert F.backward_split(32, 512, 4096) == 1 and F.backward_split(2, 64, 64) == 1
+    for nsplit in sorted(n for n in {2, 3, min(8, (N + 63) // 64)} if n <= (N + 63) // 64):
+        many = F.amis_backward(*args, nsplit=nsplit)
+        for a, b in zip(many[:3], one[:3]):
+            assert torch.equal(a, b), nsplit
+        assert _rel(many[3].cpu(), one[3].cpu()) <= 1e-5
+    with pytest.raises(RuntimeError, match='nsplit'):
+        F.amis_backward(*args, nsplit=(N + 63) // 64 + 1)
+
+
 def test_philox_sampler_statistics(backend):
     """Production mode (on-device Philox): loss agrees with the injected-noise oracle within Monte-Carlo error,
     and two calls draw different samples."""
