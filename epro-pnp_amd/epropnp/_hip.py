@@ -37,7 +37,6 @@ class AmisParams(C.Structure):
 
 ABI_VERSION = 2
 _lib = None
-_emulated = False     # True only when a test installed the CPU logic-emulation build (tests/emu)
 
 
 def _declare(lib):
@@ -99,31 +98,14 @@ def lib():
     return _lib
 
 
-def _use_emulation_library(path):
-    """TESTS ONLY: route calls to the CPU logic-emulation build of the same kernel sources (tests/emu).
-    Never called by product code; lets `pytest -m "not gpu"` exercise kernel + host logic without a GPU."""
-    global _lib, _emulated
-    _lib = _declare(C.CDLL(path)) if path else None
-    _emulated = bool(path)
-
-
-def is_emulated():
-    return _emulated
-
-
 def check_device(t, name):
-    if _emulated:
-        if t.is_cuda:
-            raise RuntimeError('emulation library installed but a device tensor was passed')
-        return
     if not t.is_cuda:
         raise RuntimeError(f'{name} must live on a HIP device (got {t.device}); the EPro-PnP HIP path has no CPU fallback')
 
 
 def on_hip_path(*tensors):
-    """True when the fused kernels can serve these tensors: fp32 on a HIP device (or the test-only emulation)."""
-    ok = all(t.dtype == torch.float32 for t in tensors)
-    return ok and (all(t.is_cuda for t in tensors) or (_emulated and not any(t.is_cuda for t in tensors)))
+    """True when the fused kernels can serve these tensors: fp32 on a HIP device."""
+    return all(t.dtype == torch.float32 and t.is_cuda for t in tensors)
 
 
 def ptr(t):
@@ -134,8 +116,6 @@ _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)     # hipStre
 
 
 def stream_of(t):
-    if _emulated:
-        return None
     idx, cur = t.device.index, torch.cuda.current_device()
     if idx is not None and idx != cur:
         # kernels are launched on the calling thread's current device: a foreign stream would fail inside HIP

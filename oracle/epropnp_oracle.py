@@ -706,6 +706,51 @@ def run_mc(prob, noise, dof, mc_samples, num_iter, lm_iter, normalize=False, rel
     return {k: v.detach().clone() for k, v in res.items()}
 
 
+def perturb_inputs(prob, seed, ulps=3):
+    """The same problem with every input (x3d, x2d, w2d, pose_init) moved by a random whole number of ulps in
+    [-ulps, ulps] (relative 2^-23 steps).  Rounding-level: what separates two correct fp32 implementations."""
+    g = torch.Generator().manual_seed(seed)
+    out = dict(prob)
+    for k in ('x3d', 'x2d', 'w2d', 'pose_init'):
+        v = prob[k]
+        kk = torch.randint(-ulps, ulps + 1, v.shape, generator=g).to(v.dtype)
+        out[k] = v * (1 + kk * 2.0 ** -23)
+    return out
+
+
+SPREAD_KEYS = {  # key -> (object dim, relative to the object's largest magnitude?)
+    'pose_opt': (0, False), 'cost': (0, True), 'cost_init': (0, True), 'loss_obj': (0, False),
+    'pose_cov': (0, True), 'gx3d': (0, True), 'gx2d': (0, True), 'gw2d': (0, True), 'pose_opt_plus': (0, False)}
+
+
+def per_object_diff(a, b, key):
+    """max |a - b| over everything but the object axis; relative to max |b| of the object for the keys marked so."""
+    od, rel = SPREAD_KEYS[key]
+    d = (a.double() - b.double()).abs().movedim(od, 0)
+    d = d.reshape(d.shape[0], -1).amax(1)
+    if rel:
+        m = b.double().abs().movedim(od, 0)
+        d = d / m.reshape(m.shape[0], -1).amax(1).clamp(min=1e-30)
+    return d.float()
+
+
+def rounding_spread(run, prob, base, trials=8, ulps=3, seed=1000, extra=()):
+    """How far `run(problem)` (a fp32 implementation of the path) moves, per object, when its inputs move by a few
+    ulps: max over `trials` perturbed runs (and over the already-computed results in `extra`, e.g. the fp64 run) of
+    |output - base|.  Two correct fp32 implementations differ by rounding-level perturbations inside the algorithm,
+    so this is the yardstick the parity tests add to the north-star bars: it is large exactly where the reference
+    itself is ill-conditioned (trust-region accept/reject flips at convergence, flat LM valleys, the cond-1e5 4x4
+    proposal fits) and ~0 elsewhere.  -> {key: (B,) tensor}"""
+    keys = [k for k in SPREAD_KEYS if k in base and base[k] is not None]
+    sp = {k: torch.zeros(base[k].shape[SPREAD_KEYS[k][0]]) for k in keys}
+    outs = [run(perturb_inputs(prob, seed + t, ulps)) for t in range(trials)] + list(extra)
+    for o in outs:
+        for k in keys:
+            if k in o and o[k] is not None:
+                sp[k] = torch.maximum(sp[k], per_object_diff(o[k], base[k], k))
+    return sp
+
+
 def make_rslm_noise(prob, dof, num_points, num_proposals, seed=2):
     """Sub-sample indices (weighted, without replacement: levenberg_marquardt.py:305-308) and random initial
     rotations (:318-326) for the RSLM initialiser."""

@@ -94,8 +94,12 @@ def case_lm(name, dof, B, N, lm_iter, fast_mode, bounds, seed):
     d_pose, d_cov, d_cost, _ = orc.lm_solve(p64['x3d'], p64['x2d'], p64['w2d'], cam_of(p64), p64['delta'],
                                             p64['pose_init'], fast_mode=fast_mode, with_pose_cov=True,
                                             with_cost=True, num_iter=lm_iter)
+    # rounding-level spread of the REFERENCE itself (inputs moved by <= 3 ulp, + its fp64 run): the tests' yardstick
+    base = dict(pose_opt=r_pose, pose_cov=r_cov, cost=r_cost)
+    spread = orc.rounding_spread(lambda q: dict(zip(('pose_opt', 'pose_cov', 'cost'), ref.run_lm(q, dof, lm_iter, fast_mode))),
+                                 prob, base, extra=[dict(pose_opt=d_pose, pose_cov=d_cov, cost=d_cost)])
     save(name, prob=prob, pose_opt=r_pose, pose_cov=r_cov, cost=r_cost, pose_opt64=d_pose, pose_cov64=d_cov,
-         cost64=d_cost, dof=dof, lm_iter=lm_iter, fast_mode=int(fast_mode),
+         cost64=d_cost, dof=dof, lm_iter=lm_iter, fast_mode=int(fast_mode), spread=spread,
          accepts=torch.stack(hist).to(torch.int32) if hist else torch.zeros(0, B, dtype=torch.int32))
 
 
@@ -125,6 +129,10 @@ def case_mc(name, dof, B, N, S, K, lm_iter, seed, normalize=False, rslm=None, wi
     extra = {}
     if rn is not None:
         extra['rslm'] = rn
+    # rounding-level spread of the REFERENCE itself (inputs moved by <= 3 ulp, + the fp64 run): the tests' yardstick
+    extra['spread'] = orc.rounding_spread(
+        lambda q: ref.run_mc(q, noise, dof, S, K, lm_iter, normalize=normalize, rslm=rslm, rslm_noise=rn,
+                             with_pose_opt_plus=with_pose_opt_plus), prob, r, extra=[o64])
     save(name, prob=prob, noise=noise, ref=r, o64={k: v.float() for k, v in o64.items()}, dof=dof, S=S, K=K,
          lm_iter=lm_iter, normalize=int(normalize), with_pose_opt_plus=int(with_pose_opt_plus),
          rslm_cfg=np.array([rslm['num_points'], rslm['num_proposals'], rslm['num_iter']] if rslm else [0, 0, 0]),

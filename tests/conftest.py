@@ -5,7 +5,8 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, 'epro-pnp_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests'), ROOT):
+for p in (os.path.join(ROOT, 'epro-pnp_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests'),
+          os.path.join(ROOT, 'tests', 'emu'), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -33,12 +34,12 @@ def _emu_lib():
 def backend(request):
     """'hip': the real library on cuda:0.  'emu': the same kernel sources compiled for the CPU fiber emulator
     (tests/emu) -- exercises kernel logic + host glue where no GPU exists; never a product path."""
-    from epropnp import _hip
+    import install as emu          # tests/emu/install.py: monkeypatches the product binding from the outside
     if request.param == 'hip':
         assert torch.cuda.is_available(), 'gpu test selected but no HIP device is visible'
-        _hip._use_emulation_library(None)
+        emu.uninstall()
         yield torch.device('cuda:0')
     else:
-        _hip._use_emulation_library(_emu_lib())
+        emu.install(_emu_lib())
         yield torch.device('cpu')
-        _hip._use_emulation_library(None)
+        emu.uninstall()

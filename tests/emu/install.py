@@ -1,0 +1,41 @@
+"""TEST INFRASTRUCTURE: route the package's ctypes binding to the CPU logic-emulation build of the kernel sources.
+
+The product binding (epro-pnp_amd/epropnp/_hip.py) knows nothing about emulation: it loads libepropnp_hip.so and
+refuses tensors that are not on a HIP device.  `install(path)` monkeypatches that module from the outside -- the
+loaded library handle and the three device predicates -- so that `pytest -m "not gpu"` can drive kernel + host
+logic on CPU tensors; `uninstall()` restores the originals.  Nothing under epro-pnp_amd/ imports this file.
+"""
+import ctypes as C
+
+import torch
+
+_saved = {}
+
+
+def installed():
+    return bool(_saved)
+
+
+def install(path):
+    from epropnp import _hip
+    if _saved:
+        uninstall()
+    for name in ('_lib', 'check_device', 'on_hip_path', 'stream_of'):
+        _saved[name] = getattr(_hip, name)
+
+    def check_device(t, name):
+        if t.is_cuda:
+            raise RuntimeError('emulation library installed but a device tensor was passed')
+
+    def on_hip_path(*tensors):
+        return all(t.dtype == torch.float32 and not t.is_cuda for t in tensors)
+
+    _hip._lib = _hip._declare(C.CDLL(path))
+    _hip.check_device, _hip.on_hip_path, _hip.stream_of = check_device, on_hip_path, (lambda t: None)
+
+
+def uninstall():
+    from epropnp import _hip
+    for name, v in _saved.items():
+        setattr(_hip, name, v)
+    _saved.clear()

@@ -5,9 +5,11 @@ import pytest
 import torch
 
 import epropnp_oracle as orc
-from helpers import load_golden, make_layer_objects, pack_noise
+from helpers import assert_within_spread, load_golden, make_layer_objects, pack_noise, rel_per_object
 
+POSE_TOL = 1e-4     # north-star tolerance on the pose
 KL_TOL = 1e-3       # north-star tolerance on the Monte-Carlo (KL) loss
+GRAD_TOL = 2e-4     # backward kernel vs autograd of the oracle at fixed samples (test below) holds this bar outright
 
 
 def _layer(dof, S, K, lm_iter, normalize=False, rslm=None):
@@ -43,30 +45,23 @@ def test_monte_carlo_forward_backward_matches_reference(backend, name):
     g = load_golden(name)
     dof, S, K = int(g['dof']), int(g['S']), int(g['K'])
     r = run_layer(backend, g['prob'], g['noise'], dof, S, K, int(g['lm_iter']), normalize=bool(g['normalize']))
-    ref, o64 = g['ref'], g['o64']
-    # how far the reference's own fp32 arithmetic is from fp64 on this input (the AMIS proposal fit inverts
-    # 4x4 matrices of condition ~1e5 in fp32): a second correct implementation cannot be closer than that
-    drift = (ref['loss_obj'] - o64['loss_obj']).abs().max().item()
-    # pose: 1e-4, except where a marginal trust-region step flipped at convergence (see tests/test_lm_solver.py):
-    # there the two LM runs must have reached the same cost
-    pose_err = (r['pose_opt'] - ref['pose_opt']).abs().max(-1).values
-    pose_drift = (ref['pose_opt'] - o64['pose_opt']).abs().max(-1).values
-    same_cost = (r['cost'] - ref['cost']).abs() <= 1e-5 * ref['cost'].abs().clamp(min=1.0)
-    assert bool(((pose_err <= 1e-4 + 2 * pose_drift) | same_cost).all()), (pose_err, r['cost'], ref['cost'])
-    assert bool((pose_err <= 2e-3).all())
+    ref, o64, sp = g['ref'], g['o64'], g['spread']
+    # Yardstick for every bar below: `spread` = how far the REFERENCE's own fp32 result moves, per object, when its
+    # inputs move by <= 3 ulp, plus its fp32-vs-fp64 drift (oracle/make_golden.py, orc.rounding_spread).  It is ~1e-6
+    # for well-conditioned objects and large exactly where the reference is ill-conditioned: a trust-region
+    # accept/reject decision on a knife edge (mc4_norm: 2.8e-4 on the pose), a flat LM valley under clip_jac whose
+    # 3e-5 pose ambiguity moves proposal 0 and, through the cond-1e5 AMIS refits, the loss by 1.4e-3 (mc6_tight).
+    # Errors and spreads are matched by rank over the objects (helpers.assert_within_spread).
+    assert_within_spread((r['pose_opt'] - ref['pose_opt']).abs().max(-1).values, sp['pose_opt'], POSE_TOL, what='pose_opt')
+    assert_within_spread((r['cost'] - ref['cost']).abs() / ref['cost'].abs().clamp(min=1e-30), sp['cost'], 1e-5, what='cost')
     torch.testing.assert_close(r['cost_init'], ref['cost_init'], rtol=2e-5, atol=1e-5)
-    # KL / Monte-Carlo loss: per object and batch mean
-    # mc6_tight: with most projections clamped (clip_jac zeroes their Jacobian rows) one object's LM valley is flat --
-    # pose_opt agrees with the reference to 3e-5 at equal cost, which already moves proposal 0 and, through the AMIS
-    # refits, that object's loss by 1.4e-3; the batch mean (what training sees) stays within the 1e-3 bar
-    per_obj = (2.5e-3 if name == 'mc6_tight' else KL_TOL) + 2 * drift
-    assert (r['loss_obj'] - ref['loss_obj']).abs().max().item() <= per_obj
+    # KL / Monte-Carlo loss: per object, and the batch mean (what training sees) strictly within the north-star bar
+    assert_within_spread((r['loss_obj'] - ref['loss_obj']).abs(), sp['loss_obj'], KL_TOL, what='loss_obj')
     assert abs(r['loss_obj'].mean().item() - ref['loss_obj'].mean().item()) <= KL_TOL
-    assert (r['loss_obj'] - o64['loss_obj']).abs().max().item() <= per_obj
-    # gradients of the loss (dominated by the highest-weight samples)
-    gdrift = {k: _rel(ref[k], o64[k]) for k in ('gx3d', 'gx2d', 'gw2d')}
+    assert abs(r['loss_obj'].mean().item() - o64['loss_obj'].mean().item()) <= KL_TOL
+    # gradients of the loss, per object relative to the object's largest entry
     for k in ('gx3d', 'gx2d', 'gw2d'):
-        assert _rel(r[k], ref[k]) <= 5e-3 + 3 * gdrift[k], (k, _rel(r[k], ref[k]), gdrift[k])
+        assert_within_spread(rel_per_object(r[k], ref[k]), sp[k], GRAD_TOL, what=k)
     assert (r['pose_samples'] - ref['pose_samples']).abs().max().item() <= 2e-2
 
 

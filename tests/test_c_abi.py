@@ -58,7 +58,8 @@ def test_product_path_refuses_cpu_tensors():
     from epropnp.camera import PerspectiveCamera
     from epropnp.cost_fun import HuberPnPCost
     from epropnp.levenberg_marquardt import LMSolver
-    _hip._use_emulation_library(None)
+    import install as emu
+    emu.uninstall()
     z = torch.zeros
     with pytest.raises(RuntimeError, match='HIP device'):
         LMSolver(dof=6, num_iter=1).solve(z(2, 8, 3), z(2, 8, 2), z(2, 8, 2), PerspectiveCamera(cam_mats=torch.eye(3).expand(2, 3, 3)),

@@ -10,8 +10,8 @@ pytestmark = pytest.mark.gpu
 
 def test_fit_identity_training_reduces_pose_error():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'demo'))
-    from epropnp import _hip
-    _hip._use_emulation_library(None)
+    import install as emu
+    emu.uninstall()
     import fit_identity
     before, after = fit_identity.train(iters=250, batch=256, verbose=False)
     assert after[0] < 0.5 * before[0], (before, after)        # translation error halves within 250 steps

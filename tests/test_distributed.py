@@ -42,7 +42,8 @@ def _worker(rank, world, port, dof, ret):
         import conftest
         from epropnp import _hip, sharding
         from epropnp.losses import MonteCarloPoseLoss
-        _hip._use_emulation_library(conftest._emu_lib())
+        import install as emu
+        emu.install(conftest._emu_lib())
         B, N, S, K = 5, 48, 32, 2          # 5 objects over 2 ranks: uneven tail
         prob = orc.make_problem(B, N, dof, seed=40)
         noise = pack_noise(orc.make_noise(B, S, K, dof, seed=41), dof)

@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope='module')
 def dev():
-    from epropnp import _hip
+    import install as emu
     assert torch.cuda.is_available()
-    _hip._use_emulation_library(None)
+    emu.uninstall()
     return torch.device('cuda:0')
 
 

@@ -56,19 +56,19 @@ def _check(backend, B, N, dof, bounds, seed, behind, zero_w):
        bounds=st.sampled_from([None, 'tensor', 'tight']), seed=st.integers(0, 10_000), behind=st.booleans(),
        zero_w=st.booleans())
 def test_sweep_kernels_random_shapes(B, N, dof, bounds, seed, behind, zero_w):
-    from epropnp import _hip
     import conftest
-    _hip._use_emulation_library(conftest._emu_lib())
+    import install as emu
+    emu.install(conftest._emu_lib())
     try:
         _check(torch.device('cpu'), B, N, dof, bounds, seed, behind, zero_w)
     finally:
-        _hip._use_emulation_library(None)
+        emu.uninstall()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,N,dof,bounds,behind,zero_w', [(3, 17, 6, 'tight', True, True), (2, 257, 4, None, True, False),
                                                           (4, 5, 4, 'tensor', False, False), (1, 1000, 6, 'tight', True, True)])
 def test_sweep_kernels_edge_shapes_gpu(B, N, dof, bounds, behind, zero_w):
-    from epropnp import _hip
-    _hip._use_emulation_library(None)
+    import install as emu
+    emu.uninstall()
     _check(torch.device('cuda:0'), B, N, dof, bounds, 123, behind, zero_w)

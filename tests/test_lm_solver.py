@@ -3,7 +3,7 @@ import pytest
 import torch
 
 import epropnp_oracle as orc
-from helpers import load_golden, make_layer_objects
+from helpers import assert_within_spread, load_golden, make_layer_objects, rel_per_object
 
 POSE_TOL = 1e-4      # north-star tolerance on the pose
 
@@ -19,35 +19,22 @@ def _solve(backend, g, prob_dict=None):
 
 @pytest.mark.parametrize('name', ['lm6_tr', 'lm6_gn', 'lm6_tr_clip', 'lm4_tr', 'lm4_gn'])
 def test_lm_matches_reference(backend, name):
-    """pose <= 1e-4 of the reference for every object whose trust-region accept/reject history agrees with the
-    reference's; where a marginal step flips (a 1-ulp effect on `cost - cost_new`, SURVEY.md section 7 hard part 2)
-    both trajectories are valid LM runs and must agree on the achieved cost instead."""
+    """pose <= 1e-4, cost <= 1e-5 rel, covariance <= 1e-3 rel of the reference -- each bar widened only by the
+    reference's OWN rounding sensitivity (fixture `spread.*`: max change of the reference's fp32 result under <= 3 ulp
+    input perturbations, plus its fp32-vs-fp64 drift), matched by rank over the objects.  That yardstick is what a
+    trust-region accept/reject flip at convergence (a 1-ulp effect on `cost - cost_new`, SURVEY.md section 7 hard part
+    2) looks like from outside: no accept-history bookkeeping, no equal-cost escape."""
     from epropnp import functional as F
     g = load_golden(name)
     dof = int(g['dof'])
     p, cam, cf = make_layer_objects(g['prob'], backend)
     prob = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
-    pose, cov, cost, acc = F.lm_solve(prob, p['pose_init'], int(g['lm_iter']), fast_mode=bool(g['fast_mode']),
-                                      with_pose_cov=True, with_cost=True, with_accepts=True)
-    pose, cov, cost, acc = pose.cpu(), cov.cpu(), cost.cpu(), acc.cpu().long()
-    if g['accepts'].numel():
-        ref_bits = (g['accepts'].long() << torch.arange(g['accepts'].shape[0])[:, None]).sum(0)
-        same = acc == ref_bits
-    else:
-        same = torch.ones(pose.shape[0], dtype=torch.bool)
-    # the fp64 run of the same algorithm brackets how far two correct fp32 implementations may drift
-    drift = (g['pose_opt'] - g['pose_opt64']).abs().max(-1).values.float()
-    err = (pose - g['pose_opt']).abs().max(-1).values
-    pose_ok = err <= POSE_TOL + 2 * drift
-    assert bool(pose_ok[same].all()), (err, drift, same)
-    # flipped marginal steps: allowed only if the pose still agrees or the achieved cost is the same to 1e-5
-    cost_same = (cost - g['cost']).abs() <= 1e-5 * g['cost'].abs().clamp(min=1.0)
-    assert bool((pose_ok | cost_same)[~same].all()), (err, cost, g['cost'])
-    torch.testing.assert_close(cost, g['cost'], rtol=1e-4, atol=1e-5)
-    cov_scale = g['pose_cov'].abs().amax(dim=(-1, -2))
-    cov_drift = (g['pose_cov'] - g['pose_cov64']).abs().amax(dim=(-1, -2)) / cov_scale
-    cov_err = (cov - g['pose_cov']).abs().amax(dim=(-1, -2)) / cov_scale
-    assert bool((cov_err[same & pose_ok] <= 1e-3 + 2 * cov_drift[same & pose_ok]).all()), (cov_err, cov_drift)
+    pose, cov, cost = F.lm_solve(prob, p['pose_init'], int(g['lm_iter']), fast_mode=bool(g['fast_mode']),
+                                 with_pose_cov=True, with_cost=True)
+    pose, cov, cost, sp = pose.cpu(), cov.cpu(), cost.cpu(), g['spread']
+    assert_within_spread((pose - g['pose_opt']).abs().max(-1).values, sp['pose_opt'], POSE_TOL, what='pose_opt')
+    assert_within_spread((cost - g['cost']).abs() / g['cost'].abs().clamp(min=1e-30), sp['cost'], 1e-5, what='cost')
+    assert_within_spread(rel_per_object(cov, g['pose_cov']), sp['pose_cov'], 1e-3, what='pose_cov')
 
 
 def test_lm_accept_history_matches_reference(backend):
@@ -72,26 +59,18 @@ def test_lm_vs_oracle_seeded(backend, dof, N, lm_iter, fast):
     prob = orc.make_problem(B, N, dof, seed=100 + N)
     p, cam, cf = make_layer_objects(prob, backend)
     hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
-    pose, _, cost, acc = F.lm_solve(hp, p['pose_init'], lm_iter, fast_mode=fast, with_cost=True, with_accepts=True)
-    pose, cost, acc = pose.cpu(), cost.cpu(), acc.cpu().long()
+    pose, _, cost = F.lm_solve(hp, p['pose_init'], lm_iter, fast_mode=fast, with_cost=True)
+    pose, cost = pose.cpu(), cost.cpu()
 
-    def run(dt):
-        q = {k: v.to(dt) for k, v in prob.items()}
-        return orc.lm_solve(q['x3d'], q['x2d'], q['w2d'], orc.Cam(q['cam_mats'], 0.1), q['delta'], q['pose_init'],
-                            fast_mode=fast, with_pose_cov=True, with_cost=True, num_iter=lm_iter)
-    o_pose, _, o_cost, hist = run(torch.float32)
-    d_pose = run(torch.float64)[0]
-    same = torch.ones(B, dtype=torch.bool)
-    if hist:
-        ref_bits = (torch.stack(hist).long() << torch.arange(len(hist))[:, None]).sum(0)
-        same = acc == ref_bits
-    drift = (o_pose - d_pose).abs().max(-1).values.float()
-    err = (pose - o_pose).abs().max(-1).values
-    pose_ok = err <= POSE_TOL + 2 * drift
-    cost_same = (cost - o_cost).abs() <= 1e-5 * o_cost.abs().clamp(min=1.0)
-    assert bool(pose_ok[same].all()), (err, drift, same)
-    assert bool((pose_ok | cost_same)[~same].all()), (err, cost, o_cost)
-    torch.testing.assert_close(cost, o_cost, rtol=1e-4, atol=1e-5)
+    def run(q, dt=torch.float32):
+        q = {k: v.to(dt) for k, v in q.items()}
+        out = orc.lm_solve(q['x3d'], q['x2d'], q['w2d'], orc.Cam(q['cam_mats'], 0.1), q['delta'], q['pose_init'],
+                           fast_mode=fast, with_pose_cov=True, with_cost=True, num_iter=lm_iter)
+        return dict(pose_opt=out[0].float(), cost=out[2].float())
+    base = run(prob)
+    sp = orc.rounding_spread(run, prob, base, extra=[run(prob, torch.float64)])
+    assert_within_spread((pose - base['pose_opt']).abs().max(-1).values, sp['pose_opt'], POSE_TOL, what='pose_opt')
+    assert_within_spread((cost - base['cost']).abs() / base['cost'].abs().clamp(min=1e-30), sp['cost'], 1e-5, what='cost')
 
 
 def test_lm_empty_batch(backend):
