@@ -133,8 +133,21 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) Cr[i][j] = (double)cov[(3 + i) * 6 + 3 + j];
-    double invd3[3], invd4[4];
-    spd_inverse<3, double>(Cr, invd3, Ci);
+    double invd4[4];
+    // the reference inverts this block with LU (torch.inverse, epropnp.py:297): a true inverse also when the block is
+    // indefinite.  Adjugate / determinant in fp64 does the same (NaN in -> NaN out -> identity fallback below).
+    {
+      const double c00 = Cr[1][1] * Cr[2][2] - Cr[1][2] * Cr[2][1], c01 = Cr[1][2] * Cr[2][0] - Cr[1][0] * Cr[2][2],
+                   c02 = Cr[1][0] * Cr[2][1] - Cr[1][1] * Cr[2][0];
+      const double idet = 1.0 / (Cr[0][0] * c00 + Cr[0][1] * c01 + Cr[0][2] * c02);
+      Ci[0][0] = c00 * idet; Ci[1][0] = c01 * idet; Ci[2][0] = c02 * idet;
+      Ci[0][1] = (Cr[0][2] * Cr[2][1] - Cr[0][1] * Cr[2][2]) * idet;
+      Ci[1][1] = (Cr[0][0] * Cr[2][2] - Cr[0][2] * Cr[2][0]) * idet;
+      Ci[2][1] = (Cr[0][1] * Cr[2][0] - Cr[0][0] * Cr[2][1]) * idet;
+      Ci[0][2] = (Cr[0][1] * Cr[1][2] - Cr[0][2] * Cr[1][1]) * idet;
+      Ci[1][2] = (Cr[0][2] * Cr[1][0] - Cr[0][0] * Cr[1][2]) * idet;
+      Ci[2][2] = (Cr[0][0] * Cr[1][1] - Cr[0][1] * Cr[1][0]) * idet;
+    }
     const double w = pose_opt[3], qi = pose_opt[4], qj = pose_opt[5], qk = pose_opt[6];
     const double T[4][3] = {{qi, qj, qk}, {-w, -qk, qj}, {qk, -w, -qi}, {-qj, qi, -w}};   // camera.py:158-165
     double TC[4][3], A[4][4], Ai[4][4];
@@ -147,7 +160,10 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         A[i][j] = TC[i][0] * T[j][0] + TC[i][1] * T[j][1] + TC[i][2] * T[j][2] + ((i == j) ? 1.0 : 0.0);
-    spd_inverse<4, double>(A, invd4, Ai);
+    // A = I + (rank <= 3) always has the eigenvalue 1, so a non-SPD A is indefinite, and so are its inverse and any
+    // rescaling of it: the reference's Cholesky (epropnp.py:302) fails and falls back to I.  Same outcome here.
+    const bool a_spd = spd_inverse<4, double>(A, invd4, Ai);
+    if (!a_spd) Ai[0][0] = -1.0;
     const double itr = 1.0 / (Ai[0][0] + Ai[1][1] + Ai[2][2] + Ai[3][3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)

@@ -680,11 +680,12 @@ def run_mc(prob, noise, dof, mc_samples, num_iter, lm_iter, normalize=False, rel
            rslm_kw=None, rslm_noise=None, with_pose_opt_plus=False, fast_mode=False, dtype=None):
     """monte_carlo_forward + MC loss (mean over objects) + backward, on the restatement.
     Same contract as oracle/ref_runner.py:run_mc, so the two can be diffed key by key."""
-    cvt = (lambda v: v.to(dtype) if v.is_floating_point() else v) if dtype is not None else (lambda v: v)
+    cvt = (lambda v: v.to(dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v) if dtype is not None \
+        else (lambda v: v)
     prob = {k: cvt(v) for k, v in prob.items()}
     noise = {k: cvt(v) for k, v in noise.items()}
     x3d, x2d, w2d = (prob[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
-    cam = Cam(prob['cam_mats'], 0.1, prob.get('lb'), prob.get('ub'))
+    cam = Cam(prob['cam_mats'], float(prob.get('z_min', 0.1)), prob.get('lb'), prob.get('ub'))
     delta = adaptive_huber_delta(x2d.detach(), w2d, relative_delta)
     rn = None
     if rslm_noise is not None:

@@ -139,6 +139,59 @@ def case_mc(name, dof, B, N, S, K, lm_iter, seed, normalize=False, rslm=None, wi
          **extra)
 
 
+def case_vm_numpy(name, seed):
+    """Pins the bounded Best-Fisher sampler (orc.vm_sample_bounded, what the HIP kernel implements) against the
+    reference's own sampler -- numpy.random.vonmises / numpy.random.uniform inside the UNMODIFIED
+    VonMisesUniformMix.sample (epropnp/distributions.py:61-72) -- on a SHARED uniform stream: the reference draws from
+    numpy's seeded global generator; the same seed is then replayed through random_sample() and dealt into the
+    (attempt, 3) layout the bounded sampler consumes: numpy's legacy von Mises takes (U, V) per attempt until one is
+    accepted and then one more double for the sign; uniform(-pi, pi) takes one double per element."""
+    import math
+    m = ref.load_reference()
+    B, s = 10, 96
+    n_u = round(0.25 * s)
+    n_v = s - n_u
+    g = torch.Generator().manual_seed(seed)
+    var = torch.tensor([1e-5, 1e-4, 1e-3, 0.01, 0.05, 0.33, 2.0, 33.0, 330.0, 3300.0])
+    kappa = (0.33 / var.clamp(min=1e-5)).reshape(B, 1)               # as epropnp.py:218 computes it (fp32)
+    loc = (torch.rand(B, 1, generator=g) * 2 - 1) * 3.0
+    dist = m['distributions'].VonMisesUniformMix(loc, kappa)
+    np.random.seed(seed)
+    x = m['vm_sample_unpatched'](dist, torch.Size([s]))               # (s,B,1) float32, the reference's draw
+    np.random.seed(seed)
+    u_uni = torch.from_numpy(np.random.random_sample((n_u, B, 1)))
+    T = orc.VM_MAX_TRIES
+    u_vm = torch.full((n_v, B, 1, T, 3), 0.5, dtype=torch.float64)
+    worst = 0
+    for i in range(n_v):
+        for b in range(B):
+            k = float(kappa[b, 0])
+            if k < 1e-5:
+                r = 1.0 / k + k
+            else:
+                tau = 1 + math.sqrt(1 + 4 * k * k)
+                rho = (tau - math.sqrt(2 * tau)) / (2 * k)
+                r = (1 + rho * rho) / (2 * rho)
+            for a in range(T):
+                U, V = np.random.random_sample(), np.random.random_sample()
+                u_vm[i, b, 0, a, 0], u_vm[i, b, 0, a, 1] = U, V
+                Z = math.cos(math.pi * U)
+                W = (1 + r * Z) / (r + Z)
+                Y = k * (r - W)
+                if (Y * (2 - Y) - V >= 0) or (math.log(Y / V) + 1 - Y >= 0):
+                    u_vm[i, b, 0, a, 2] = np.random.random_sample()
+                    worst = max(worst, a + 1)
+                    break
+            else:
+                raise AssertionError('numpy needed more than VM_MAX_TRIES attempts; pick another seed')
+    got = orc.vm_mix_sample(loc.double(), kappa.double(), u_uni, u_vm, s)
+    d = (got - x.double()).abs()
+    d = torch.minimum(d, 2 * math.pi - d)
+    REPORT.append((name, f'vm sample vs numpy stream (max tries {worst})', float(d.max()), 1e-6))
+    assert float(d.max()) <= 1e-6, f'{name}: bounded sampler vs numpy.random.vonmises differ by {float(d.max()):.3e}'
+    save(name, loc=loc, var=var, kappa=kappa, u_uniform=u_uni, u_vm=u_vm, x=x, seed=seed)
+
+
 def main():
     case_evaluate('eval6', 6, 6, 40, None, 10)
     case_evaluate('eval6_clip', 6, 6, 40, 'tight', 11)
@@ -160,6 +213,7 @@ def main():
     case_mc('mc6_k1', 6, 3, 40, 32, 1, 3, 38)
     case_mc('mc4_det', 4, 2, 64, 32, 4, 5, 37, rslm=dict(num_points=16, num_proposals=64, num_iter=3), normalize=True,
             bounds='tensor', with_pose_opt_plus=True)
+    case_vm_numpy('vm_numpy', 7)
     w = max(len(n) for n, *_ in REPORT)
     for n, k, d, tol in REPORT:
         print(f'{n:<{w}}  {k:<32} maxdiff {d:.3e}   tol {tol:.1e}')

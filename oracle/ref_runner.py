@@ -69,6 +69,8 @@ def load_reference():
         return g
     mods['distributions']._standard_normal = std_normal
 
+    _ref['vm_sample_unpatched'] = mods['distributions'].VonMisesUniformMix.sample      # numpy-driven original (:61-72)
+
     def vm_sample(self, sample_shape=torch.Size()):
         u, vm = INJ.noise['u'][INJ.it_r], INJ.noise['vm'][INJ.it_r]
         INJ.it_r += 1

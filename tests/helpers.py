@@ -47,7 +47,7 @@ def make_layer_objects(prob, device, relative_delta=None):
     from epropnp.camera import PerspectiveCamera
     from epropnp.cost_fun import AdaptiveHuberPnPCost, HuberPnPCost
     p = to_dev(prob, device)
-    cam = PerspectiveCamera(cam_mats=p['cam_mats'], z_min=0.1, lb=p.get('lb'), ub=p.get('ub'))
+    cam = PerspectiveCamera(cam_mats=p['cam_mats'], z_min=float(p.get('z_min', 0.1)), lb=p.get('lb'), ub=p.get('ub'))
     if relative_delta is None:
         cf = HuberPnPCost(delta=p['delta'])
     else:

@@ -253,3 +253,80 @@ def test_von_mises_draws_match_oracle_over_kappa_range(backend):
     assert d.max().item() < 2e-5, d.max(0).values
     uni = samples[:n_u, :, 3].cpu()
     torch.testing.assert_close(uni, ((noise['u'][0, :, :, 0] * 2 - 1) * math.pi).float(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize('dof', [6, 4])
+def test_non_spd_pose_cov_falls_back_like_cholesky_wrapper(backend, dof):
+    """cholesky_wrapper (epropnp/epropnp.py:16-33): a covariance block whose Cholesky fails (indefinite, NaN) is replaced
+    by diag(default) -- I for 6-DoF, [1,1,4] for the 4-DoF translation proposal (:216-217), I for the ACG scatter matrix
+    (:301-302).  Feed such pose_cov straight into the AMIS kernel: proposal 0 and the samples drawn from it must equal
+    the oracle's (orc.chol_or_default inside initial_fit_*), object by object; healthy objects are untouched."""
+    from epropnp import functional as F
+    B, N, S, K = 5, 48, 32, 1
+    prob = orc.make_problem(B, N, dof, seed=91)
+    noise = orc.make_noise(B, S, K, dof, seed=92)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose_opt, cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
+    pose_opt, cov = pose_opt.cpu(), cov.cpu().clone()
+    cov[0, 0, 0] = -cov[0, 0, 0]                                  # indefinite translation block
+    cov[1, :3, :3] = float('nan')                                 # NaN translation block
+    if dof == 6:
+        cov[2, 4, 4] = -1e-3                                      # indefinite rotation block -> T C^-1 T^T + I not SPD
+        cov[3, 3:, 3:] = float('nan')                             # NaN rotation block
+    else:
+        cov[2] = float('nan')                                     # everything NaN (kappa = 0.33 / max(NaN, eps))
+    samples, logw, props = F.amis_forward(hp, pose_opt.to(backend), cov.to(backend), S, K,
+                                          noise=pack_noise(noise, dof).to(backend), with_proposals=True)
+    samples, props = samples.cpu(), props.cpu()[:, 0]
+
+    def tril(v, n):
+        L = torch.zeros(v.shape[:-1] + (n, n))
+        idx = torch.tril_indices(n, n)
+        L[..., idx[0], idx[1]] = v
+        return L
+    if dof == 6:
+        # fp64 oracle: the kernel fits in fp64, the reference's fp32 fit of a healthy object drifts by ~5e-4 (cond ~1e5)
+        mode, Lt, Lr = (v.float() for v in orc.initial_fit_6dof(pose_opt.double(), cov.double()))
+        torch.testing.assert_close(tril(props[:, 16:26], 4), Lr, rtol=2e-4, atol=1e-6)
+        assert torch.equal(Lr[2], torch.eye(4)) and torch.equal(Lr[3], torch.eye(4))
+        t = orc.student_t_sample(mode, Lt, noise['z'][0], noise['chi2'][0])
+        want = torch.cat((t, orc.acg_sample(Lr, noise['g'][0])), -1)
+        ok = [0, 1, 2, 3, 4]
+    else:
+        mode, Lt, rmode, kappa = orc.initial_fit_4dof(pose_opt, cov)
+        assert torch.equal(Lt[0], torch.diag(torch.tensor([1.0, 1.0, 4.0])))      # the default IS the factor (scale_tril)
+        t = orc.student_t_sample(mode, Lt, noise['z'][0], noise['chi2'][0])
+        want = torch.cat((t, torch.zeros(S, B, 1)), -1)
+        ok = [0, 1, 3, 4]                                         # object 2: kappa from a NaN variance (no reference value)
+    torch.testing.assert_close(tril(props[:, 3:9], 3), Lt, rtol=2e-4, atol=1e-6)
+    assert torch.equal(tril(props[:, 3:9], 3)[0], Lt[0]) and torch.equal(tril(props[:, 3:9], 3)[1], Lt[1])
+    nt = 7 if dof == 6 else 3
+    torch.testing.assert_close(samples[:, ok, :nt], want[:, ok, :nt], rtol=1e-4, atol=2e-5)
+    assert torch.isfinite(logw.cpu()[:, ok]).all() and torch.isfinite(samples[:, ok]).all()
+
+
+def test_von_mises_draws_match_numpy_stream(backend):
+    """The device sampler against numpy.random.vonmises itself (fixture `vm_numpy`: the reference's unmodified
+    VonMisesUniformMix.sample under a seeded numpy generator + the uniform stream it consumed): one AMIS iteration whose
+    proposal 0 has loc = pose_opt yaw and kappa = 0.33 / cov[3,3] (epropnp.py:218), fed the same uniforms."""
+    from epropnp import functional as F
+    g = load_golden('vm_numpy')
+    x, var = g['x'], g['var']
+    s, B = x.shape[0], x.shape[1]
+    n_u = g['u_uniform'].shape[0]
+    prob = orc.make_problem(B, 32, 4, seed=31)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 4)
+    cov = torch.diag_embed(torch.stack((torch.full((B,), 1e-2),) * 3 + (var,), -1))
+    pose_opt = prob['pose_gt'].clone()
+    pose_opt[:, 3] = g['loc'][:, 0]
+    noise = orc.make_noise(B, s, 1, 4, seed=5)
+    noise['u'] = g['u_uniform'].float().unsqueeze(0)                     # (1,n_u,B,1)
+    noise['vm'] = g['u_vm'].float().unsqueeze(0)                         # (1,n_v,B,1,T,3)
+    samples, _ = F.amis_forward(hp, pose_opt.to(backend), cov.to(backend), s, 1, noise=pack_noise(noise, 4).to(backend))
+    d = (samples[:, :, 3].cpu() - x[:, :, 0]).abs()
+    d = torch.minimum(d, 2 * math.pi - d)
+    # fp32 uniforms (the fixture's doubles rounded) move a draw by ~1e-7 * d(angle)/du; 2e-5 rad as in the oracle test above
+    assert d[n_u:].max().item() < 2e-5, d[n_u:].max(0).values
+    assert d[:n_u].max().item() < 2e-6

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import epropnp_oracle as orc
-from helpers import load_golden, make_layer_objects, pack_noise
+from helpers import assert_within_spread, load_golden, make_layer_objects, pack_noise, rel_per_object
 
 
 def test_public_names_and_signatures():
@@ -89,22 +89,14 @@ def test_demo_config_with_rslm_and_pose_opt_plus(backend, name):
     total = loss_obj.mean() + 0.1 * (pose_opt_plus * torch.linspace(0.5, 1.5, pose_opt_plus.shape[-1],
                                                                     device=backend)).sum(-1).mean()
     total.backward()
-    r, o64 = g['ref'], g['o64']
-    pose_err = (pose_opt.detach().cpu() - r['pose_opt']).abs().max(-1).values
-    same_cost = (cost.cpu() - r['cost']).abs() <= 1e-5 * r['cost'].abs().clamp(min=1.0)
-    drift = (r['pose_opt'] - o64['pose_opt']).abs().max(-1).values
-    assert bool(((pose_err <= 1e-4 + 2 * drift) | same_cost).all()), (pose_err, drift)
-    ok = pose_err <= 1e-4 + 2 * drift
-    if bool(ok.all()):
-        assert (pose_opt_plus.detach().cpu() - r['pose_opt_plus']).abs().max() <= 2e-4 + \
-            2 * (r['pose_opt_plus'] - o64['pose_opt_plus']).abs().max()
-    ldrift = (r['loss_obj'] - o64['loss_obj']).abs().max().item()
-    assert (loss_obj.detach().cpu() - r['loss_obj']).abs().max().item() <= 1e-3 + 2 * ldrift
+    r, sp = g['ref'], g['spread']      # bars widened only by the reference's own rounding spread (see tests/test_amis.py)
+    assert_within_spread((pose_opt.detach().cpu() - r['pose_opt']).abs().max(-1).values, sp['pose_opt'], 1e-4, what='pose_opt')
+    assert_within_spread((pose_opt_plus.detach().cpu() - r['pose_opt_plus']).abs().max(-1).values, sp['pose_opt_plus'], 1e-4,
+                         what='pose_opt_plus')
+    assert_within_spread((loss_obj.detach().cpu() - r['loss_obj']).abs(), sp['loss_obj'], 1e-3, what='loss_obj')
+    assert abs(loss_obj.mean().item() - r['loss_obj'].mean().item()) <= 1e-3
     for k, t in (('gx3d', x3d), ('gx2d', x2d), ('gw2d', w2d)):
-        ref_g, o64_g = r[k], o64[k]
-        gd = ((ref_g - o64_g).abs().max() / ref_g.abs().max()).item()
-        err = ((t.grad.cpu() - ref_g).abs().max() / ref_g.abs().max()).item()
-        assert err <= 5e-3 + 3 * gd, (k, err, gd)
+        assert_within_spread(rel_per_object(t.grad, r[k]), sp[k], 5e-4, what=k)       # incl. the gn_step backward
 
 
 def test_inference_forward_and_empty_batch(backend):

@@ -64,3 +64,17 @@ def test_von_mises_bounded_sampler_distribution():
         d = stats.kstest((x - loc + 3.141592653589793) % (2 * 3.141592653589793) - 3.141592653589793,
                          stats.vonmises(kappa).cdf)
         assert d.pvalue > 1e-3, (kappa, d)
+
+
+def test_von_mises_sampler_matches_numpy_stream():
+    """Fixture `vm_numpy`: the UNMODIFIED VonMisesUniformMix.sample (numpy.random.uniform / numpy.random.vonmises,
+    epropnp/distributions.py:61-72) under a seeded global generator, together with the very doubles numpy consumed, dealt
+    into the bounded sampler's (attempt, 3) layout (oracle/make_golden.py:case_vm_numpy).  The bounded Best-Fisher sampler
+    fed that stream must return the reference's angles: kappa from 1e-4 to 3.3e4."""
+    import math
+    g = load_golden('vm_numpy')
+    s = g['x'].shape[0]
+    got = orc.vm_mix_sample(g['loc'].double(), g['kappa'].double(), g['u_uniform'], g['u_vm'], s)
+    d = (got - g['x'].double()).abs()
+    d = torch.minimum(d, 2 * math.pi - d)
+    assert d.max().item() <= 1e-6, d.amax((0, 2))
