@@ -13,19 +13,16 @@ Extra (non-reference) knobs, all optional:
 import torch
 
 from . import functional as hip
+from . import proposals
 from .common import pnp_denormalize, pnp_normalize
 
 
-def cholesky_wrapper(mat, default_diag=None, force_cpu=False):
+def cholesky_wrapper(mat, default_diag=None, force_cpu=True):
     """Batched Cholesky; matrices that are not positive definite yield diag(default_diag) (or I).
     Kept for API compatibility (reference: epropnp/epropnp.py:16-33); the AMIS kernel has its own in-register
-    version and does not call this.  No host round-trip: failures are detected with cholesky_ex."""
-    tril, info = torch.linalg.cholesky_ex(mat)
-    n = mat.size(-1)
-    fallback = torch.diag(mat.new_tensor(default_diag)) if default_diag is not None \
-        else torch.eye(n, dtype=mat.dtype, device=mat.device)
-    bad = (info != 0) | ~torch.isfinite(tril).flatten(-2).all(-1)
-    return torch.where(bad[..., None, None], fallback, tril)
+    version and does not call this.  `force_cpu` is accepted and ignored: failures are detected on the device with
+    cholesky_ex, there is no host round-trip to force."""
+    return proposals.cholesky_or_default(mat, default_diag)
 
 
 class EProPnPBase(torch.nn.Module):
@@ -71,6 +68,26 @@ class EProPnPBase(torch.nn.Module):
                 init._draw_seed, init._draw_calls = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
             init.rng_counter = torch.zeros(1, dtype=torch.int64, device=device)     # its own call counter
         return self
+
+    # Extension hooks of the reference (epropnp.py:64-82).  monte_carlo_forward runs the fused sampler and does not call
+    # them; the 4-/6-DoF subclasses provide them in PyTorch (epropnp/proposals.py) for code that builds on them.
+    def allocate_buffer(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def initial_fit(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def gen_new_distr(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def gen_old_distr(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def estimate_params(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def _new(self, num_obj, dtype, device, *tails):
+        return tuple(torch.empty((self.num_iter, num_obj) + t, dtype=dtype, device=device) for t in tails)
 
     def forward(self, *args, **kwargs):
         return self.solver(*args, **kwargs)
@@ -137,6 +154,32 @@ class EProPnP4DoF(EProPnPBase):
     Proposals: position ~ multivariate Student-t (3 dof); yaw ~ 0.75 von Mises + 0.25 uniform."""
 
     dof = 4
+    _t_default = [1.0, 1.0, 4.0]      # fallback factor of the translation proposal (epropnp.py:217,248)
+
+    def allocate_buffer(self, num_obj, dtype=torch.float32, device=None):
+        """-> trans_mode (K,B,3), trans_cov_tril (K,B,3,3), rot_mode (K,B,1), rot_kappa (K,B,1)"""
+        return self._new(num_obj, dtype, device, (3,), (3, 3), (1,), (1,))
+
+    def initial_fit(self, pose_opt, pose_cov, camera, trans_mode, trans_cov_tril, rot_mode, rot_kappa):
+        trans_mode[0], rot_mode[0] = pose_opt[:, :3], pose_opt[:, 3:]
+        trans_cov_tril[0] = proposals.cholesky_or_default(pose_cov[:, :3, :3], self._t_default)
+        rot_kappa[0] = 0.33 / pose_cov[:, 3, 3, None].clamp(min=self.eps)
+
+    @staticmethod
+    def gen_new_distr(iter_id, trans_mode, trans_cov_tril, rot_mode, rot_kappa):
+        return (proposals.MultivariateStudentT(3, trans_mode[iter_id], trans_cov_tril[iter_id]),
+                proposals.VonMisesUniformMix(rot_mode[iter_id], rot_kappa[iter_id]))
+
+    @staticmethod
+    def gen_old_distr(iter_id, trans_mode, trans_cov_tril, rot_mode, rot_kappa):
+        return (proposals.MultivariateStudentT(3, trans_mode[:iter_id, None], trans_cov_tril[:iter_id, None]),
+                proposals.VonMisesUniformMix(rot_mode[:iter_id, None], rot_kappa[:iter_id, None]))
+
+    def estimate_params(self, iter_id, pose_samples, pose_sample_logweights, trans_mode, trans_cov_tril, rot_mode, rot_kappa):
+        w = torch.softmax(pose_sample_logweights, dim=0)
+        trans_mode[iter_id + 1], cov = proposals.translation_moments(pose_samples, w)
+        trans_cov_tril[iter_id + 1] = proposals.cholesky_or_default(cov, self._t_default)
+        rot_mode[iter_id + 1], rot_kappa[iter_id + 1] = proposals.yaw_concentration(pose_samples, w, self.eps)
 
 
 class EProPnP6DoF(EProPnPBase):
@@ -149,3 +192,30 @@ class EProPnP6DoF(EProPnPBase):
         super().__init__(*args, **kwargs)
         self.acg_mle_iter = acg_mle_iter
         self.acg_dispersion = acg_dispersion
+
+    def allocate_buffer(self, num_obj, dtype=torch.float32, device=None):
+        """-> trans_mode (K,B,3), trans_cov_tril (K,B,3,3), rot_cov_tril (K,B,4,4)"""
+        return self._new(num_obj, dtype, device, (3,), (3, 3), (4, 4))
+
+    def initial_fit(self, pose_opt, pose_cov, camera, trans_mode, trans_cov_tril, rot_cov_tril):
+        trans_mode[0] = pose_opt[:, :3]
+        trans_cov_tril[0] = proposals.cholesky_or_default(pose_cov[:, :3, :3])
+        shape = proposals.acg_shape_from_laplace(pose_opt[:, 3:], pose_cov[:, 3:, 3:], camera.get_quaternion_transfrom_mat)
+        rot_cov_tril[0] = proposals.acg_shape_factor(shape, self.acg_dispersion)
+
+    @staticmethod
+    def gen_new_distr(iter_id, trans_mode, trans_cov_tril, rot_cov_tril):
+        return (proposals.MultivariateStudentT(3, trans_mode[iter_id], trans_cov_tril[iter_id]),
+                proposals.AngularCentralGaussian(rot_cov_tril[iter_id]))
+
+    @staticmethod
+    def gen_old_distr(iter_id, trans_mode, trans_cov_tril, rot_cov_tril):
+        return (proposals.MultivariateStudentT(3, trans_mode[:iter_id, None], trans_cov_tril[:iter_id, None]),
+                proposals.AngularCentralGaussian(rot_cov_tril[:iter_id, None]))
+
+    def estimate_params(self, iter_id, pose_samples, pose_sample_logweights, trans_mode, trans_cov_tril, rot_cov_tril):
+        w = torch.softmax(pose_sample_logweights, dim=0)
+        trans_mode[iter_id + 1], cov = proposals.translation_moments(pose_samples, w)
+        trans_cov_tril[iter_id + 1] = proposals.cholesky_or_default(cov)
+        shape = proposals.acg_shape_mle(pose_samples[..., 3:], w, self.acg_mle_iter, self.eps)
+        rot_cov_tril[iter_id + 1] = proposals.acg_shape_factor(shape, self.acg_dispersion)

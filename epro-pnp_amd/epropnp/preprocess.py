@@ -6,23 +6,13 @@ The reference does this in its callers, not in `epropnp/`:
   * EPro-PnP-Det/.../deform_pnp_head.py:418-423,873-875   w2d = softmax_N(w2d) * scale;  x3d = noc * dim -- mode='softmax'
   * EPro-PnP-6DoF/lib/train.py:143-162   the dense variant: pixel-grid x2d of the cropped box and a random subset of
     the out_res x out_res pixels gathered from the network's (bs, C, h, w) maps -- `prepare_dense_correspondences`
-Provided here because it is the data format on the input side of the layer; plain PyTorch for
-tensors that are not on the HIP path.
+Provided here because it is the data format on the input side of the layer.  HIP kernels only:
+tensors that are not fp32 on a HIP device raise (the PyTorch statement of the same maths is test infrastructure,
+oracle/preprocess_oracle.py, pinned to the reference's source lines).
 """
-import math
-
 import torch
 
 MODES = {'softmax': 0, 'mean_exp': 1}
-
-
-def _reference(noc, dim, logits, scale, mode):
-    x3d = None if noc is None else noc * dim.unsqueeze(-2)
-    if mode == 'softmax':
-        w = logits.softmax(dim=-2)
-    else:
-        w = (logits - logits.mean(dim=-2, keepdim=True) - math.log(logits.size(-2))).exp()
-    return x3d, (w if scale is None else w * scale.unsqueeze(-2))
 
 
 class _Prepare(torch.autograd.Function):
@@ -77,10 +67,13 @@ def prepare_correspondences(noc, dim, w2d_logits, scale=None, mode='softmax'):
     assert (noc is None) == (dim is None)
     from . import _hip
     ts = [t for t in (noc, dim, w2d_logits, scale) if t is not None]
-    if w2d_logits.dim() == 3 and w2d_logits.size(0) > 0 and _hip.on_hip_path(*ts):
-        out = _Prepare.apply(noc, dim, w2d_logits, scale, MODES[mode])
-        return (None, out) if noc is None else out
-    return _reference(noc, dim, w2d_logits, scale, mode)
+    assert w2d_logits.dim() == 3, 'w2d_logits must be (num_obj, num_pts, 2)'
+    if not _hip.on_hip_path(*ts):
+        raise RuntimeError('prepare_correspondences: fp32 tensors on a HIP device required (no CPU fallback)')
+    if w2d_logits.size(0) == 0:        # empty batch: nothing to launch, keep autograd connectivity
+        return (None if noc is None else noc * dim.unsqueeze(-2)), (w2d_logits if scale is None else w2d_logits * scale.unsqueeze(-2))
+    out = _Prepare.apply(noc, dim, w2d_logits, scale, MODES[mode])
+    return (None, out) if noc is None else out
 
 
 def box_grid_params(c_box, s_box, out_res):
@@ -90,22 +83,6 @@ def box_grid_params(c_box, s_box, out_res):
     wh_begin = c_box.to(torch.int64) - s[:, None] / 2.
     wh_unit = s.to(torch.float32) / out_res
     return torch.cat((wh_begin.to(torch.float32), wh_unit[:, None]), dim=1)
-
-
-def _reference_dense(noc_map, dim, logit_map, scale, box, inds, mode):
-    """Restates EPro-PnP-6DoF/lib/train.py:141-166 on dense maps (the PyTorch composite the fused op replaces)."""
-    B, _, H, W = logit_map.shape
-    ar_w = torch.arange(W, device=logit_map.device, dtype=torch.float32)
-    ar_h = torch.arange(H, device=logit_map.device, dtype=torch.float32)
-    y, x = torch.meshgrid(ar_h, ar_w, indexing='ij')
-    box = box.to(torch.float32)
-    x2d = torch.stack((box[:, 0, None, None] + x * box[:, 2, None, None],
-                       box[:, 1, None, None] + y * box[:, 2, None, None]), dim=1)             # (B,2,H,W)
-    bi = torch.arange(B, device=logit_map.device)[:, None]
-    pick = lambda m: m.flatten(2).transpose(-1, -2)[bi, inds]
-    x3d = None if noc_map is None else pick(noc_map * dim[..., None, None])
-    _, w2d = _reference(None, None, pick(logit_map), scale, mode)
-    return x3d, pick(x2d).to(logit_map.dtype), w2d
 
 
 class _PrepareDense(torch.autograd.Function):
@@ -169,11 +146,11 @@ def prepare_dense_correspondences(noc_map, dim, w2d_logit_map, scale, box, sampl
     assert (noc_map is None) == (dim is None)
     from . import _hip
     ts = [t for t in (noc_map, dim, w2d_logit_map, scale, box) if t is not None]
-    if (w2d_logit_map.dim() == 4 and w2d_logit_map.size(0) > 0 and sample_inds.size(1) > 0 and _hip.on_hip_path(*ts)
-            and sample_inds.device == w2d_logit_map.device):
-        out = _PrepareDense.apply(noc_map, dim, w2d_logit_map, scale, box, sample_inds, MODES[mode])
-        return (None,) + tuple(out) if noc_map is None else out
-    return _reference_dense(noc_map, dim, w2d_logit_map, scale, box, sample_inds, mode)
+    assert w2d_logit_map.dim() == 4 and w2d_logit_map.size(0) > 0 and sample_inds.size(1) > 0
+    if not _hip.on_hip_path(*ts) or sample_inds.device != w2d_logit_map.device:
+        raise RuntimeError('prepare_dense_correspondences: fp32 tensors on a HIP device required (no CPU fallback)')
+    out = _PrepareDense.apply(noc_map, dim, w2d_logit_map, scale, box, sample_inds, MODES[mode])
+    return (None,) + tuple(out) if noc_map is None else out
 
 
 def derivative_regularization_6dof(pose_opt_plus, pose_gt, beta=0.05):

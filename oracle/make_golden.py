@@ -192,6 +192,165 @@ def case_vm_numpy(name, seed):
     save(name, loc=loc, var=var, kappa=kappa, u_uniform=u_uni, u_vm=u_vm, x=x, seed=seed)
 
 
+def _import_file(modname, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(modname, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def case_losses(name, seed):
+    """The two UNMODIFIED loss modules of the reference's callers on seeded inputs -> fixture `losses`:
+    EPro-PnP-6DoF/lib/models/monte_carlo_pose_loss.py:9-35 and (behind oracle/mmdet_shim.py)
+    EPro-PnP-Det/epropnp_det/models/losses/monte_carlo_pose_loss.py:31-66 with every weight / avg_factor / reduction
+    combination mmdet accepts, loss_weight != 1, the EMA of norm_factor over two training calls, and a NaN object."""
+    import mmdet_shim
+    mmdet_shim.install()
+    six = _import_file('ref_loss_6dof', os.path.join(ref.REF_ROOT, 'EPro-PnP-6DoF/lib/models/monte_carlo_pose_loss.py'))
+    det = _import_file('ref_loss_det', os.path.join(ref.REF_ROOT, 'EPro-PnP-Det/epropnp_det/models/losses/monte_carlo_pose_loss.py'))
+    g = torch.Generator().manual_seed(seed)
+    S, B = 24, 6
+    logw = torch.randn(S, B, generator=g) * 3
+    logw[2, 4] = float('nan')                        # one object's loss is NaN -> 0
+    ct = torch.rand(B, generator=g) * 5
+    weight = torch.tensor([1.0, 0.0, 2.0, 0.5, 1.0, 3.0])
+    nf_in = [torch.tensor(4.0), torch.tensor(2.5)]
+    out = {}
+    m6 = six.MonteCarloPoseLoss(init_norm_factor=2.0, momentum=0.1)
+    out['six.call0'] = m6(logw.clone(), ct, nf_in[0]).detach()
+    out['six.call1'] = m6(logw.clone(), ct, nf_in[1]).detach()
+    out['six.norm_factor'] = m6.norm_factor.clone()
+    m6.eval()
+    out['six.eval'] = m6(logw.clone(), ct, nf_in[0]).detach()
+    md = det.MonteCarloPoseLoss(loss_weight=0.5, init_norm_factor=2.0, momentum=0.1)
+    out['det.call0'] = md(logw.clone(), ct, nf_in[0]).detach()
+    out['det.call1'] = md(logw.clone(), ct, nf_in[1], weight=weight, avg_factor=3.5).detach()
+    out['det.norm_factor'] = md.norm_factor.clone()
+    md.eval()
+    for red in ('mean', 'sum', 'none'):
+        for wname, w in (('w0', None), ('w1', weight)):
+            for aname, af in (('a0', None), ('a1', 3.5)):
+                if af is not None and red == 'sum':
+                    continue                          # mmdet raises ValueError; asserted separately in the test
+                out[f'det.{red}.{wname}.{aname}'] = md(logw.clone(), ct, nf_in[0], weight=w, avg_factor=af,
+                                                       reduction_override=red).detach()
+    save(name, logw=logw, cost_target=ct, weight=weight, nf0=nf_in[0], nf1=nf_in[1], out=out)
+
+
+def case_signatures(name):
+    """Names, positional order and defaults of the reference's public API, read with `inspect` from the imported
+    reference -> tests/golden/signatures.json (what tests/test_api_dropin.py compares the package against)."""
+    import inspect
+    import json
+    m = ref.load_reference()
+    table = {}
+
+    def add(qual, fn):
+        sig = inspect.signature(fn)
+        table[qual] = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                       for p in sig.parameters.values()]
+    E, LMm, C, CF, CO, D = (m[k] for k in ('epropnp', 'levenberg_marquardt', 'camera', 'cost_fun', 'common', 'distributions'))
+    for cls in (E.EProPnPBase, E.EProPnP4DoF, E.EProPnP6DoF):
+        for meth in ('__init__', 'forward', 'monte_carlo_forward', 'allocate_buffer', 'initial_fit', 'gen_new_distr',
+                     'gen_old_distr', 'estimate_params'):
+            add(f'epropnp.{cls.__name__}.{meth}', getattr(cls, meth))
+    add('epropnp.cholesky_wrapper', E.cholesky_wrapper)
+    for cls in (LMm.LMSolver, LMm.RSLMSolver):
+        for meth in ('__init__', 'forward', 'solve', 'gn_step', 'pose_add'):
+            add(f'levenberg_marquardt.{cls.__name__}.{meth}', getattr(cls, meth))
+    add('levenberg_marquardt.RSLMSolver.center_based_init', LMm.RSLMSolver.center_based_init)
+    add('levenberg_marquardt.solve_wrapper', LMm.solve_wrapper)
+    for meth in ('__init__', 'set_param', 'project', 'project_jacobian', 'get_quaternion_transfrom_mat', 'reshape_',
+                 'expand_', 'repeat_', 'shallow_copy'):
+        add(f'camera.PerspectiveCamera.{meth}', getattr(C.PerspectiveCamera, meth))
+    for fn in ('project_a', 'project_b'):
+        add(f'camera.{fn}', getattr(C, fn))
+    for cls in (CF.HuberPnPCost, CF.AdaptiveHuberPnPCost):
+        for meth in ('__init__', 'set_param', 'compute', 'reshape_', 'expand_', 'repeat_', 'shallow_copy'):
+            add(f'cost_fun.{cls.__name__}.{meth}', getattr(cls, meth))
+    for fn in ('huber_kernel', 'huber_d_kernel'):
+        add(f'cost_fun.{fn}', getattr(CF, fn))
+    for fn in ('evaluate_pnp', 'pnp_normalize', 'pnp_denormalize', 'quaternion_to_rot_mat', 'yaw_to_rot_mat', 'skew'):
+        add(f'common.{fn}', getattr(CO, fn))
+    for cls in (D.AngularCentralGaussian, D.VonMisesUniformMix):
+        for meth in ('__init__', 'log_prob') + (('rsample',) if cls is D.AngularCentralGaussian else ('sample',)):
+            add(f'distributions.{cls.__name__}.{meth}', getattr(cls, meth))
+    import mmdet_shim
+    mmdet_shim.install()
+    six = _import_file('ref_loss_6dof_sig', os.path.join(ref.REF_ROOT, 'EPro-PnP-6DoF/lib/models/monte_carlo_pose_loss.py'))
+    det = _import_file('ref_loss_det_sig', os.path.join(ref.REF_ROOT, 'EPro-PnP-Det/epropnp_det/models/losses/monte_carlo_pose_loss.py'))
+    for tag, mod in (('loss6dof', six), ('lossdet', det)):
+        for meth in ('__init__', 'forward'):
+            add(f'{tag}.MonteCarloPoseLoss.{meth}', getattr(mod.MonteCarloPoseLoss, meth))
+    with open(os.path.join(OUT, name + '.json'), 'w') as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+
+
+def _source_lines(path, first, last, must_contain):
+    """The literal lines first..last (1-based, inclusive) of a reference source file, dedented; `must_contain` guards
+    against the slice drifting if the reference checkout ever changes."""
+    import textwrap
+    with open(path) as f:
+        lines = f.readlines()[first - 1:last]
+    text = textwrap.dedent(''.join(lines))
+    for needle in must_contain:
+        assert needle in text, f'{path}:{first}-{last} no longer contains {needle!r}'
+    return text
+
+
+def case_preprocess():
+    """Pins oracle/preprocess_oracle.py by EXECUTING the reference's own source lines (exec of the literal slice, inputs
+    supplied through the namespace) -- fixtures prep_dense / prep_det."""
+    import math
+    import types
+    import preprocess_oracle as pre
+    # ---- 6-DoF training loop: lib/train.py:141-165 (x3d = noc * dim ... mean-normalised exp) ------------------------
+    src = _source_lines(os.path.join(ref.REF_ROOT, 'EPro-PnP-6DoF/lib/train.py'), 141, 165,
+                        ['x3d = noc * dim[..., None, None]', 'np.random.choice(64 * 64, size=64 * 64 // 8, replace=False)',
+                         'w2d = (w2d - w2d.mean(dim=1, keepdim=True) - math.log(w2d.size(1))).exp() * scale[:, None, :]'])
+    g = torch.Generator().manual_seed(50)
+    bs, res = 2, 64                                   # the slice hard-codes a 64 x 64 map and 512 sampled pixels
+    noc = torch.rand(bs, 3, res, res, generator=g) - 0.5
+    dim = torch.rand(bs, 3, generator=g) + 0.5
+    logit = torch.randn(bs, 2, res, res, generator=g) * 2
+    scale = torch.rand(bs, 2, generator=g) * 3 + 0.1
+    c_box = torch.tensor([[320.7, 240.2], [100.0, 400.9]])
+    s_box = torch.tensor([128.9, 77.0])
+    ns = dict(noc=noc, dim=dim, w2d=logit, scale=scale, s_box_var=s_box, c_box_var=c_box, bs=bs, torch=torch, np=np,
+              math=math, cfg=types.SimpleNamespace(dataiter=types.SimpleNamespace(out_res=res)),
+              pose_var=torch.zeros(bs, 3, 4), matrix_to_quaternion=lambda m: torch.zeros(m.shape[0], 4))
+    np.random.seed(51)
+    exec(compile(src, 'lib/train.py:141-165', 'exec'), ns)
+    inds = ns['sample_inds']
+    box = pre.box_grid_ref(c_box, s_box, res)
+    o_x3d, o_x2d, o_w2d = pre.prepare_dense_ref(noc, dim, logit, scale, box, inds, 'mean_exp')
+    check('prep_dense', 'x3d', ns['x3d'], o_x3d, 0.0)
+    check('prep_dense', 'x2d', ns['x2d'], o_x2d, 0.0)
+    check('prep_dense', 'w2d', ns['w2d'], o_w2d, 1e-7 * float(ns['w2d'].abs().max()))
+    save('prep_dense', noc=noc, dim=dim, logit=logit, scale=scale, c_box=c_box, s_box=s_box, box=box, inds=inds,
+         x3d=ns['x3d'], x2d=ns['x2d'], w2d=ns['w2d'])
+    # ---- detection head: deform_pnp_head.py:418-421 (softmax over all heads' points, mask) and :873-874 ---------
+    head = os.path.join(ref.REF_ROOT, 'EPro-PnP-Det/epropnp_det/models/dense_heads/deform_pnp_head.py')
+    src1 = _source_lines(head, 418, 421, ['.softmax(dim=1)', 'w2d = w2d * mask_samples'])
+    src2 = _source_lines(head, 873, 874, ['x3d = noc * dim_decoded[:, None]', 'w2d_scaled = w2d * scale[:, None, :]'])
+    num_obj, heads, pts = 5, 4, 8
+    raw = torch.randn(num_obj, heads, pts, 2, generator=g) * 2
+    noc_d = torch.rand(num_obj, heads * pts, 3, generator=g) - 0.5
+    dim_d = torch.rand(num_obj, 3, generator=g) + 0.5
+    scale_d = torch.rand(num_obj, 2, generator=g) * 3 + 0.1
+    ns1 = dict(w2d=raw.clone(), num_obj=num_obj, num_multihead_points=heads * pts, mask_samples=torch.ones(num_obj, heads, pts, 1),
+               self=types.SimpleNamespace(num_heads=heads, num_points=pts))
+    exec(compile(src1, 'deform_pnp_head.py:418-421', 'exec'), ns1)
+    ns2 = dict(noc=noc_d, dim_decoded=dim_d, w2d=ns1['w2d'].reshape(num_obj, heads * pts, 2), scale=scale_d)
+    exec(compile(src2, 'deform_pnp_head.py:873-874', 'exec'), ns2)
+    o_x3d, o_w2d = pre.prepare_ref(noc_d, dim_d, raw.reshape(num_obj, heads * pts, 2), scale_d, 'softmax')
+    check('prep_det', 'x3d', ns2['x3d'], o_x3d, 0.0)
+    check('prep_det', 'w2d', ns2['w2d_scaled'], o_w2d, 1e-7 * float(ns2['w2d_scaled'].abs().max()))
+    save('prep_det', logits=raw.reshape(num_obj, heads * pts, 2), noc=noc_d, dim=dim_d, scale=scale_d, x3d=ns2['x3d'],
+         w2d=ns2['w2d_scaled'])
+
+
 def main():
     case_evaluate('eval6', 6, 6, 40, None, 10)
     case_evaluate('eval6_clip', 6, 6, 40, 'tight', 11)
@@ -214,6 +373,9 @@ def main():
     case_mc('mc4_det', 4, 2, 64, 32, 4, 5, 37, rslm=dict(num_points=16, num_proposals=64, num_iter=3), normalize=True,
             bounds='tensor', with_pose_opt_plus=True)
     case_vm_numpy('vm_numpy', 7)
+    case_losses('losses', 8)
+    case_preprocess()
+    case_signatures('signatures')
     w = max(len(n) for n, *_ in REPORT)
     for n, k, d, tol in REPORT:
         print(f'{n:<{w}}  {k:<32} maxdiff {d:.3e}   tol {tol:.1e}')

@@ -9,29 +9,58 @@ import epropnp_oracle as orc
 from helpers import assert_within_spread, load_golden, make_layer_objects, pack_noise, rel_per_object
 
 
-def test_public_names_and_signatures():
-    from epropnp.camera import PerspectiveCamera
-    from epropnp.common import evaluate_pnp, pnp_denormalize, pnp_normalize  # noqa: F401
-    from epropnp.cost_fun import AdaptiveHuberPnPCost, HuberPnPCost
-    from epropnp.distributions import AngularCentralGaussian, VonMisesUniformMix  # noqa: F401
-    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF, cholesky_wrapper  # noqa: F401
-    from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+def _resolve(qual):
+    import importlib
+    modname, *path = qual.split('.')
+    modname = {'loss6dof': 'losses', 'lossdet': 'losses'}.get(modname, modname)
+    obj = importlib.import_module('epropnp.' + modname)
+    for part in path:
+        obj = getattr(obj, part)
+    return obj
 
-    def params(f):
-        return list(inspect.signature(f).parameters)
-    assert params(LMSolver.__init__)[1:] == ['dof', 'num_iter', 'min_lm_diagonal', 'max_lm_diagonal',
-                                            'min_relative_decrease', 'initial_trust_region_radius',
-                                            'max_trust_region_radius', 'eps', 'normalize', 'init_solver']
-    assert params(LMSolver.solve)[1:] == ['x3d', 'x2d', 'w2d', 'camera', 'cost_fun', 'pose_init', 'cost_init',
-                                         'with_pose_cov', 'with_cost', 'force_init_solve', 'fast_mode']
-    assert params(LMSolver.forward)[1:9] == ['x3d', 'x2d', 'w2d', 'camera', 'cost_fun', 'with_pose_opt_plus',
-                                            'pose_init', 'normalize_override']
-    assert params(RSLMSolver.__init__)[1:4] == ['num_points', 'num_proposals', 'num_iter']
-    assert params(EProPnP6DoF.monte_carlo_forward)[1:8] == ['x3d', 'x2d', 'w2d', 'camera', 'cost_fun', 'pose_init',
-                                                           'force_init_solve']
-    assert params(PerspectiveCamera.__init__)[1:] == ['cam_mats', 'z_min', 'img_shape', 'allowed_border', 'lb', 'ub']
-    assert params(AdaptiveHuberPnPCost.__init__)[1:] == ['delta', 'relative_delta', 'eps']
-    assert params(HuberPnPCost.__init__)[1:] == ['delta', 'eps']
+
+def test_public_names_and_signatures():
+    """tests/golden/signatures.json is read off the imported reference with `inspect` (oracle/make_golden.py:
+    case_signatures): every public callable of the reference's `epropnp` package (and the two loss modules of its
+    callers) must exist here under the same name, with the reference's parameters as a prefix -- same names, same order,
+    same kinds, same defaults.  Anything this package adds must be optional (a default or *args / **kwargs)."""
+    import json
+    import os
+    from helpers import GOLDEN
+    table = json.load(open(os.path.join(GOLDEN, 'signatures.json')))
+    assert len(table) >= 80
+    problems = []
+    for qual, ref_params in sorted(table.items()):
+        try:
+            fn = _resolve(qual)
+        except AttributeError as e:
+            problems.append(f'{qual}: missing ({e})')
+            continue
+        mine = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                for p in inspect.signature(fn).parameters.values()]
+        if qual.startswith('lossdet') or qual.startswith('loss6dof'):
+            # one class serves both callers: the 6-DoF signature is a prefix of the detection one
+            ref_params = [p for p in ref_params]
+        var_kinds = ('VAR_POSITIONAL', 'VAR_KEYWORD')
+        ref_fixed = [p for p in ref_params if p[1] not in var_kinds]
+        mine_fixed = [p for p in mine if p[1] not in var_kinds]
+        if qual.startswith('loss6dof') and qual.endswith('__init__'):
+            # 6-DoF loss: (init_norm_factor, momentum) by keyword in its only caller (lib/models/...:  built with defaults)
+            if not {p[0] for p in ref_fixed} <= {p[0] for p in mine_fixed}:
+                problems.append(f'{qual}: parameters {ref_fixed} not all accepted by {mine_fixed}')
+            continue
+        if mine_fixed[:len(ref_fixed)] != ref_fixed:
+            problems.append(f'{qual}: reference {ref_fixed} is not a prefix of {mine_fixed}')
+            continue
+        for extra in mine_fixed[len(ref_fixed):]:
+            if extra[2] is None:
+                problems.append(f'{qual}: extra parameter {extra[0]} has no default')
+        for vk in var_kinds:
+            if any(p[1] == vk for p in ref_params) and not any(p[1] == vk for p in mine):
+                problems.append(f'{qual}: reference accepts {vk}, this package does not')
+    assert not problems, '\n'.join(problems)
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver
     layer = EProPnP6DoF(mc_samples=512, num_iter=4, solver=LMSolver(dof=6, num_iter=10))
     assert len(list(layer.parameters())) == 0 and len(list(layer.buffers())) == 0
     layer.solver.num_iter = 5          # Det overrides this at test time via rsetattr
@@ -175,6 +204,100 @@ def test_distributions_and_loss_modules():
     torch.testing.assert_close(v, orc.mc_pose_loss(logw, ct, 2.2), rtol=1e-6, atol=1e-6)
     v2 = loss(logw, ct, 4.0, weight=torch.tensor([1.0, 0.0, 2.0]), avg_factor=3.0)
     assert v2.dim() == 0
+
+
+def test_loss_modules_match_reference_fixture():
+    """Fixture `losses`: the UNMODIFIED loss modules of the reference's two callers (6-DoF lib/models/
+    monte_carlo_pose_loss.py:9-35; detection models/losses/monte_carlo_pose_loss.py:31-66 behind oracle/mmdet_shim.py)
+    -- values for every weight / avg_factor / reduction combination, loss_weight, the norm_factor EMA over two training
+    calls, a NaN object."""
+    from epropnp.losses import MonteCarloPoseLoss
+    g = load_golden('losses')
+    logw, ct, weight, out = g['logw'], g['cost_target'], g['weight'], g['out']
+    close = lambda a, b: torch.testing.assert_close(torch.as_tensor(a), torch.as_tensor(b, dtype=torch.float32), rtol=1e-6, atol=1e-6)
+    m6 = MonteCarloPoseLoss(init_norm_factor=2.0, momentum=0.1)            # the 6-DoF caller's constructor arguments
+    close(m6(logw.clone(), ct, g['nf0']), out['six.call0'])
+    close(m6(logw.clone(), ct, g['nf1']), out['six.call1'])
+    close(m6.norm_factor, out['six.norm_factor'])
+    m6.eval()
+    close(m6(logw.clone(), ct, g['nf0']), out['six.eval'])
+    md = MonteCarloPoseLoss(loss_weight=0.5, init_norm_factor=2.0, momentum=0.1)
+    close(md(logw.clone(), ct, g['nf0']), out['det.call0'])
+    close(md(logw.clone(), ct, g['nf1'], weight=weight, avg_factor=3.5), out['det.call1'])
+    close(md.norm_factor, out['det.norm_factor'])
+    md.eval()
+    n = 0
+    for red in ('mean', 'sum', 'none'):
+        for wname, w in (('w0', None), ('w1', weight)):
+            for aname, af in (('a0', None), ('a1', 3.5)):
+                if af is not None and red == 'sum':
+                    with pytest.raises((ValueError, AssertionError)):
+                        md(logw.clone(), ct, g['nf0'], weight=w, avg_factor=af, reduction_override=red)
+                    continue
+                close(md(logw.clone(), ct, g['nf0'], weight=w, avg_factor=af, reduction_override=red),
+                      out[f'det.{red}.{wname}.{aname}'])
+                n += 1
+    assert n == 10
+    with pytest.raises(AssertionError):
+        md(logw, ct, g['nf0'], reduction_override='max')
+
+
+@pytest.mark.parametrize('dof', [6, 4])
+def test_amis_extension_hooks_reproduce_the_sampler(backend, dof):
+    """allocate_buffer / initial_fit / gen_new_distr / gen_old_distr / estimate_params (epropnp.py:199-342): the AMIS
+    loop of epropnp.py:132-182 written with the hooks (PyTorch), fed the kernel's own samples, arrives at the proposals
+    the fused kernel fitted and at its log-weights."""
+    import math
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+    B, N, S, K = 4, 64, 64, 4
+    s = S // K
+    prob = orc.make_problem(B, N, dof, seed=17)
+    noise = orc.make_noise(B, S, K, dof, seed=18)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 4, with_pose_cov=True)
+    samples, logw, props = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=pack_noise(noise, dof).to(backend),
+                                          with_proposals=True)
+    samples, logw, props = samples.cpu().double(), logw.cpu().double(), props.cpu()
+    pose_opt, pose_cov = pose_opt.cpu().double(), pose_cov.cpu().double()
+    layer = (EProPnP6DoF if dof == 6 else EProPnP4DoF)(mc_samples=S, num_iter=K)
+    bufs = layer.allocate_buffer(B, dtype=torch.float64)
+    assert [tuple(b.shape) for b in bufs][:2] == [(K, B, 3), (K, B, 3, 3)]
+    layer.initial_fit(pose_opt, pose_cov, PerspectiveCamera(cam_mats=prob['cam_mats'].double()), *bufs)
+    cost = orc.evaluate(prob['x3d'].double(), prob['x2d'].double(), prob['w2d'].double(), samples,
+                        orc.Cam(prob['cam_mats'].double(), 0.1), prob['delta'].double(), want_cost=True)[1]
+    logprobs = torch.zeros(K, K, s, B, dtype=torch.float64)
+    blocks = samples.reshape(K, s, B, -1)
+    for i in range(K):
+        new_t, new_r = layer.gen_new_distr(i, *bufs)
+        assert new_t.rsample((3,)).shape == (3, B, 3)
+        seen = blocks[:i + 1]                                             # (i+1,s,B,p)
+        logprobs[i, :i + 1] = new_t.log_prob(seen[..., :3]) + new_r.log_prob(seen[..., 3:]).reshape(i + 1, s, B)
+        if i > 0:
+            old_t, old_r = layer.gen_old_distr(i, *bufs)
+            logprobs[:i, i] = old_t.log_prob(blocks[i][..., :3]) + old_r.log_prob(blocks[i][..., 3:]).reshape(i, s, B)
+        mix = torch.logsumexp(logprobs[:i + 1, :i + 1], dim=0) - math.log(i + 1)
+        lw = -cost.reshape(K, s, B)[:i + 1] - mix
+        if i < K - 1:
+            layer.estimate_params(i, samples[:(i + 1) * s], lw.reshape(-1, B), *bufs)
+    assert (lw.reshape(S, B) - logw).abs().max().item() <= 5e-4 * max(1.0, logw.abs().max().item())
+
+    def tril(v, n):
+        L = torch.zeros(v.shape[:-1] + (n, n), dtype=torch.float64)
+        idx = torch.tril_indices(n, n)
+        L[..., idx[0], idx[1]] = v.double()
+        return L
+    rec = props.permute(1, 0, 2)                                          # (K,B,40)
+    torch.testing.assert_close(rec[..., 0:3].double(), bufs[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(tril(rec[..., 3:9], 3), bufs[1], rtol=2e-3, atol=1e-5)
+    if dof == 6:
+        torch.testing.assert_close(tril(rec[..., 16:26], 4), bufs[2], rtol=5e-3, atol=2e-5)
+    else:
+        d = (rec[..., 16:17].double() - bufs[2]).abs()
+        assert torch.minimum(d, 2 * math.pi - d).max() < 1e-4
+        torch.testing.assert_close(rec[..., 17:18].double(), bufs[3], rtol=2e-3, atol=1e-6)
 
 
 def test_fused_delta_and_loss_match_torch(backend):

@@ -1,5 +1,7 @@
-"""Fused correspondence pre-processing (csrc/eval_kernels.hip: prepare_{forward,backward}_kernel) vs its PyTorch
-definition, which restates EPro-PnP-6DoF/lib/train.py:141,163-166 and EPro-PnP-Det deform_pnp_head.py:418-423,873-875."""
+"""Fused correspondence pre-processing (csrc/eval_kernels.hip: prepare_{forward,backward}_kernel) vs the reference's own
+outputs (fixtures prep_dense / prep_det: produced by exec'ing EPro-PnP-6DoF/lib/train.py:141-165 and EPro-PnP-Det
+deform_pnp_head.py:418-421,873-874, oracle/make_golden.py:case_preprocess) and vs the restatement pinned by them
+(oracle/preprocess_oracle.py) for gradients and other shapes."""
 import math
 
 import pytest
@@ -9,7 +11,8 @@ import torch
 @pytest.mark.parametrize('mode', ['softmax', 'mean_exp'])
 @pytest.mark.parametrize('with_x3d,with_scale,N', [(True, True, 200), (False, True, 64), (True, False, 33)])
 def test_prepare_matches_torch(backend, mode, with_x3d, with_scale, N):
-    from epropnp.preprocess import _reference, prepare_correspondences
+    from epropnp.preprocess import prepare_correspondences
+    from preprocess_oracle import prepare_ref as _reference
     g = torch.Generator().manual_seed(N)
     B = 5
     noc = (torch.rand(B, N, 3, generator=g) - 0.5) if with_x3d else None
@@ -60,7 +63,8 @@ def test_prepare_dense_matches_reference_composite(backend, mode, with_x3d, with
     """Dense maps + sampled pixels (EPro-PnP-6DoF/lib/train.py:141-166): the fused gather against the PyTorch composite
     (meshgrid, flatten/transpose/index, mean-normalised exp) -- x2d bit-exact, the rest and all gradients to fp32 rounding."""
     import numpy as np
-    from epropnp.preprocess import _reference_dense, box_grid_params, prepare_dense_correspondences
+    from epropnp.preprocess import box_grid_params, prepare_dense_correspondences
+    from preprocess_oracle import prepare_dense_ref as _reference_dense
     g = torch.Generator().manual_seed(H * W + N)
     B = 3
     noc = (torch.rand(B, 3, H, W, generator=g) - 0.5) if with_x3d else None
@@ -100,7 +104,8 @@ def test_prepare_dense_matches_reference_composite(backend, mode, with_x3d, with
 
 def test_prepare_dense_repeated_pixels_accumulate(backend):
     """`inds` may repeat a pixel (sampling with replacement): the map gradients accumulate like index_put_(accumulate=True)."""
-    from epropnp.preprocess import _reference_dense, prepare_dense_correspondences
+    from epropnp.preprocess import prepare_dense_correspondences
+    from preprocess_oracle import prepare_dense_ref as _reference_dense
     g = torch.Generator().manual_seed(3)
     logits = torch.randn(2, 2, 4, 4, generator=g)
     box = torch.tensor([[0.0, 0.0, 1.0], [10.0, 20.0, 2.5]])
@@ -115,3 +120,31 @@ def test_prepare_dense_repeated_pixels_accumulate(backend):
     assert torch.equal(outs[0][0], outs[1][0])
     torch.testing.assert_close(outs[1][1], outs[0][1], rtol=2e-5, atol=1e-7)
     torch.testing.assert_close(outs[1][2], outs[0][2], rtol=1e-4, atol=1e-6)
+
+
+def test_prepare_matches_reference_fixtures(backend):
+    """The literal reference lines, executed in the build container: 6-DoF dense gather + mean-normalised exp, and the
+    detection head's softmax x scale."""
+    from helpers import load_golden
+    from epropnp.preprocess import box_grid_params, prepare_correspondences, prepare_dense_correspondences
+    g = load_golden('prep_dense')
+    box = box_grid_params(g['c_box'], g['s_box'], 64)
+    assert torch.equal(box, g['box'])
+    x3d, x2d, w2d = prepare_dense_correspondences(g['noc'].to(backend), g['dim'].to(backend), g['logit'].to(backend),
+                                                  g['scale'].to(backend), box.to(backend), g['inds'].to(backend), 'mean_exp')
+    assert torch.equal(x2d.cpu(), g['x2d'])                                   # mul then add, un-fused: bit-exact
+    torch.testing.assert_close(x3d.cpu(), g['x3d'], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(w2d.cpu(), g['w2d'], rtol=2e-5, atol=1e-7)
+    d = load_golden('prep_det')
+    x3d, w2d = prepare_correspondences(d['noc'].to(backend), d['dim'].to(backend), d['logits'].to(backend),
+                                       d['scale'].to(backend), 'softmax')
+    torch.testing.assert_close(x3d.cpu(), d['x3d'], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(w2d.cpu(), d['w2d'], rtol=2e-5, atol=1e-7)
+
+
+def test_prepare_refuses_cpu_tensors():
+    import install as emu
+    from epropnp.preprocess import prepare_correspondences
+    emu.uninstall()
+    with pytest.raises(RuntimeError, match='HIP device'):
+        prepare_correspondences(None, None, torch.zeros(2, 8, 2), None, 'softmax')

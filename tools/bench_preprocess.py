@@ -10,7 +10,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'epro-pnp_amd'))
-from epropnp.preprocess import _reference_dense, box_grid_params, prepare_dense_correspondences  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))      # the PyTorch composite being compared against is test infrastructure
+from epropnp.preprocess import box_grid_params, prepare_dense_correspondences  # noqa: E402
+from preprocess_oracle import prepare_dense_ref as _reference_dense  # noqa: E402
 
 
 def main():
