@@ -1,21 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- EPro-PnP hot path throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config ...]
 
 One "step" = one pass of the hot path over one batch of synthetic objects:
-    cost(pose_init) -> fused LM solve (1+L sweeps) -> fused AMIS sampler (S pose evaluations) -> Monte-Carlo pose
-    loss -> backward to d/dx3d, d/dx2d, d/dw2d (one recompute kernel + autograd through set_param / the loss).
-Workload (BASELINE.json configs[1], "C2"): B=4096 objects x N=512 points, S=512 samples, K=4 AMIS iterations,
-L=3 LM iterations, 6-DoF, fp32, inputs resident in HBM before the timed region.  Objects shard over ranks with no
-data-path collective (every rank owns B objects: weak scaling).
+    cost(pose_init) -> [RSLM initialiser] -> fused LM solve (1+L sweeps) -> fused AMIS sampler (S pose evaluations) ->
+    Monte-Carlo pose loss -> backward to d/dx3d, d/dx2d, d/dw2d (one recompute kernel + autograd through set_param / loss).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the Jacobian sweep of the fused LM kernel (HBM-bound by
-construction, SURVEY.md 8d: 28 B/point per logical sweep); `roofline_valu` reports the VALU-bound AMIS kernels
-against the fp32 vector peak.  `cpu_baseline` is the oracle (a PyTorch-CPU restatement with the reference's op
-structure, pinned to the reference) timed on a bounded sample of the same workload on the host cores.
+--config (BASELINE.json `configs`), one process per GPU, objects sharded over ranks:
+  C2 (default, the headline metric): 4096 objects/GPU x N=512 points, S=512, K=4, L=3, 6-DoF.  Every rank owns its own
+      objects, NO data-path collective: weak scaling.
+  C5 (stress): 65 536 objects over 8 GPUs = 8192 objects/GPU x N=2048 x S=1024, disjoint shards, no collective: weak.
+  C4 (EPro-PnP-Det nuScenes shape): ONE batch of 600 objects x N=128, 4-DoF, RSLM(16,64,3) + LM 5 + AMIS S=128/K=4,
+      normalize=True, split contiguously over the ranks (75/GPU at 8: `sharding.shard_objects`), fwd+bwd on the shard,
+      then ONE RCCL `all_gather_into_tensor` of the pose outputs (`sharding.gather_objects`) and the scalar world-mean
+      of norm_factor (MonteCarloPoseLoss) -- both INSIDE the timed region: strong scaling.  The line reports the
+      collective's share of the step.
+fp32, inputs resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is the Jacobian sweep: the fused LM kernel credited one 28 B/point read per
+logical sweep with its physical traffic beside it, and `roofline.single_sweep` = normal_equations_kernel,
+where one logical sweep IS one physical read of the correspondences, timed after the step loop on the same inputs.
+`roofline_valu` reports the VALU-bound AMIS kernels against the fp32 vector peak.  `cpu_baseline` is the oracle (a
+PyTorch-CPU restatement with the reference's op structure, pinned to the reference and timed beside it in
+profiles/r02_cpu_reference_vs_oracle.txt) on a bounded sample of the same workload on the host cores.
 """
 import argparse
 import json
@@ -133,20 +143,65 @@ def hipgraph_replay():
         return {'error': str(e)[:200]}
 
 
+CONFIGS = {
+    # name: objects (per GPU for weak configs / total for the strong one), points, samples, AMIS iters, LM iters, dof
+    'C2': dict(objects=4096, points=512, samples=512, amis_iters=4, lm_iters=3, dof=6, scaling='weak'),
+    'C5': dict(objects=8192, points=2048, samples=1024, amis_iters=4, lm_iters=3, dof=6, scaling='weak'),
+    'C4': dict(objects=600, points=128, samples=128, amis_iters=4, lm_iters=5, dof=4, scaling='strong'),
+}
+
+
+def measured_traffic(kernel, shape_key):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json, written by
+    tools/pmc_traffic.py from separate --pmc runs; gfx950 corrections applied there) -- None when no profile of this
+    exact shape is on file, so a stale number can never be attached to a changed workload."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    try:
+        rec = json.load(open(path)).get(shape_key, {}).get(kernel)
+    except (OSError, ValueError):
+        return None, None
+    if not rec:
+        return None, None
+    return rec['hbm_bytes_per_launch'], 'profiles/r02_pmc_traffic.json'
+
+
+def single_sweep(F, prob_hip, pose, launches=50):
+    """normal_equations_kernel alone (one logical sweep = one physical read of the correspondences): mean launch time
+    from HIP events on the launch stream, after `launches // 5` warm-ups."""
+    for _ in range(max(2, launches // 5)):
+        F.normal_equations(prob_hip, pose)
+    evs = []
+    for _ in range(launches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        F.normal_equations(prob_hip, pose)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--objects', type=int, default=4096, help='objects per GPU')
-    ap.add_argument('--points', type=int, default=512)
-    ap.add_argument('--samples', type=int, default=512)
-    ap.add_argument('--amis-iters', type=int, default=4)
-    ap.add_argument('--lm-iters', type=int, default=3)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='C2', help='BASELINE.json configuration (default: C2)')
+    ap.add_argument('--objects', type=int, default=None, help='objects per GPU (C2, C5) / in the whole batch (C4)')
+    ap.add_argument('--points', type=int, default=None)
+    ap.add_argument('--samples', type=int, default=None)
+    ap.add_argument('--amis-iters', type=int, default=None)
+    ap.add_argument('--lm-iters', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hipgraph', action='store_true', help='skip the informational hipGraph replay measurement')
     ap.add_argument('--cpu-sample', type=int, default=64)
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ('objects', 'points', 'samples', 'amis_iters', 'lm_iters'):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    default_shape = all(cfg[k] == CONFIGS[args.config][k] for k in cfg)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -155,37 +210,73 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:          # under torchrun also with one rank: the RCCL path is then exercised
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', device_id=dev)
     assert world == args.gpus or world == 1 and args.gpus == 1, f'WORLD_SIZE={world} but --gpus {args.gpus}'
 
     from epropnp import functional as F
+    from epropnp import sharding
     from epropnp.camera import PerspectiveCamera
     from epropnp.cost_fun import AdaptiveHuberPnPCost
-    from epropnp.epropnp import EProPnP6DoF
-    from epropnp.levenberg_marquardt import LMSolver
-    from epropnp.losses import monte_carlo_pose_loss
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+    from epropnp.losses import MonteCarloPoseLoss, monte_carlo_pose_loss
 
-    B, N, S, K, L = args.objects, args.points, args.samples, args.amis_iters, args.lm_iters
-    prob = synth_problem(B, N, dev, seed=1000 + rank)      # every rank owns its own shard of objects
+    N, S, K, L, dof = cfg['points'], cfg['samples'], cfg['amis_iters'], cfg['lm_iters'], cfg['dof']
+    strong = cfg['scaling'] == 'strong'
+    if strong:      # ONE batch (the same on every rank), split contiguously over the ranks
+        total = cfg['objects']
+        full = synth_problem(total, N, dev, seed=1000, dof=dof)
+        lo, hi = sharding.shard_range(total, rank, world)
+        prob = {k: v[lo:hi].contiguous() for k, v in full.items()}
+        B = hi - lo
+    else:           # every rank owns its own shard of objects
+        B = cfg['objects']
+        total = B * world
+        prob = synth_problem(B, N, dev, seed=1000 + rank, dof=dof)
     x3d, x2d, w2d = (prob[k].requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
-    camera = PerspectiveCamera(cam_mats=prob['cam_mats'], z_min=0.1)
     cost_fun = AdaptiveHuberPnPCost(relative_delta=0.5)
-    layer = EProPnP6DoF(mc_samples=S, num_iter=K, solver=LMSolver(dof=6, num_iter=L), seed=1 + rank)
+    if args.config == 'C4':
+        camera = PerspectiveCamera(z_min=0.1, allowed_border=200)
+        camera.set_param(prob['cam_mats'], img_shape=torch.tensor([[480., 640.]], device=dev).expand(B, 2))
+        init = RSLMSolver(dof=4, num_points=16, num_proposals=64, num_iter=3)
+        layer = EProPnP4DoF(mc_samples=S, num_iter=K, normalize=True, seed=1 + rank,
+                            solver=LMSolver(dof=4, num_iter=L, init_solver=init))
+        loss_mod = MonteCarloPoseLoss(momentum=0.01).to(dev)           # training mode: world-mean of norm_factor
+        force_init = True
+    else:
+        camera = PerspectiveCamera(cam_mats=prob['cam_mats'], z_min=0.1)
+        layer = EProPnP6DoF(mc_samples=S, num_iter=K, solver=LMSolver(dof=6, num_iter=L), seed=1 + rank)
+        loss_mod, force_init = None, False
 
     timers = {n: KernelTimer(F, n) for n in ('lm_solve', 'amis_forward', 'amis_backward', 'evaluate_cost')}
     # (the adaptive-delta and Monte-Carlo-loss kernels are part of the step as well, untimed individually)
+    coll_events = []
+    gathered = {}
 
-    def step():
+    def step(timed=False):
         for t in (x3d, x2d, w2d):
             t.grad = None
         cost_fun.set_param(x2d.detach(), w2d)
-        _, _, _, _, logw, cost_init = layer.monte_carlo_forward(x3d, x2d, w2d, camera, cost_fun,
-                                                                pose_init=prob['pose_init'], force_init_solve=False)
-        loss = monte_carlo_pose_loss(logw, cost_init).mean()           # Monte-Carlo pose (KL) loss, NaN -> 0
+        pose_opt, _, _, _, logw, cost_init = layer.monte_carlo_forward(x3d, x2d, w2d, camera, cost_fun,
+                                                                      pose_init=prob['pose_init'], force_init_solve=force_init)
+        if loss_mod is None:
+            loss = monte_carlo_pose_loss(logw, cost_init).mean()       # Monte-Carlo pose (KL) loss, NaN -> 0
+        else:     # detection loss: per-object weights, avg_factor = the whole batch, world-mean EMA of norm_factor
+            loss = loss_mod(logw, cost_init, w2d.detach().sum() / max(2 * B, 1), avg_factor=float(total))
         loss.backward()
+        if strong:   # the end-to-end Det exchange: every rank receives all pose outputs (one all_gather_into_tensor)
+            e0 = e1 = None
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            gathered['pose_opt'] = sharding.gather_objects(pose_opt, total, obj_dim=0, force_collective=dist is not None)
+            if timed:
+                e1.record()
+                coll_events.append((e0, e1))
         return loss
 
     def fence():
@@ -201,7 +292,7 @@ def main():
         t.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = step(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
     loss_val = float(loss.detach())
@@ -209,37 +300,57 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
+    if strong:
+        assert gathered['pose_opt'].shape[0] == total
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
+        value = total * args.steps / elapsed
         t_lm = timers['lm_solve'].mean_ms()
         t_fw = timers['amis_forward'].mean_ms()
         t_bw = timers['amis_backward'].mean_ms()
         t_ci = timers['evaluate_cost'].mean_ms()
         sweeps = 1 + L
-        lm_bytes = sweeps * 28.0 * B * N + B * 4.0 * (7 + 9 + 1) + B * 4.0 * (7 + 36 + 1)
+        p_len, d = (7, 6) if dof == 6 else (4, 4)
+        lm_bytes = sweeps * 28.0 * B * N + B * 4.0 * (p_len + 9 + 1) + B * 4.0 * (p_len + d * d + 1)
         lm_gbs = lm_bytes / (t_lm * 1e-3) / 1e9
         fw_tf = 40.0 * S * N * B / (t_fw * 1e-3) / 1e12
         bw_tf = 80.0 * (S + 1) * N * B / (t_bw * 1e-3) / 1e12
+        shape_key = f'{args.config}:B{B}:N{N}:S{S}:K{K}:L{L}' if default_shape else None
+        lm_traffic, lm_src = measured_traffic('lm_solve_kernel', shape_key) if shape_key else (None, None)
+        # one physical sweep: normal_equations_kernel on the same correspondences (after the timed region)
+        hp = F.PnPProblem(x3d.detach(), x2d.detach(), w2d.detach(), camera, cost_fun, dof)
+        ne_mean_ms, ne_median_ms = single_sweep(F, hp, prob['pose_init'])
+        ne_bytes = B * (28.0 * N + 4.0 * (p_len + 9 + 1 + 4) + 4.0 * (d * (d + 1) // 2 + d + 1))
+        ne_gbs = ne_bytes / (ne_mean_ms * 1e-3) / 1e9
+        ne_traffic, ne_src = measured_traffic('normal_equations_kernel', shape_key) if shape_key else (None, None)
+        names = {'C2': 'C2 batched synthetic', 'C5': 'C5 stress (one shard per GPU)', 'C4': 'C4 EPro-PnP-Det nuScenes shape'}
+        par = (f'one batch of {total} objects split x{world} ({B} on rank 0), all_gather_into_tensor of pose outputs + '
+               f'world-mean of norm_factor inside the step') if strong else f'objects sharded x{world}, no data-path collective'
         out = {
-            'metric': 'PnP instances/sec (fwd+bwd, N=512 pts, 512 samples)',
+            'metric': f'PnP instances/sec (fwd+bwd, N={N} pts, {S} samples)',
             'value': round(value, 1), 'unit': 'instances/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': cfg['scaling'],
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'C2 batched synthetic: {B} objects/GPU x N={N} points, S={S} MC samples, '
-                                   f'K={K} AMIS iters, L={L} LM iters, EProPnP6DoF fwd+bwd',
-                       'objects_per_gpu': B, 'num_points': N, 'mc_samples': S, 'amis_iters': K, 'lm_iters': L,
-                       'dof': 6, 'parallelism': f'objects sharded x{world}, no data-path collective'},
+            'config': {'workload': f'{names[args.config]}: {B} objects/GPU x N={N} points, S={S} MC samples, '
+                                   f'K={K} AMIS iters, L={L} LM iters, EProPnP{dof}DoF fwd+bwd'
+                                   + (', RSLM(16,64,3) init, normalize=True, Det loss' if args.config == 'C4' else ''),
+                       'name': args.config, 'objects_per_gpu': B, 'objects_total': total, 'num_points': N, 'mc_samples': S,
+                       'amis_iters': K, 'lm_iters': L, 'dof': dof, 'parallelism': par},
             'roofline': {'kernel': 'lm_solve_kernel (Jacobian sweep, fused 1+L sweeps)', 'bound': 'hbm',
                          'achieved': round(lm_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(lm_gbs / HBM_PEAK_GBS, 4),
-                         # HBM bytes per launch from rocprofv3 PMC (separate passes): 2 x FETCH_SIZE (gfx950 counts a
-                         # coalesced read at half size, MI355X_MICROARCH.md) + WRITE_SIZE, for the default C2 workload:
-                         # profiles/r01_final_pmc_counters.txt (FETCH_SIZE 29260.6 KiB, WRITE_SIZE 688.9 KiB)
-                         'traffic': (2 * 29260.6 + 688.9) * 1024 if (B, N, L) == (4096, 512, 3) else None,
+                         # HBM bytes per launch from rocprofv3 PMC (separate passes; gfx950: 2 x FETCH_SIZE + WRITE_SIZE,
+                         # MI355X_MICROARCH.md), read from the committed profile of this exact shape -- or null
+                         'traffic': lm_traffic, 'traffic_source': lm_src,
                          'algorithmic_bytes_per_launch': lm_bytes, 'logical_sweeps': sweeps,
-                         'launch_ms': round(t_lm, 4)},
+                         'launch_ms': round(t_lm, 4),
+                         'physical_frac': None if lm_traffic is None else round(lm_traffic / (t_lm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         'single_sweep': {'kernel': 'normal_equations_kernel (one logical = one physical sweep)',
+                                          'bound': 'hbm', 'achieved': round(ne_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                          'frac': round(ne_gbs / HBM_PEAK_GBS, 4), 'algorithmic_bytes_per_launch': ne_bytes,
+                                          'launch_ms': round(ne_mean_ms, 5), 'launch_ms_median': round(ne_median_ms, 5),
+                                          'traffic': ne_traffic, 'traffic_source': ne_src}},
             'roofline_valu': {
                 'amis_forward_mfma_kernel': {'bound': 'valu_fp32', 'achieved': round(fw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
                                         'unit': 'TFLOP/s', 'frac': round(fw_tf / FP32_VECTOR_PEAK_TF, 4),
@@ -251,10 +362,16 @@ def main():
                           'amis_backward': round(t_bw, 4)},
             'loss': round(loss_val, 5),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(N, S, K, L, args.cpu_sample)
+        if strong:
+            c_ms = sum(a.elapsed_time(b) for a, b in coll_events) / max(len(coll_events), 1)
+            out['collective'] = {'op': 'all_gather_into_tensor(pose_opt) per step (+ scalar all_reduce of norm_factor in the loss)',
+                                 'backend': 'nccl (RCCL)' if dist is not None else 'none (single process)',
+                                 'ms_per_step_rank0': round(c_ms, 4), 'share_of_step': round(c_ms / ms, 4),
+                                 'bytes_per_rank': int(gathered['pose_opt'].numel() * 4)}
+        if world == 1 and not args.no_cpu_baseline and dof == 6:
+            out['cpu_baseline'] = cpu_baseline(N, S, K, L, args.cpu_sample if args.config == 'C2' else 8)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
-        if world == 1 and not args.no_hipgraph and (B, N, S, K, L) == (4096, 512, 512, 4, 3):
+        if world == 1 and not args.no_hipgraph and args.config == 'C2' and default_shape:
             out['hipgraph_replay'] = hipgraph_replay()      # informational: the same step replayed from a hipGraph
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -31,10 +31,12 @@ def shard_objects(tensors, num_obj, obj_dim=0, rank=None, world_size=None):
     return out
 
 
-def gather_objects(local, num_obj, obj_dim=0, group=None):
+def gather_objects(local, num_obj, obj_dim=0, group=None, force_collective=False):
     """Inverse of shard_objects for an output tensor: every rank receives the full (num_obj, ...) tensor.
-    One `all_gather_into_tensor` over equally padded per-rank chunks (uneven tails are padded, then trimmed)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    One `all_gather_into_tensor` over equally padded per-rank chunks (uneven tails are padded, then trimmed).
+    A single-rank group returns `local` untouched unless `force_collective` asks for the (trivial) collective anyway --
+    bench.py does, so that the very code path of the 8-GPU run executes under `torchrun --nproc-per-node 1`."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return local
     world = dist.get_world_size(group)
     chunk = (num_obj + world - 1) // world

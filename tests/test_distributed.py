@@ -81,3 +81,77 @@ def test_shard_range_covers_everything():
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
             assert max(e[1] - e[0] for e in edges) - min(e[1] - e[0] for e in edges) <= 1
+
+
+def _nccl_worker(rank, world, port, ret):
+    """Object sharding over RCCL on real GPUs: each rank solves its contiguous shard of ONE batch, pose outputs are
+    all-gathered, the result equals the single-GPU run (objects are independent; the gather only moves data)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    try:
+        from epropnp import sharding
+        from epropnp.epropnp import EProPnP4DoF
+        from epropnp.levenberg_marquardt import LMSolver
+        B, N, S, K = 37, 64, 64, 4                       # uneven tail
+        prob = orc.make_problem(B, N, 4, seed=40, bounds='tensor')
+        noise = pack_noise(orc.make_noise(B, S, K, 4, seed=41), 4)
+
+        def run(lo, hi):
+            sub = {k: (v[lo:hi] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == B else v) for k, v in prob.items()}
+            p, cam, cf = make_layer_objects(sub, dev, relative_delta=0.5)
+            cf.set_param(p['x2d'], p['w2d'])
+            layer = EProPnP4DoF(mc_samples=S, num_iter=K, normalize=True, solver=LMSolver(dof=4, num_iter=5))
+            out = layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'],
+                                            force_init_solve=False, noise=noise[lo:hi].contiguous().to(dev))
+            return out[0], out[4]
+        lo, hi = sharding.shard_range(B)
+        pose_l, logw_l = run(lo, hi)
+        pose = sharding.gather_objects(pose_l, B, obj_dim=0, force_collective=True)
+        logw = sharding.gather_objects(logw_l, B, obj_dim=1, force_collective=True)
+        pose_full, logw_full = run(0, B)
+        # launch shapes depend on the batch size, so shard vs full batch agree to rounding, not bit for bit
+        ret[rank] = bool(pose.shape == (B, 4) and logw.shape == (S, B) and (pose - pose_full).abs().max().item() < 1e-5
+                         and (torch.logsumexp(logw, 0) - torch.logsumexp(logw_full, 0)).abs().max().item() < 1e-3)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_object_sharding_all_gather_nccl():
+    """RCCL `all_gather_into_tensor` of the pose outputs: 2 ranks when the box has two GPUs, otherwise the same code path
+    (process group on the nccl backend, forced collective) with a single rank."""
+    import install as emu
+    emu.uninstall()
+    world = 2 if torch.cuda.device_count() >= 2 else 1
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_nccl_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {r: True for r in range(world)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('config', ['C4', 'C5'])
+def test_bench_multi_gpu_harness_under_torchrun(config):
+    """The command the driver launches on an 8-GPU node, here with one rank: bench.py --config C4 (600 objects split over
+    the ranks + all_gather_into_tensor of the pose outputs inside the timed region) / C5 (disjoint shards) under
+    torch.distributed.run on the nccl backend."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    extra = ['--objects', '512'] if config == 'C5' else []          # a slice of the 8192-object shard: keeps the test short
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+           '--config', config, '--no-cpu-baseline', '--no-hipgraph'] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['config']['name'] == config and line['value'] > 0
+    assert line['roofline']['single_sweep']['achieved'] > 0
+    if config == 'C4':
+        assert line['scaling'] == 'strong' and line['config']['objects_total'] == 600
+        assert line['collective']['backend'].startswith('nccl') and line['collective']['bytes_per_rank'] == 600 * 4 * 4
+    else:
+        assert line['scaling'] == 'weak' and 'collective' not in line
