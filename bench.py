@@ -165,20 +165,22 @@ def measured_traffic(kernel, shape_key):
     return rec['hbm_bytes_per_launch'], 'profiles/r02_pmc_traffic.json'
 
 
-def single_sweep(F, prob_hip, pose, launches=50):
-    """normal_equations_kernel alone (one logical sweep = one physical read of the correspondences): mean launch time
-    from HIP events on the launch stream, after `launches // 5` warm-ups."""
-    for _ in range(max(2, launches // 5)):
+def single_sweep(F, prob_hip, pose, windows=8, inner=10):
+    """normal_equations_kernel alone (one logical sweep = one physical read of the correspondences): HIP events on the
+    launch stream around windows of `inner` back-to-back launches (a lone 17 us launch bracketed by its own two events
+    reads ~3 us high) -> (mean, median) ms per launch."""
+    for _ in range(5):
         F.normal_equations(prob_hip, pose)
     evs = []
-    for _ in range(launches):
+    for _ in range(windows):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        F.normal_equations(prob_hip, pose)
+        for _ in range(inner):
+            F.normal_equations(prob_hip, pose)
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    ts = sorted(a.elapsed_time(b) / inner for a, b in evs)
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 

@@ -13,8 +13,9 @@
 //     the previous accumulate -- 1.6-1.9 ms instead of 1.08 ms at C2 (profiles/r01_bwd_mfma_sweep.txt).  Dropped.
 //   * the VALU keeps what is genuinely per pair: perspective divide, weighted residual, Huber weight, and the
 //     accumulation of the gradients (~40 instructions, 2 of them transcendental).
-// The weighted poses are built ONCE into an LDS table (compacted: poses whose weight is below 2^-30 of the object's
-// largest are dropped before tiling, see amis_kernels.hip), then every wave sweeps all pose tiles for its own points.
+// The weighted poses are built ONCE into an LDS table (compacted: the low-weight tail whose total |weight| is below
+// drop_eps -- default 2^-24 -- of the object's total is dropped before tiling, mass_drop_threshold in amis_common.h;
+// EPROPNP_BWD_DROP=0 keeps every non-zero sample), then every wave sweeps all pose tiles for its own points.
 #include "amis_common.h"
 #include "dispatch.h"
 
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
                                                                      const float* __restrict__ g_init, int P16,
                                                                      float* __restrict__ gx3d, float* __restrict__ gx2d,
                                                                      float* __restrict__ gw2d, float* __restrict__ gdelta,
-                                                                     int nsplit) {
+                                                                     int nsplit, float drop_eps) {
   constexpr int PL = PoseLen<DOF>::value;
   // nsplit > 1 (few objects): an object's point chunks are dealt to nsplit workgroups (v = b * nsplit + part), each with
   // its own copy of the pose table; per-point gradients are disjoint, grad_delta comes out as nsplit partials per object
@@ -55,26 +56,31 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   float* wraw = wtab + P16;                             // [P16]      weights by sample index (0 = dropped)
   int* idx = reinterpret_cast<int*>(wraw + P16);        // [P16]      sample index of compacted pose c
   float* red = reinterpret_cast<float*>(idx + P16);     // [80]       reductions, lane counts, active count
+  float* hist = red + 80;                               // [kDropHistFloats] weight histogram of the drop threshold
 
   float Kc[9], delta;
   Bounds bd;
   load_camera<BOUNDS>(p, b, Kc, bd, delta);
   const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
+#ifndef PNP_BWD_NO_FOLD
+  const float tiny_v = to_vgpr(1e-30f);     // keeps rsq finite at a zero residual; folded into the norm's first fma
+#endif
 
   const bool with_init = (pose_init != nullptr) && (g_init != nullptr);
   const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
 
-  // ---- weights, drop threshold, compaction ----
-  constexpr float kSkipRel = 9.313225746154785e-10f;   // 2^-30, see amis_backward_kernel
+  // ---- weights, drop threshold (mass_drop_threshold, amis_common.h), compaction ----
   float amax = 0.f;
-  for (int m = tid; m < S; m += T) amax = fmaxf(amax, fabsf(g_logw[(size_t)m * p.B + b]));
-  amax = block_max(amax, red);
-  const float askip = amax * kSkipRel;
   for (int m = tid; m < P; m += T) {
-    float w = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init[b];       // logw = -cost - const
-    if (m < S && fabsf(w) <= askip) w = 0.f;
+    const float w = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init[b];       // logw = -cost - const
     wraw[m] = w;
+    if (m < S) amax = fmaxf(amax, fabsf(w));
   }
+  amax = block_max(amax, red);          // (barriers inside: wraw is visible to every wave afterwards)
+  __syncthreads();
+  const float askip = mass_drop_threshold([&](int m) { return fabsf(wraw[m]); }, S, amax, drop_eps, hist);
+  for (int m = tid; m < S; m += T)
+    if (fabsf(wraw[m]) <= askip) wraw[m] = 0.f;
   __syncthreads();
   if (wv == 0) {     // ordered compaction by one wave: lane l owns the contiguous samples [l*seg, (l+1)*seg)
     const int seg = (P + 63) >> 6;
@@ -169,8 +175,13 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
             py = fminf(fmaxf(py, bd.lby), bd.uby);
           }
           const float rx = fmaf(px, w4.x, w4.z), ry = fmaf(py, w4.y, w4.w);
+#ifndef PNP_BWD_NO_FOLD
+          const float s2 = fmaf(rx, rx, fmaf(ry, ry, tiny_v));   // |r|^2 + 1e-30: one v_max less per pair than clamping
+          const float rs = fast_rsqrt(s2);
+#else
           const float s2 = fmaf(rx, rx, ry * ry);
           const float rs = fast_rsqrt(fmaxf(s2, 1e-30f));
+#endif
           const float rho = s2 * rs;
           const float mm = fminf(rho, delta_v);
           const float coef = aw[r] * mm * rs;                  // a * min(1, delta / rho)
@@ -243,7 +254,7 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
   const Problem d = to_device_problem(prob);
   const int P = mc_samples + ((pose_init && grad_cost_init) ? 1 : 0);
   const int P16 = ((P + 15) / 16) * 16 + 16;
-  const size_t smem = sizeof(float) * (15 * (size_t)P16 + 80);
+  const size_t smem = sizeof(float) * (15 * (size_t)P16 + 80 + kDropHistFloats);
   if (smem > 160 * 1024) return 1;
   // 4 waves x NPT <= 4 point tiles of 16 per chunk (<= 164 VGPRs: 3 workgroups per CU); larger N loops over chunks of
   // 256 points against the LDS-resident pose table.  Measured at C2: 4x4 (2 chunks) 1.07 ms, 4x8 1.11, 8x4 1.22.
@@ -265,7 +276,7 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
       PNP_LAUNCH(kern, grid, block, smem, st, d, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init, P16,
-                 grad_x3d, grad_x2d, grad_w2d, grad_delta, nsplit);
+                 grad_x3d, grad_x2d, grad_w2d, grad_delta, nsplit, backward_drop_eps());
       return 0;
     });
   });

@@ -173,6 +173,60 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Which samples the backward may skip.  sum_j a_j dc_j/dx is a sum of S terms whose weights a_j (softmax of the AMIS
+// log-weights times the upstream gradient) span tens of orders of magnitude; the per-pair factor dc/dx is bounded
+// (Huber), so terms whose TOTAL weight is below `eps` of the object's total |weight| move the result by less than eps
+// relative -- at the default eps = 2^-24 that is one fp32 rounding of the sum itself.  The threshold is the largest
+// power-of-two fraction of max|a| for which the dropped mass stays within that budget (64 power-of-two bins, summed in
+// a fixed order: results stay bit-reproducible).  eps = 0 keeps every non-zero sample (exact).  Returns t: drop |a| <= t.
+// `wabs(m)` = |a_m| for m < S (wave-uniform argument); hist: LDS, (waves + 1) * 64 floats.  Ends on a barrier.
+constexpr int kDropHistFloats = 17 * 64;
+template <class W>
+__device__ __forceinline__ float mass_drop_threshold(W&& wabs, int S, float amax, float eps, float* hist) {
+  const int nw = (int)(blockDim.x >> 6), w = wave_id(), lane = lane_id();
+  const bool usable = (amax > 0.f) && (amax < INFINITY);          // all-zero / non-finite weights: drop nothing
+  const float inv = usable ? 1.0f / amax : 0.f;
+  const int per = (S + nw - 1) / nw, m0 = w * per, m1 = min(S, m0 + per);
+  float mass = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    const float a = wabs(m);
+    const float rel = a * inv;
+    // bin k holds 2^-(k+1) < rel <= 2^-k (k = 0..62); bin 63 holds the rest, zeros included
+#ifndef EPROPNP_EMU
+    int k = (rel > 0.f) ? (int)(-__builtin_amdgcn_logf(rel)) : 63;
+#else
+    int k = (rel > 0.f) ? (int)(-log2f(rel)) : 63;
+#endif
+    k = min(max(k, 0), 63);
+    mass += (k == lane) ? a : 0.f;
+  }
+  hist[w * 64 + lane] = mass;
+  __syncthreads();
+  if (w == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < nw; ++k) tot += hist[k * 64 + lane];
+    hist[nw * 64 + lane] = tot;
+    wave_lds_fence();
+    if (lane == 0) {
+      float total = 0.f;
+      for (int j = 0; j < 64; ++j) total += hist[nw * 64 + j];
+      const float budget = eps * total;
+      float c = 0.f;
+      int kmin = 64;
+      for (int j = 63; j >= 0; --j) {
+        c += hist[nw * 64 + j];
+        if (c <= budget) kmin = j; else break;
+      }
+      hist[nw * 64] = (usable && kmin < 64) ? ldexpf(amax, -kmin) : 0.f;
+    }
+  }
+  __syncthreads();
+  const float t = hist[nw * 64];
+  __syncthreads();
+  return t;
+}
+
 // log q_j(sample) for proposal record `rec`; sample components passed in registers
 template <int DOF>
 PNP_FN float proposal_logprob(const float* rec, const float* smp /*PL*/) {

@@ -168,11 +168,13 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
                                                                     const float* __restrict__ pose_init,
                                                                     const float* __restrict__ g_init,
                                                                     float* __restrict__ gx3d, float* __restrict__ gx2d,
-                                                                    float* __restrict__ gw2d, float* __restrict__ gdelta) {
+                                                                    float* __restrict__ gw2d, float* __restrict__ gdelta,
+                                                                    float drop_eps) {
   constexpr int PL = PoseLen<DOF>::value;
   // pose tiles: 64 poses x {K R (9) | K t (3) | weight | pad} as 4 float4 rows, double buffered
   __shared__ __attribute__((aligned(16))) float tab[2][64][16];
   __shared__ float red[16];
+  __shared__ float hist[kDropHistFloats];
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x;
@@ -194,14 +196,13 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
   const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
   const int ntile = (P + 63) >> 6;
 
-  // Poses whose weight is below 2^-30 of the object's largest |weight| are dropped: with S <= 2^13 samples their
-  // combined contribution is < 2^-17 of ONE term of the largest kind, i.e. under the fp32 rounding error that the
-  // S-term sums carry anyway.  After softmax normalisation this is ~10-15 % of the AMIS samples (the Student-t tails).
-  constexpr float kSkipRel = 9.313225746154785e-10f;   // 2^-30
+  // Samples whose total |weight| is below drop_eps of the object's total are skipped (mass_drop_threshold,
+  // amis_common.h): at the default 2^-24 that is under the fp32 rounding of the S-term sums; ~17 % of the AMIS samples
+  // after softmax normalisation (the Student-t tails).  drop_eps = 0: exact.
   float amax = 0.f;
   for (int m = tid; m < S; m += T) amax = fmaxf(amax, fabsf(g_logw[(size_t)m * p.B + b]));
   amax = block_max(amax, red);
-  const float askip = amax * kSkipRel;
+  const float askip = mass_drop_threshold([&](int m) { return fabsf(g_logw[(size_t)m * p.B + b]); }, S, amax, drop_eps, hist);
 
   // lanes 0..63 of the workgroup fetch one pose each of tile t (global loads issued early, consumed late)
   float nps[PL], naw = 0.f;
@@ -424,7 +425,7 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((amis_backward_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),
                grid, block, 0, st, d, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init, grad_x3d,
-               grad_x2d, grad_w2d, grad_delta);
+               grad_x2d, grad_w2d, grad_delta, backward_drop_eps());
     return 0;
   });
   return check_launch("amis_backward_kernel");

@@ -13,43 +13,68 @@
 namespace pnp {
 
 // ----------------------------------------------------------------------------------------------------------
-template <int DOF, bool BOUNDS>
-__global__ __launch_bounds__(1024) void normal_equations_kernel(Problem p, const float* __restrict__ pose, int clip,
-                                                                  float* __restrict__ jtj, float* __restrict__ jtr,
-                                                                  float* __restrict__ cost) {
+// PPL >= 1: the object's points are loaded up front into registers (all loads of a lane in flight at once -- this is
+// what lets one sweep approach the HBM rate: the loop form below issues load -> 230-instruction body -> load and was
+// latency-bound at 2.3 TB/s at C2), 64 * waves * PPL >= N.  PPL == 0: streaming loop for N beyond the resident limit.
+template <int DOF, bool BOUNDS, int NV>
+__device__ __forceinline__ void store_normal_equations(const float (&acc)[NV], int b, float* __restrict__ jtj,
+                                                       float* __restrict__ jtr, float* __restrict__ cost) {
+  constexpr int NH = NormalEq<DOF>::NH;
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < DOF; ++i)
+#pragma unroll
+    for (int j = i; j < DOF; ++j) {
+      jtj[(size_t)b * DOF * DOF + i * DOF + j] = acc[idx];
+      jtj[(size_t)b * DOF * DOF + j * DOF + i] = acc[idx];
+      ++idx;
+    }
+#pragma unroll
+  for (int i = 0; i < DOF; ++i) jtr[(size_t)b * DOF + i] = acc[NH + i];
+  cost[b] = acc[NV - 1];
+}
+
+template <int DOF, int PPL, bool BOUNDS, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void normal_equations_kernel(Problem p, const float* __restrict__ pose, int clip,
+                                                                      float* __restrict__ jtj, float* __restrict__ jtr,
+                                                                      float* __restrict__ cost) {
   constexpr int PL = PoseLen<DOF>::value;
-  constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
-  __shared__ float scratch[NV * 16];
+  constexpr int NV = NormalEq<DOF>::NV;
+  PNP_DYN_SMEM(float, scratch);      // waves * kSumTStride<NV> (transposed reduction) or NV * 16 (DPP fallback)
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
   float K[9], R[9], ps[PL], delta;
   Bounds bd;
-  load_camera<BOUNDS>(p, b, K, bd, delta);
-#pragma unroll
-  for (int i = 0; i < PL; ++i) ps[i] = pose[(size_t)b * PL + i];
-  pose_to_rot<DOF>(ps, R);
   float acc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-  for (int n = (int)threadIdx.x; n < p.N; n += (int)blockDim.x) {
-    const Point q = load_point(p, b, n);
-    point_normal_eq<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, bd, clip != 0, acc);
+  if (PPL > 0) {
+    Point pts[PPL > 0 ? PPL : 1];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) pts[k] = load_point(p, b, (int)threadIdx.x + k * (int)blockDim.x);
+    load_camera<BOUNDS>(p, b, K, bd, delta);
+#pragma unroll
+    for (int i = 0; i < PL; ++i) ps[i] = pose[(size_t)b * PL + i];
+    pose_to_rot<DOF>(ps, R);
+    // wave-uniform operands in VGPRs (an SGPR source operand halves the VALU issue rate on gfx950)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { K[i] = to_vgpr(K[i]); R[i] = to_vgpr(R[i]); }
+    float t[3] = {to_vgpr(ps[0]), to_vgpr(ps[1]), to_vgpr(ps[2])};
+    const float zm = to_vgpr(p.z_min), dl = to_vgpr(delta);
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, zm, dl, bd, clip != 0, acc);
+  } else {
+    load_camera<BOUNDS>(p, b, K, bd, delta);
+#pragma unroll
+    for (int i = 0; i < PL; ++i) ps[i] = pose[(size_t)b * PL + i];
+    pose_to_rot<DOF>(ps, R);
+    for (int n = (int)threadIdx.x; n < p.N; n += (int)blockDim.x) {
+      const Point q = load_point(p, b, n);
+      point_normal_eq<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, bd, clip != 0, acc);
+    }
   }
-  block_sum<NV>(acc, scratch);
-  if (threadIdx.x == 0) {
-    int idx = 0;
-#pragma unroll
-    for (int i = 0; i < DOF; ++i)
-#pragma unroll
-      for (int j = i; j < DOF; ++j) {
-        jtj[(size_t)b * DOF * DOF + i * DOF + j] = acc[idx];
-        jtj[(size_t)b * DOF * DOF + j * DOF + i] = acc[idx];
-        ++idx;
-      }
-#pragma unroll
-    for (int i = 0; i < DOF; ++i) jtr[(size_t)b * DOF + i] = acc[NH + i];
-    cost[b] = acc[NV - 1];
-  }
+  if (MAXW <= 4) block_sum_t<NV>(acc, scratch); else block_sum<NV>(acc, scratch);
+  if (threadIdx.x == 0) store_normal_equations<DOF, BOUNDS, NV>(acc, b, jtj, jtr, cost);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -685,17 +710,29 @@ int launch_normal_equations(const epropnp_problem* prob, const float* pose, int 
   if (prob->num_obj == 0) return EPROPNP_OK;
   if (!pose || !jtj || !jtr || !cost) return fail(EPROPNP_EINVAL, "normal_equations: NULL pointer");
   const Problem d = to_device_problem(prob);
-  // streaming kernel: no register residency constraint; 1..4 waves per object
-  int waves = 1;
-  while (waves < 4 && 64 * 8 * waves < d.N) waves *= 2;
-  while (waves < 4 && (long)d.B * waves < 8192) waves *= 2;
-  const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
-  int rc = dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
-    PNP_LAUNCH((normal_equations_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, 0, st, d, pose,
-               clip_jac, jtj, jtr, cost);
+  const dim3 grid(padded_object_grid(d.B));
+  if (d.N > kMaxResidentPoints) {     // streaming loop, 8 waves per object
+    dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+      PNP_LAUNCH((normal_equations_kernel<decltype(DOF)::value, 0, decltype(BND)::value, 8>), grid, dim3(512),
+                 sizeof(float) * NormalEq<decltype(DOF)::value>::NV * 16, st, d, pose, clip_jac, jtj, jtr, cost);
+      return 0;
+    });
+    return check_launch("normal_equations_kernel (streaming)");
+  }
+  // one sweep, latency matters more than anything: the fewest waves that hold the points, as in lm_solve_kernel.
+  // (Two objects per wave, the second one's loads in flight while the first computes, was built and measured at C2:
+  //  22.9 us against 21.3 us -- 190 VGPRs halve the occupancy and cost more than the overlap gains.)
+  Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/0);
+  int ov[2];
+  if (env_ints("EPROPNP_NE_SHAPE", ov, 2) && 64 * ov[0] * ov[1] >= d.N) { s.waves = ov[0]; s.ppl = ov[1]; }
+  dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
+    PNP_LAUNCH((normal_equations_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),
+               grid, dim3(64 * s.waves),
+               sizeof(float) * (decltype(MAXW)::value <= 4 ? s.waves * kSumTStride<NormalEq<decltype(DOF)::value>::NV>
+                                                           : NormalEq<decltype(DOF)::value>::NV * 16),
+               st, d, pose, clip_jac, jtj, jtr, cost);
     return 0;
   });
-  (void)rc;
   return check_launch("normal_equations_kernel");
 }
 

@@ -80,6 +80,18 @@ inline bool env_ints(const char* name, int* out, int n) {
   return true;
 }
 
+// Fraction of an object's total |weight| that the backward may leave out (see mass_drop_threshold, amis_common.h).
+// Default 2^-24; EPROPNP_BWD_DROP=<float> overrides it, 0 = exact (every non-zero sample is evaluated).
+inline float backward_drop_eps() {
+  const char* v = getenv("EPROPNP_BWD_DROP");
+  if (v && *v) {
+    char* end = nullptr;
+    const float f = strtof(v, &end);
+    if (end != v && f >= 0.f && f < 1.f) return f;
+  }
+  return 5.9604644775390625e-08f;
+}
+
 // launchers (one per .hip translation unit)
 int launch_evaluate_cost(const epropnp_problem* prob, const float* poses, int num_poses, float* cost, hipStream_t st);
 int launch_normal_equations(const epropnp_problem* prob, const float* pose, int clip_jac, float* jtj, float* jtr,

@@ -330,3 +330,43 @@ def test_von_mises_draws_match_numpy_stream(backend):
     # fp32 uniforms (the fixture's doubles rounded) move a draw by ~1e-7 * d(angle)/du; 2e-5 rad as in the oracle test above
     assert d[n_u:].max().item() < 2e-5, d[n_u:].max(0).values
     assert d[:n_u].max().item() < 2e-6
+
+
+@pytest.mark.parametrize('impl', ['mfma', 'valu'])
+def test_backward_drop_threshold_is_mass_bounded(backend, monkeypatch, impl):
+    """The backward skips the low-weight tail whose TOTAL |weight| is below EPROPNP_BWD_DROP (default 2^-24) of the
+    object's total (csrc/amis_common.h: mass_drop_threshold).  Heavy-tailed softmax weights (most samples negligible):
+    the default differs from the exact sum (EPROPNP_BWD_DROP=0) by rounding only, a coarse 1e-3 budget by at most ~1e-3."""
+    from epropnp import functional as F
+    monkeypatch.setenv('EPROPNP_BWD_IMPL', impl)
+    B, N, S, dof = 3, 100, 256, 6
+    prob = orc.make_problem(B, N, dof, seed=23)
+    g = torch.Generator().manual_seed(9)
+    poses = prob['pose_gt'].unsqueeze(0).repeat(S, 1, 1)
+    poses[..., :3] += 0.2 * torch.randn(S, B, 3, generator=g)
+    q = poses[..., 3:] + 0.1 * torch.randn(S, B, 4, generator=g)
+    poses[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+    w = torch.softmax(12.0 * torch.randn(S, B, generator=g), dim=0)          # log-weights spread over ~+-30 nats
+    assert float((w < 1e-9 * w.max(0).values).float().mean()) > 0.3          # a third of the samples are negligible
+    g_init = torch.randn(B, generator=g)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    outs = {}
+    for eps in ('0', None, '1e-3'):
+        if eps is None:
+            monkeypatch.delenv('EPROPNP_BWD_DROP', raising=False)
+        else:
+            monkeypatch.setenv('EPROPNP_BWD_DROP', eps)
+        outs[eps] = [t.cpu() for t in F.amis_backward(hp, poses.to(backend), (-w).to(backend), p['pose_init'], g_init.to(backend))]
+    for a, e in zip(outs[None], outs['0']):
+        assert _rel(a, e) <= 1e-6
+    coarse = max(_rel(a, e) for a, e in zip(outs['1e-3'], outs['0']))
+    assert 0 < coarse <= 3e-3, coarse
+    # exact mode against autograd of the oracle
+    x3d, x2d, w2d, delta = (prob[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta'))
+    ocam = orc.Cam(prob['cam_mats'], 0.1)
+    c_s = orc.evaluate(x3d, x2d, w2d, poses, ocam, delta, want_cost=True)[1]
+    c_i = orc.evaluate(x3d, x2d, w2d, prob['pose_init'], ocam, delta, want_cost=True)[1]
+    ((c_s * w).sum() + (c_i * g_init).sum()).backward()
+    for mine, ref in zip(outs['0'], (x3d.grad, x2d.grad, w2d.grad, delta.grad)):
+        assert _rel(mine, ref) <= 2e-4

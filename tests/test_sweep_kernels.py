@@ -76,3 +76,32 @@ def test_shift_poses_is_differentiable_in_the_pose(backend, dof):
     (ref * up.double()).sum().backward()
     torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('dof,bounds,B,N', [(6, None, 11, 300), (4, 'tight', 7, 64), (6, 'tight', 9, 512)])
+def test_normal_equations_launch_shapes_agree(backend, monkeypatch, dof, bounds, B, N):
+    """normal_equations_kernel launch shapes (one wave per object = what bench.py's single-sweep roofline runs at C2,
+    two waves, eight waves with the DPP reduction) against the oracle's J^T J / J^T r / cost."""
+    import epropnp_oracle as orc
+    from epropnp import functional as F
+    prob = orc.make_problem(B, N, dof, seed=B + N, bounds=bounds)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    res, cost, jac = orc.evaluate(*(prob[k].double() for k in ('x3d', 'x2d', 'w2d', 'pose_init')),
+                                  orc.Cam(prob['cam_mats'].double(), 0.1, *(None if prob.get(k) is None else prob[k].double() for k in ('lb', 'ub'))),
+                                  prob['delta'].double(), True, True)
+    jtj = jac.transpose(-1, -2) @ jac
+    jtr = (jac.transpose(-1, -2) @ res.unsqueeze(-1)).squeeze(-1)
+    ppl = 1
+    while 64 * ppl < N:
+        ppl *= 2
+    for shape in (None, f'2,{max(ppl // 2, 1)}', f'8,{max(ppl // 8, 1)}'):
+        if shape is None:
+            monkeypatch.delenv('EPROPNP_NE_SHAPE', raising=False)
+        else:
+            monkeypatch.setenv('EPROPNP_NE_SHAPE', shape)
+        a, b, c = (t.cpu().double() for t in F.normal_equations(hp, p['pose_init']))
+        scale = jtj.abs().amax(dim=(-1, -2), keepdim=True)
+        assert ((a - jtj).abs() / scale).max() < 2e-5, shape
+        assert ((b - jtr).abs() / jtr.abs().amax(-1, keepdim=True).clamp(min=1e-3)).max() < 1e-4, shape
+        torch.testing.assert_close(c, cost, rtol=1e-5, atol=1e-6)

@@ -27,17 +27,23 @@ def worker(B, N, S, K, L, reps=8):
     cf.set_param(prob['x2d'], prob['w2d'])
     hp = F.PnPProblem(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf, 6)
 
-    def timeit(fn):
-        fn()
+    def timeit(fn, inner=10):
+        """median over `reps` windows of `inner` back-to-back launches (a single launch from an idle queue reads ~5 us high)"""
+        for _ in range(3):
+            out = fn()
         torch.cuda.synchronize()
         ts = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); out = fn(); e1.record()
+            e0.record()
+            for _ in range(inner):
+                out = fn()
+            e1.record()
             torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
+            ts.append(e0.elapsed_time(e1) / inner)
         ts.sort()
         return ts[len(ts) // 2], out
+    t_ne, _ = timeit(lambda: F.normal_equations(hp, prob['pose_init']))
     t_lm, (pose_opt, cov, _) = timeit(lambda: F.lm_solve(hp, prob['pose_init'], L, with_pose_cov=True, with_cost=True))
     t_fw, (smp, logw) = timeit(lambda: F.amis_forward(hp, pose_opt, cov, S, K, seed=1))
     phases = None
@@ -60,7 +66,7 @@ def worker(B, N, S, K, L, reps=8):
     t_bw, grads = timeit(lambda: F.amis_backward(hp, smp, g, prob['pose_init'], gi))
     gsum = sum(float(t.double().abs().sum()) for t in grads)
     lse = torch.logsumexp(logw, 0).mean().item()
-    print(json.dumps(dict(lm_ms=round(t_lm, 4), fwd_ms=round(t_fw, 4), bwd_ms=round(t_bw, 4), lse=round(lse, 4), gsum=round(gsum, 6), fwd_phases=phases)))
+    print(json.dumps(dict(ne_ms=round(t_ne, 4), lm_ms=round(t_lm, 4), fwd_ms=round(t_fw, 4), bwd_ms=round(t_bw, 4), lse=round(lse, 4), gsum=round(gsum, 6), fwd_phases=phases)))
 
 
 VARIANTS = [
