@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['eval_kernels.hip', 'lm_kernel.hip', 'amis_kernels.hip', 'amis_forward_mfma.hip', 'amis_backward_mfma.hip', 'gn_step_kernel.hip', 'rslm_kernel.hip', 'c_api.hip']
+SOURCES = ['eval_kernels.hip', 'lm_kernel.hip', 'amis_kernels.hip', 'amis_forward_mfma.hip', 'amis_backward_mfma.hip', 'gn_step_kernel.hip', 'rslm_kernel.hip', 'mc_forward.hip', 'c_api.hip']
 # per-source flags (HIP build only).  Where the SLP vectoriser packs independent scalar FMAs into v_pk_* it pays for it in
 # v_mov shuffles and gains nothing (packed fp32 runs at the scalar flop rate): lm 79 -> 70 us at C2, rslm 117 -> 107 us at
 # C4, forward 0.84 -> 0.82 ms (its Huber sweep is packed explicitly, on 2-vectors).  The backward keeps the default.

@@ -14,6 +14,8 @@ constexpr int kPropStride = 40;   // floats per fitted proposal (layout below)
 // proposal record:  [0..2] t-mode | [3..8] L_t (lower, row-major packed) | [9..14] L_t^-1 | [15] Student-t log-norm
 //   6-DoF: [16..25] L_r (lower 4x4 packed) | [26..35] L_r^-1 | [36] sum log diag L_r
 //   4-DoF: [16] yaw mode | [17] kappa | [18] log I0(kappa)
+//   [37] 1 if the translation covariance fell back to its default factor, [38] 1 if the ACG shape matrix did
+//   (cholesky_wrapper, epropnp.py:16-33) -- reported through the status word as EPROPNP_ST_CHOL_FALLBACK
 #ifndef PNP_VM_TRIES
 #define PNP_VM_TRIES 16      // tuning builds may lower it to time the rejection loop; the noise layout assumes 16
 #endif
@@ -47,6 +49,7 @@ __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) 
 PNP_FIT_FN void fit_translation(double (&C)[3][3], const float* fallback_diag, float* rec) {
   double invd[3];
   const bool ok = cholesky<3, double>(C, invd);
+  rec[37] = ok ? 0.f : 1.f;
   if (!ok) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -86,6 +89,7 @@ PNP_FIT_FN void fit_rotation_acg(double (&Rc)[4][4], float dispersion, float* re
 #pragma unroll
   for (int i = 0; i < 4; ++i) Rc[i][i] += add;
   ok = cholesky<4, double>(Rc, invd) && ok;
+  rec[38] = ok ? 0.f : 1.f;
   if (!ok) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -113,6 +117,7 @@ PNP_FIT_FN void fit_rotation_acg(double (&Rc)[4][4], float dispersion, float* re
 template <int DOF>
 PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, float dispersion, float* rec) {
   rec[0] = pose_opt[0]; rec[1] = pose_opt[1]; rec[2] = pose_opt[2];
+  rec[37] = rec[38] = rec[39] = 0.f;
   double Ct[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -659,6 +664,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
           Ct[j][i] = (double)c6[tri(i, j)];
         }
       const float dflt[3] = {1.f, 1.f, 1.f};
+      nrec[38] = nrec[39] = 0.f;
       fit_translation(Ct, dflt, nrec);
       double Sg[4][4];
       const double inorm = (a.mle_iter > 0) ? 1.0 / (double)acc[10] : 0.0;
@@ -712,6 +718,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
           Ct[j][i] = (double)c8[tri(i, j)];
         }
       const float dflt[3] = {1.f, 1.f, 4.f};
+      nrec[38] = nrec[39] = 0.f;
       fit_translation(Ct, dflt, nrec);
       nrec[16] = atan2f(c8[6], c8[7]);
       const float r_sq = c8[6] * c8[6] + c8[7] * c8[7];

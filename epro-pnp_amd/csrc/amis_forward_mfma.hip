@@ -280,7 +280,17 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
     PNP_PHASE(4);
   }
 
-  for (int m = tid; m < S; m += T) logweights[(size_t)m * p.B + b] = lgw[m];
+  {   // numerical events for the caller's status word (include/epropnp_hip.h); no-op without one
+    int st_bits = 0;
+    for (int m = tid; m < S; m += T) {
+      const float lw = lgw[m];
+      logweights[(size_t)m * p.B + b] = lw;
+      st_bits |= (lw == lw && lw != INFINITY) ? 0 : EPROPNP_ST_NONFINITE_WEIGHT;     // -inf = zero weight is legitimate
+    }
+    for (int i = tid; i < K; i += T)
+      st_bits |= (prop[i * kPropStride + 37] != 0.f || prop[i * kPropStride + 38] != 0.f) ? EPROPNP_ST_CHOL_FALLBACK : 0;
+    raise_status(p, st_bits, b);
+  }
   if (proposals != nullptr)
     for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
   PNP_PHASE(5);

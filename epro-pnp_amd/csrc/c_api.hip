@@ -20,6 +20,16 @@ const char* epropnp_last_error(void) { return pnp::last_error_buffer(); }
 
 int epropnp_noise_stride(int dof) { return dof == 6 ? 8 : (dof == 4 ? 4 + 3 * 16 : -1); }
 
+int epropnp_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_params* par, const float* pose_init,
+                                const float* noise, float* x3d_centered, float* offset, float* pose_init_n,
+                                float* start_pose, float* start_cost, float* pose_opt_n, float* pose_cov, float* cost,
+                                float* pose_samples_n, float* logweights, float* cost_init, float* pose_opt,
+                                float* pose_samples, void* stream) {
+  return pnp::launch_monte_carlo_forward(prob, par, pose_init, noise, x3d_centered, offset, pose_init_n, start_pose,
+                                         start_cost, pose_opt_n, pose_cov, cost, pose_samples_n, logweights, cost_init,
+                                         pose_opt, pose_samples, (hipStream_t)stream);
+}
+
 int epropnp_evaluate_cost(const epropnp_problem* prob, const float* poses, int32_t num_poses, float* cost, void* stream) {
   return pnp::launch_evaluate_cost(prob, poses, num_poses, cost, (hipStream_t)stream);
 }

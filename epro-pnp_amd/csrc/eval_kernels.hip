@@ -61,8 +61,9 @@ __global__ __launch_bounds__(MAXW * 64) void normal_equations_kernel(Problem p, 
     for (int i = 0; i < 9; ++i) { K[i] = to_vgpr(K[i]); R[i] = to_vgpr(R[i]); }
     float t[3] = {to_vgpr(ps[0]), to_vgpr(ps[1]), to_vgpr(ps[2])};
     const float zm = to_vgpr(p.z_min), dl = to_vgpr(delta);
+    const float ie = to_vgpr(p.inv_huber_eps);
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, zm, dl, bd, clip != 0, acc);
+    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, zm, dl, ie, bd, clip != 0, acc);
   } else {
     load_camera<BOUNDS>(p, b, K, bd, delta);
 #pragma unroll
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(MAXW * 64) void normal_equations_kernel(Problem p, 
     pose_to_rot<DOF>(ps, R);
     for (int n = (int)threadIdx.x; n < p.N; n += (int)blockDim.x) {
       const Point q = load_point(p, b, n);
-      point_normal_eq<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, bd, clip != 0, acc);
+      point_normal_eq<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, p.inv_huber_eps, bd, clip != 0, acc);
     }
   }
   if (MAXW <= 4) block_sum_t<NV>(acc, scratch); else block_sum<NV>(acc, scratch);

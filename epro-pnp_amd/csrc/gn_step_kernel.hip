@@ -22,13 +22,13 @@ struct PointFwd {
   float xr0, xr1, xr2, hx, hy, hz, rz, ppx, ppy, px, py;
   float d0[3], d1[3];        // d x2d / d x3d_cam rows
   float Jc0[DOF], Jc1[DOF];  // camera Jacobian rows (before clip / rescaling)
-  float dx, dy, rx, ry, rho, gam, s0, s1, e0, e1;
-  bool k0, k1, outlier;
+  float dx, dy, rx, ry, rho, rc, gam, s0, s1, e0, e1;
+  bool k0, k1, outlier, rho_live;
 };
 
 template <int DOF, bool BOUNDS>
 PNP_FN void point_forward(const Point& p, const float (&K)[9], const float (&R)[9], const float* t, float z_min, float delta,
-                          const Bounds& bd, PointFwd<DOF>& f) {
+                          float huber_eps, const Bounds& bd, PointFwd<DOF>& f) {
   f.xr0 = R[0] * p.X + R[1] * p.Y + R[2] * p.Z;
   f.xr1 = R[3] * p.X + R[4] * p.Y + R[5] * p.Z;
   f.xr2 = R[6] * p.X + R[7] * p.Y + R[8] * p.Z;
@@ -70,8 +70,10 @@ PNP_FN void point_forward(const Point& p, const float (&K)[9], const float (&R)[
   f.rx = f.dx * p.wu;
   f.ry = f.dy * p.wv;
   f.rho = sqrtf(f.rx * f.rx + f.ry * f.ry);
-  f.outlier = f.rho > delta;                                  // min(delta / max(rho, eps), 1) < 1
-  f.gam = f.outlier ? sqrtf(delta / f.rho) : 1.0f;
+  f.rc = fmaxf(f.rho, huber_eps);                             // cost_fun.py:18-22: max(rho, eps)
+  f.rho_live = f.rho >= huber_eps;                            // the clamp passes the gradient only where it is inactive
+  f.outlier = f.rc > delta;                                   // min(delta / max(rho, eps), 1) < 1
+  f.gam = f.outlier ? sqrtf(delta / f.rc) : 1.0f;
   const bool zc = (z == z_min);
   f.k0 = zc;
   f.k1 = zc;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_forward_kernel(Problem 
   for (int n0 = 0; n0 < p.N; n0 += (int)blockDim.x) {
     const Point q = load_point(p, b, n0 + (int)threadIdx.x);
     PointFwd<DOF> f;
-    point_forward<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, bd, f);
+    point_forward<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, p.huber_eps, bd, f);
     accumulate_normal_eq<DOF>(f, acc);
   }
   block_sum_t<NV>(acc, scratch);
@@ -158,12 +160,17 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_forward_kernel(Problem 
   unpack_sym<DOF>(acc, eps, H);
 #pragma unroll
   for (int i = 0; i < DOF; ++i) g[i] = acc[NH + i];
-  scaled_cholesky<DOF>(H, fac);
+  const bool spd = scaled_cholesky<DOF>(H, fac);
   scaled_solve<DOF>(fac, g);
   if (threadIdx.x == 0) {
     float st[DOF];
+    int st_bits = spd ? 0 : EPROPNP_ST_LM_NOT_SPD;
 #pragma unroll
-    for (int i = 0; i < DOF; ++i) st[i] = -g[i];
+    for (int i = 0; i < DOF; ++i) {
+      st[i] = -g[i];
+      st_bits |= isfinite(st[i]) ? 0 : EPROPNP_ST_NONFINITE_POSE;
+    }
+    raise_status(p, st_bits, b);
     if (step_out != nullptr) {
 #pragma unroll
       for (int i = 0; i < DOF; ++i) step_out[(size_t)b * DOF + i] = st[i];
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_backward_kernel(Problem
   for (int n0 = 0; n0 < p.N; n0 += T) {
     const Point q = load_point(p, b, n0 + tid);
     PointFwd<DOF> f;
-    point_forward<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, bd, f);
+    point_forward<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, p.huber_eps, bd, f);
     accumulate_normal_eq<DOF>(f, acc);
   }
   block_sum_t<NV>(acc, scratch);
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_backward_kernel(Problem
   for (int n0 = 0; n0 < p.N; n0 += T) {
     const Point q = load_point(p, b, n0 + tid);
     PointFwd<DOF> f;
-    point_forward<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, bd, f);
+    point_forward<DOF, BOUNDS>(q, K, R, ps, p.z_min, delta, p.huber_eps, bd, f);
     // row-level gradients
     float a0 = 0.f, c0 = 0.f, a1 = 0.f, c1 = 0.f;
 #pragma unroll
@@ -263,10 +270,12 @@ __global__ __launch_bounds__(kGnMaxThreads) void gn_step_backward_kernel(Problem
     float Gwu = f.gam * Gs0, Gwv = f.gam * Gs1;
     float Grx = f.gam * Ge0, Gry = f.gam * Ge1;
     if (f.outlier) {
-      const float Grho = -0.5f * f.gam / f.rho * Ggam;
       gd = fmaf(0.5f * f.gam / delta, Ggam, gd);
-      Grx = fmaf(Grho, f.rx / f.rho, Grx);
-      Gry = fmaf(Grho, f.ry / f.rho, Gry);
+      if (f.rho_live) {
+        const float Grho = -0.5f * f.gam / f.rho * Ggam;
+        Grx = fmaf(Grho, f.rx / f.rho, Grx);
+        Gry = fmaf(Grho, f.ry / f.rho, Gry);
+      }
     }
     float Gpx = Grx * q.wu, Gpy = Gry * q.wv;
     Gwu = fmaf(Grx, f.dx, Gwu);

@@ -3,6 +3,7 @@
 // acc = [upper-tri J^T J | J^T r | cost] reduced over the object's points (every lane of the owning group gets it).
 // Reference: epropnp/levenberg_marquardt.py:132-241 (solve, _lm_iter), :255-265 (pose_add).
 #pragma once
+#include "../../include/epropnp_hip.h"
 #include "pnp_sweep.h"
 
 namespace pnp {
@@ -30,7 +31,7 @@ PNP_FN void unpack_h(const float (&acc)[NormalEq<DOF>::NV], float (&H)[DOF][DOF]
 // (GN fast mode) point, bit i of `accepted_bits` says whether LM step i was accepted.
 template <int DOF, class Sweep>
 PNP_FN void lm_iterate(const LmParams& lm, Sweep&& sweep, float (&pose)[PoseLen<DOF>::value],
-                       float (&cur)[NormalEq<DOF>::NV], int& accepted_bits) {
+                       float (&cur)[NormalEq<DOF>::NV], int& accepted_bits, int& status_bits) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
   accepted_bits = 0;
@@ -47,7 +48,7 @@ PNP_FN void lm_iterate(const LmParams& lm, Sweep&& sweep, float (&pose)[PoseLen<
         H[i][i] += lm.eps;
         g[i] = cur[NH + i];
       }
-      scaled_cholesky<DOF>(H, f);
+      if (!scaled_cholesky<DOF>(H, f)) status_bits |= EPROPNP_ST_LM_NOT_SPD;   // the reference's LU raises on a zero pivot
       scaled_solve<DOF>(f, g);
       float step[DOF], nxt[PL];
 #pragma unroll
@@ -75,7 +76,7 @@ PNP_FN void lm_iterate(const LmParams& lm, Sweep&& sweep, float (&pose)[PoseLen<
         g[i] = cur[NH + i];
         st[i] = g[i];
       }
-      scaled_cholesky<DOF>(Hlm, f);
+      if (!scaled_cholesky<DOF>(Hlm, f)) status_bits |= EPROPNP_ST_LM_NOT_SPD;
       scaled_solve<DOF>(f, st);   // st = Hlm^-1 g ; step = -st
       float step[DOF], pose_new[PL];
 #pragma unroll

@@ -14,6 +14,8 @@ namespace pnp {
 
 // MAXW == 0 selects the small-problem variant: N <= 16 points, one object per 16-lane DPP row (4 objects per wave,
 // reductions are row_ror adds only) -- the shape of the RSLM initialiser's 10^4..10^5 sub-problems.
+// PPL == 0 selects the streaming variant for N beyond the register-resident limit (8192): every sweep re-reads the
+// object's points from HBM / L2 (the reference accepts any N).
 template <int DOF, int PPL, bool BOUNDS, int MAXW>
 __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(Problem p, LmParams lm, const float* __restrict__ pose_init,
                                                                float* __restrict__ pose_opt, float* __restrict__ pose_cov,
@@ -36,8 +38,8 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
 #pragma unroll
   for (int i = 0; i < 9; ++i) K[i] = to_vgpr(K[i]);
   delta = to_vgpr(delta);
-  const float z_min = to_vgpr(p.z_min);
-  Point pts[PPL];
+  const float z_min = to_vgpr(p.z_min), inv_eps = to_vgpr(p.inv_huber_eps);
+  Point pts[PPL > 0 ? PPL : 1];
 #pragma unroll
   for (int k = 0; k < PPL; ++k)
     pts[k] = load_point(p, b, kRow ? (int)(threadIdx.x & 15u) : (int)threadIdx.x + k * (int)blockDim.x);
@@ -57,7 +59,11 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, z_min, delta, bd, clip, acc);
+    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, z_min, delta, inv_eps, bd, clip, acc);
+    if (PPL == 0) {
+      for (int n = (int)threadIdx.x; n < p.N; n += (int)blockDim.x)
+        point_normal_eq<DOF, BOUNDS>(load_point(p, b, n), K, R, t, z_min, delta, inv_eps, bd, clip, acc);
+    }
     if (kRow) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) acc[i] = row_sum16(acc[i]);
@@ -69,8 +75,11 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
   };
 
   float cur[NV];
-  int accepted_bits = 0;
-  lm_iterate<DOF>(lm, sweep, pose, cur, accepted_bits);
+  int accepted_bits = 0, st_bits = 0;
+  lm_iterate<DOF>(lm, sweep, pose, cur, accepted_bits, st_bits);
+#pragma unroll
+  for (int i = 0; i < PL; ++i) st_bits |= isfinite(pose[i]) ? 0 : EPROPNP_ST_NONFINITE_POSE;
+  if (writer) raise_status(p, st_bits, b);
 
   if (writer) {
 #pragma unroll
@@ -102,9 +111,6 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
   if (prob->num_obj == 0) return EPROPNP_OK;
   if (!pose_init || !pose_opt) return fail(EPROPNP_EINVAL, "lm_solve: NULL pose pointer");
   if (lm->num_iter < 0 || lm->num_iter > 31 * 1000) return fail(EPROPNP_EINVAL, "lm_solve: bad num_iter");
-  if (prob->num_pts > kMaxResidentPoints)
-    return fail(EPROPNP_EINVAL, "lm_solve: num_pts %d exceeds the register-resident limit %d", prob->num_pts,
-                kMaxResidentPoints);
   const Problem d = to_device_problem(prob);
   LmParams k;
   k.num_iter = lm->num_iter; k.fast_mode = lm->fast_mode;
@@ -119,6 +125,16 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
       return 0;
     });
     return check_launch("lm_solve_kernel (row variant)");
+  }
+  if (d.N > kMaxResidentPoints) {   // streaming: 8 waves per object, points re-read on every sweep
+    const dim3 grid(padded_object_grid(d.B)), block(512);
+    dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+      PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 0, decltype(BND)::value, 8>), grid, block,
+                 sizeof(float) * NormalEq<decltype(DOF)::value>::NV * 16, st, d, k, pose_init, pose_opt, pose_cov, cost,
+                 accept_mask);
+      return 0;
+    });
+    return check_launch("lm_solve_kernel (streaming)");
   }
   // fewest waves per object at every batch size: more waves only add cross-wave reduction + barrier latency to each of
   // the 1+L dependent sweeps (measured on MI355X at B = 32 / 256 / 600: 1 wave 38 / 30 / 30 us vs 86 / 62 / 41 us)

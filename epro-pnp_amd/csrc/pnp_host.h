@@ -41,6 +41,9 @@ inline Problem to_device_problem(const epropnp_problem* p) {
   d.x3d = p->x3d; d.x2d = p->x2d; d.w2d = p->w2d; d.cam = p->cam_mats;
   d.lb = p->lb; d.ub = p->ub; d.delta = p->delta;
   d.z_min = p->z_min; d.B = p->num_obj; d.N = p->num_pts;
+  d.huber_eps = (p->huber_eps > 0.f) ? p->huber_eps : 1e-10f;
+  d.inv_huber_eps = 1.0f / d.huber_eps;
+  d.status = p->status;
   return d;
 }
 
@@ -93,6 +96,11 @@ inline float backward_drop_eps() {
 }
 
 // launchers (one per .hip translation unit)
+int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_params* par, const float* pose_init,
+                               const float* noise, float* x3d_centered, float* offset, float* pose_init_n,
+                               float* start_pose, float* start_cost, float* pose_opt_n, float* pose_cov, float* cost,
+                               float* pose_samples_n, float* logweights, float* cost_init, float* pose_opt,
+                               float* pose_samples, hipStream_t st);
 int launch_evaluate_cost(const epropnp_problem* prob, const float* poses, int num_poses, float* cost, hipStream_t st);
 int launch_normal_equations(const epropnp_problem* prob, const float* pose, int clip_jac, float* jtj, float* jtr,
                             float* cost, hipStream_t st);

@@ -17,7 +17,17 @@ struct Problem {
   const float* __restrict__ delta;
   float z_min;
   int B, N;
+  float huber_eps, inv_huber_eps;   // HuberPnPCost.eps (default 1e-10) and its reciprocal
+  int* status;                      // optional int32[2]: [0] |= flags, [1] = min(object index); see epropnp_hip.h
 };
+
+// record a numerical event for the caller (no-op without a status buffer); rare by construction, so plain atomics
+__device__ __forceinline__ void raise_status(const Problem& p, int flags, int b) {
+  if (p.status != nullptr && flags != 0) {
+    atomicOr(p.status, flags);
+    atomicMin(p.status + 1, b);
+  }
+}
 
 // XCD-aware object index: the dispatcher is observed to place workgroup g on XCD g % 8, so give each XCD
 // a contiguous range of objects -- neighbouring objects then share an L2 and their partial-line output
@@ -72,7 +82,7 @@ struct NormalEq {
 // reference's eight divisions by z; gamma = sqrt(min(delta / rho, 1)) reuses 1/rho from the norm.
 template <int DOF, bool BOUNDS>
 PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R)[9], const float* t, float z_min,
-                            float delta, const Bounds& bd, bool clip, float (&acc)[NormalEq<DOF>::NV]) {
+                            float delta, float inv_eps, const Bounds& bd, bool clip, float (&acc)[NormalEq<DOF>::NV]) {
   const float xr0 = R[0] * p.X + R[1] * p.Y + R[2] * p.Z;
   const float xr1 = R[3] * p.X + R[4] * p.Y + R[5] * p.Z;
   const float xr2 = R[6] * p.X + R[7] * p.Y + R[8] * p.Z;
@@ -109,7 +119,7 @@ PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R
   const float ir = fast_rsqrt(fmaxf(s2, 1e-36f));             // ~ 1 / rho
   float rho = s2 * ir;
   rho = fmaf(0.5f * ir, fmaf(-rho, rho, s2), rho);            // Newton step on sqrt
-  const float q = fminf(delta * ir, 1.0f);                    // min(delta / max(rho, eps), 1); eps = 1e-10 never binds first
+  const float q = fminf(delta * fminf(ir, inv_eps), 1.0f);    // min(delta / max(rho, eps), 1)
   const float iq = fast_rsqrt(fmaxf(q, 1e-36f));
   float gam = q * iq;
   gam = fmaf(0.5f * iq, fmaf(-gam, gam, q), gam);

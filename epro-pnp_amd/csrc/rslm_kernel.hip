@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
   float Kv[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) Kv[i] = to_vgpr(K[i]);
-  const float delta_v = to_vgpr(delta), zmin_v = to_vgpr(p.z_min);
+  const float delta_v = to_vgpr(delta), zmin_v = to_vgpr(p.z_min), inv_eps_v = to_vgpr(p.inv_huber_eps);
 
   float best_cost = INFINITY, best_pose[PL];
 #pragma unroll
@@ -234,13 +234,14 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
       for (int i = 0; i < 3; ++i) t[i] = ps[i];
 #pragma unroll
       for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-      point_normal_eq<DOF, BOUNDS>(pt, Kv, R, t, zmin_v, delta_v, bd, clip, acc);
+      point_normal_eq<DOF, BOUNDS>(pt, Kv, R, t, zmin_v, delta_v, inv_eps_v, bd, clip, acc);
 #pragma unroll
       for (int i = 0; i < NV; ++i) acc[i] = row_sum16(acc[i]);
     };
     float cur[NV];
     int bits = 0;
-    lm_iterate<DOF>(lm, sweep, pose, cur, bits);
+    int st_bits = 0;      // sub-sample solves may be degenerate by design (16 random points): not reported
+    lm_iterate<DOF>(lm, sweep, pose, cur, bits, st_bits);
     PNP_RSLM_PHASE(3);
 
     // ---- score the proposal on the full correspondence set (:343); hardware rcp / sqrt as in the AMIS sweeps: the

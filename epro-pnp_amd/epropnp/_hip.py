@@ -19,7 +19,8 @@ _i32p = C.POINTER(C.c_int32)
 class Problem(C.Structure):
     _fields_ = [('x3d', C.c_void_p), ('x2d', C.c_void_p), ('w2d', C.c_void_p), ('cam_mats', C.c_void_p),
                 ('lb', C.c_void_p), ('ub', C.c_void_p), ('delta', C.c_void_p), ('z_min', C.c_float),
-                ('num_obj', C.c_int32), ('num_pts', C.c_int32), ('dof', C.c_int32)]
+                ('num_obj', C.c_int32), ('num_pts', C.c_int32), ('dof', C.c_int32),
+                ('huber_eps', C.c_float), ('status', C.c_void_p)]
 
 
 class LmParams(C.Structure):
@@ -35,7 +36,14 @@ class AmisParams(C.Structure):
                 ('offset', C.c_uint64), ('offset_dev', C.c_void_p)]
 
 
-ABI_VERSION = 2
+class McParams(C.Structure):
+    _fields_ = [('lm', LmParams), ('amis', AmisParams), ('normalize', C.c_int32), ('init_mode', C.c_int32),
+                ('rslm_lm', LmParams), ('rslm_points', C.c_int32), ('rslm_proposals', C.c_int32),
+                ('rslm_seed', C.c_uint64), ('rslm_offset', C.c_uint64), ('rslm_offset_dev', C.c_void_p),
+                ('rslm_inds', C.c_void_p), ('rslm_rot', C.c_void_p)]
+
+
+ABI_VERSION = 3
 _lib = None
 
 
@@ -44,6 +52,7 @@ def _declare(lib):
     lib.epropnp_abi_version.restype = C.c_int
     lib.epropnp_last_error.restype = C.c_char_p
     lib.epropnp_noise_stride.argtypes = [C.c_int]
+    lib.epropnp_monte_carlo_forward.argtypes = [C.POINTER(Problem), C.POINTER(McParams)] + [vp] * 16
     lib.epropnp_evaluate_cost.argtypes = [C.POINTER(Problem), vp, i32, vp, vp]
     lib.epropnp_normal_equations.argtypes = [C.POINTER(Problem), vp, i32, vp, vp, vp, vp]
     lib.epropnp_lm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), vp, vp, vp, vp, vp, vp]
@@ -69,7 +78,7 @@ def _declare(lib):
     lib.epropnp_mc_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     for name in ('evaluate_cost', 'normal_equations', 'lm_solve', 'amis_forward', 'amis_backward', 'adaptive_delta',
                  'mc_loss_forward', 'mc_loss_backward', 'rslm_draw', 'gn_step_forward', 'gn_step_backward', 'rslm_solve', 'center_points', 'shift_poses', 'prepare_forward', 'prepare_backward', 'pose_opt_plus_forward', 'pose_opt_plus_backward', 'shift_poses_backward', 'prepare_dense_forward',
-                 'prepare_dense_backward', 'amis_backward_split'):
+                 'prepare_dense_backward', 'amis_backward_split', 'monte_carlo_forward'):
         getattr(lib, 'epropnp_' + name).restype = C.c_int
     return lib
 
@@ -80,7 +89,8 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_gn_step_forward', 'epropnp_gn_step_backward', 'epropnp_rslm_solve',
            'epropnp_center_points', 'epropnp_shift_poses', 'epropnp_prepare_forward', 'epropnp_prepare_backward',
            'epropnp_pose_opt_plus_forward', 'epropnp_pose_opt_plus_backward', 'epropnp_shift_poses_backward',
-           'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split')
+           'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split',
+           'epropnp_monte_carlo_forward')
 
 
 def lib():

@@ -112,9 +112,11 @@ class EProPnPBase(torch.nn.Module):
         Returns: pose_opt (B,4|7), cost (B,)|None, pose_opt_plus (B,4|7)|None, pose_samples (S,B,4|7),
                  pose_sample_logweights (S,B) [differentiable], cost_init (B,)|None [differentiable].
         """
+        assert x3d.dim() == x2d.dim() == w2d.dim() == 3
+        if self._fusable(x3d, x2d, w2d, pose_init, force_init_solve, kwargs):
+            return self._fused_forward(x3d, x2d, w2d, camera, cost_fun, pose_init, force_init_solve, noise, **kwargs)
         if self.normalize:
             transform, x3d, pose_init = pnp_normalize(x3d, pose_init, detach_transformation=True)
-        assert x3d.dim() == x2d.dim() == w2d.dim() == 3
         num_obj = x3d.size(0)
 
         prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof) if num_obj > 0 else None
@@ -147,6 +149,81 @@ class EProPnPBase(torch.nn.Module):
             if pose_opt_plus is not None:
                 pose_opt_plus = pnp_denormalize(transform, pose_opt_plus)
         return pose_opt, cost, pose_opt_plus, pose_samples, pose_sample_logweights, cost_init
+
+
+    # ---- one host call for the whole forward (csrc/mc_forward.hip) -------------------------------------------------
+    def _fusable(self, x3d, x2d, w2d, pose_init, force_init_solve, kwargs):
+        """The fused entry serves the reference's own solver stack: LMSolver with no or an RSLMSolver initialiser whose
+        sub-problems fit the one-launch kernel.  Anything else (a custom solver object, > 16 points per proposal, > 512
+        points with RSLM) takes the composite path below, made of the same kernels."""
+        import os
+        from . import _hip
+        from .levenberg_marquardt import LMSolver, RSLMSolver
+        sv = self.solver
+        if type(sv) is not LMSolver or sv.dof != self.dof or x3d.size(0) == 0 or os.environ.get('EPROPNP_NO_FUSED_FORWARD'):
+            return False
+        if set(kwargs) - {'with_pose_opt_plus', 'with_cost', 'fast_mode'}:
+            return False
+        ts = [x3d, x2d, w2d] + ([pose_init] if pose_init is not None else [])
+        if not _hip.on_hip_path(*ts) or (pose_init is not None and pose_init.requires_grad and torch.is_grad_enabled()):
+            return False
+        if pose_init is None or force_init_solve:
+            init = sv.init_solver
+            if type(init) is not RSLMSolver or init.dof != self.dof or init.num_points > 16 \
+                    or not (2 <= x2d.size(1) <= hip.RSLM_MAX_POINTS) or os.environ.get('EPROPNP_RSLM_COMPOSITE'):
+                return False
+        return True
+
+    def _fused_forward(self, x3d, x2d, w2d, camera, cost_fun, pose_init, force_init_solve, noise, with_pose_opt_plus=False,
+                       with_cost=False, fast_mode=False):
+        from . import _hip
+        from .levenberg_marquardt import RSLMSolver
+        sv = self.solver
+        prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
+        cfg = self._amis_config(noise)
+        par = _hip.McParams()
+        par.lm = hip._lm_struct(sv, fast_mode)
+        par.amis = _hip.AmisParams(cfg['mc_samples'], cfg['num_iter'], cfg['eps'], int(cfg['acg_mle_iter']),
+                                   cfg['acg_dispersion'], int(cfg['seed']), int(cfg['offset']),
+                                   _hip.ptr(cfg.get('offset_dev')))
+        par.normalize = int(bool(self.normalize))
+        par.init_mode = 1 if pose_init is None else (2 if force_init_solve else 0)
+        keep = None
+        if par.init_mode:
+            init = sv.init_solver
+            par.rslm_lm = hip._lm_struct(init, fast_mode)
+            par.rslm_points, par.rslm_proposals = int(init.num_points), int(init.num_proposals)
+            if getattr(init.draw, '__func__', None) is RSLMSolver.draw:          # default sampler: device Philox
+                inds = rot = None
+            else:                                                               # overridden draw(): inject its output
+                inds, rot = init.draw(w2d)
+                inds, rot = inds.contiguous(), hip._f32c(rot, 'rot')
+                assert inds.dtype == torch.int64 and inds.shape == (par.rslm_proposals, prob.B, par.rslm_points)
+            if not hasattr(init, '_draw_seed'):
+                init._draw_seed, init._draw_calls = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
+            counter = getattr(init, 'rng_counter', None)                        # device-side call counter (hipGraph replay)
+            if counter is None:
+                init._draw_calls += 1
+            par.rslm_seed = init._draw_seed
+            par.rslm_offset = 0 if counter is not None else init._draw_calls - 1
+            par.rslm_offset_dev, par.rslm_inds, par.rslm_rot = _hip.ptr(counter), _hip.ptr(inds), _hip.ptr(rot)
+            keep = (inds, rot, counter)
+        delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
+        pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
+            x3d, x2d, w2d, delta, prob, pose_init, par, noise, bool(with_cost))
+        del keep
+        if par.init_mode and inds is None and counter is not None:
+            counter.add_(1)
+        if self.rng_counter is not None and noise is None:
+            self.rng_counter.add_(1)              # in-stream: part of a captured graph
+        pose_opt_plus = None
+        if with_pose_opt_plus:      # differentiable Gauss-Newton step at pose_opt, in the solver frame, then denormalised
+            if self.normalize:      # d/dx3d passes through the (detached) centring unchanged: differentiate w.r.t. x3d itself
+                plus_n = hip.pose_opt_plus(x3d, x2d, w2d, delta, prob.with_points(x3d_c), pose_opt_n, sv.eps)
+                pose_opt_plus = hip.shift_poses(plus_n, offset, -1.0)
+            else:
+                pose_opt_plus = hip.pose_opt_plus(x3d, x2d, w2d, delta, prob, pose_opt_n, sv.eps)
+        return pose_opt, cost, pose_opt_plus, samples, logw, cost_init
 
 
 class EProPnP4DoF(EProPnPBase):

@@ -18,6 +18,68 @@ def _f32c(t, name):
     return t.detach().contiguous()
 
 
+# ---- device-side status word (include/epropnp_hip.h: epropnp_problem.status) -----------------------------------------
+ST_LM_NOT_SPD, ST_NONFINITE_POSE, ST_CHOL_FALLBACK, ST_NONFINITE_WEIGHT = 1, 2, 4, 8
+_status = threading.local()
+
+
+def status_buffer(device):
+    """The int32[2] status word kernels report numerical events into on `device`, or None when checking is off."""
+    bufs = getattr(_status, 'bufs', None)
+    if bufs is None:
+        return None
+    key = str(device)
+    if key not in bufs:
+        bufs[key] = torch.tensor([0, 2 ** 31 - 1], dtype=torch.int32, device=device)
+    return bufs[key]
+
+
+class numerics_check:
+    """Context manager: kernels launched inside record numerical events in a device-side status word (no host sync on
+    the way); leaving the block -- or calling .check() -- synchronises once and raises what the reference would have
+    raised where the event happened:
+
+        with hip.numerics_check():                 # or EProPnP*/LMSolver(...).check_numerics = True
+            pose_opt, *_ = solver(x3d, x2d, w2d, camera, cost_fun, pose_init=p0)
+
+    * a damped normal-equation system without a Cholesky factor (singular or NaN input) or a non-finite pose
+      -> RuntimeError, as `torch.linalg.solve` / `torch.inverse` raise in levenberg_marquardt.py:15-19,178-181;
+    * `strict=True` also reports what the reference tolerates silently: a proposal covariance replaced by its default
+      (cholesky_wrapper, epropnp.py:16-33) and non-finite AMIS log-weights."""
+
+    def __init__(self, strict=False):
+        self.strict = strict
+
+    def __enter__(self):
+        self.prev = getattr(_status, 'bufs', None)
+        _status.bufs = {}
+        return self
+
+    def check(self):
+        events = []
+        for key, buf in _status.bufs.items():
+            flags, first = buf.tolist()            # the one synchronisation
+            buf.copy_(torch.tensor([0, 2 ** 31 - 1], dtype=torch.int32))
+            if flags & ST_LM_NOT_SPD:
+                events.append(f'linalg.solve: the damped normal equations of object {first} on {key} are singular or not finite')
+            elif flags & ST_NONFINITE_POSE:
+                events.append(f'the solver produced a non-finite pose for object {first} on {key}')
+            if self.strict and flags & ST_CHOL_FALLBACK:
+                events.append(f'cholesky: a proposal covariance of object {first} on {key} was replaced by its default')
+            if self.strict and flags & ST_NONFINITE_WEIGHT:
+                events.append(f'non-finite AMIS log-weight for object {first} on {key}')
+        if events:
+            raise RuntimeError('; '.join(events))
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            if exc_type is None:
+                self.check()
+        finally:
+            _status.bufs = self.prev
+        return False
+
+
 class PnPProblem:
     """Contiguous fp32 device views of one batch of correspondences + camera + Huber threshold.
 
@@ -34,9 +96,7 @@ class PnPProblem:
         self.x3d, self.x2d, self.w2d = _f32c(x3d, 'x3d'), _f32c(x2d, 'x2d'), _f32c(w2d, 'w2d')
         dev = self.x2d.device
         self.device = dev
-        eps = getattr(cost_fun, 'eps', 1e-10)
-        if abs(eps - 1e-10) > 1e-16:
-            raise NotImplementedError('HuberPnPCost.eps other than 1e-10 is not supported by the HIP kernels')
+        self.huber_eps = float(getattr(cost_fun, 'eps', 1e-10))
         self.z_min = float(camera.z_min)
         # contiguous (B,3,3) intrinsics and (B,2) bounds: callers pass an expanded view of one matrix / plain floats, and
         # a step builds several PnPProblems from the same camera object -- materialise them once per camera state
@@ -63,8 +123,10 @@ class PnPProblem:
         if not isinstance(delta, torch.Tensor):
             delta = torch.full((B,), float(delta), dtype=torch.float32, device=dev)
         self.delta = _f32c(delta.to(dev).expand(B) if delta.dim() <= 1 else delta.reshape(B), 'delta')
+        self.status = status_buffer(dev)          # None unless numerics checking is on (epropnp.status)
         self.c = _hip.Problem(_hip.ptr(self.x3d), _hip.ptr(self.x2d), _hip.ptr(self.w2d), _hip.ptr(self.cam),
-                              _hip.ptr(self.lb), _hip.ptr(self.ub), _hip.ptr(self.delta), self.z_min, B, N, dof)
+                              _hip.ptr(self.lb), _hip.ptr(self.ub), _hip.ptr(self.delta), self.z_min, B, N, dof,
+                              self.huber_eps, _hip.ptr(self.status))
         self.stream = _hip.stream_of(self.x2d)
 
     @staticmethod
@@ -75,6 +137,15 @@ class PnPProblem:
 
     def new(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def with_points(self, x3d):
+        """The same problem over other (contiguous fp32) 3D points -- the centred ones of pnp_normalize."""
+        import copy
+        other = copy.copy(self)
+        other.x3d = x3d
+        other.c = _hip.Problem.from_buffer_copy(self.c)
+        other.c.x3d = x3d.data_ptr()
+        return other
 
 
 _shared = threading.local()
@@ -187,9 +258,11 @@ def backward_split(B, N, S):
     return n
 
 
-def amis_backward(prob, pose_samples, grad_logweights, pose_init=None, grad_cost_init=None, nsplit=None):
-    """-> grad_x3d (B,N,3), grad_x2d (B,N,2), grad_w2d (B,N,2), grad_delta (B,)."""
+def amis_backward(prob, pose_samples, grad_logweights, pose_init=None, grad_cost_init=None, nsplit=None, cstruct=None):
+    """-> grad_x3d (B,N,3), grad_x2d (B,N,2), grad_w2d (B,N,2), grad_delta (B,).
+    `cstruct`: a C problem struct to use instead of prob.c (same shapes; the fused path's centred points)."""
     B, N = prob.B, prob.N
+    cs = prob.c if cstruct is None else cstruct
     S = 0 if pose_samples is None else pose_samples.shape[0]
     smp = None if S == 0 else _f32c(pose_samples, 'pose_samples')
     glw = None if S == 0 else _f32c(grad_logweights, 'grad_logweights')
@@ -200,11 +273,11 @@ def amis_backward(prob, pose_samples, grad_logweights, pose_init=None, grad_cost
     nsplit = backward_split(B, N, S) if nsplit is None else int(nsplit)
     if nsplit > 1:
         parts = prob.new(B, nsplit)
-        _hip.call('epropnp_amis_backward_split', C.byref(prob.c), _hip.ptr(smp), _hip.ptr(glw), S, _hip.ptr(pin),
+        _hip.call('epropnp_amis_backward_split', C.byref(cs), _hip.ptr(smp), _hip.ptr(glw), S, _hip.ptr(pin),
                   _hip.ptr(gin), nsplit, _hip.ptr(gx3d), _hip.ptr(gx2d), _hip.ptr(gw2d), _hip.ptr(parts), prob.stream)
         return gx3d, gx2d, gw2d, parts.sum(dim=1)
     gdel = prob.new(B)
-    _hip.call('epropnp_amis_backward', C.byref(prob.c), _hip.ptr(smp), _hip.ptr(glw), S, _hip.ptr(pin), _hip.ptr(gin),
+    _hip.call('epropnp_amis_backward', C.byref(cs), _hip.ptr(smp), _hip.ptr(glw), S, _hip.ptr(pin), _hip.ptr(gin),
               _hip.ptr(gx3d), _hip.ptr(gx2d), _hip.ptr(gw2d), _hip.ptr(gdel), prob.stream)
     return gx3d, gx2d, gw2d, gdel
 
@@ -246,6 +319,81 @@ class _MonteCarloCost(torch.autograd.Function):
 
 def monte_carlo_cost(x3d, x2d, w2d, delta, prob, pose_opt, pose_cov, pose_init, cost_init_value, cfg):
     return _MonteCarloCost.apply(x3d, x2d, w2d, delta, prob, pose_opt, pose_cov, pose_init, cost_init_value, cfg)
+
+
+def _lm_struct(solver, fast_mode):
+    return _hip.LmParams(int(solver.num_iter), int(bool(fast_mode)), solver.min_lm_diagonal, solver.max_lm_diagonal,
+                         solver.min_relative_decrease, solver.initial_trust_region_radius,
+                         solver.max_trust_region_radius, solver.eps)
+
+
+class _FusedMonteCarlo(torch.autograd.Function):
+    """monte_carlo_forward as ONE autograd node over ONE host call (epropnp_monte_carlo_forward, csrc/mc_forward.hip):
+    [normalize] -> cost_init -> [RSLM, cheaper-of-two start] -> LM -> AMIS -> [denormalize] are enqueued from C++;
+    (x3d, x2d, w2d, delta) -> (pose_opt, cost, pose_samples, logweights, cost_init), the last two differentiable.
+    Backward: the same recompute kernel as _MonteCarloCost, in the solver's (normalised) frame."""
+
+    @staticmethod
+    def forward(ctx, x3d, x2d, w2d, delta, prob, pose_init, par, noise, with_cost):
+        B, N, PL, d = prob.B, prob.N, prob.pose_len, prob.dof
+        S = par.amis.mc_samples
+        new = prob.new
+        pin = None if pose_init is None else _f32c(pose_init, 'pose_init')
+        nz = None
+        if noise is not None:
+            nz = _f32c(noise, 'noise')
+            assert nz.shape == (B, par.amis.num_iter, S // par.amis.num_iter, noise_stride(d)), f'noise shape {tuple(nz.shape)}'
+        normalize = bool(par.normalize)
+        x3d_c = new(B, N, 3) if normalize else None
+        offset = new(B, 3) if normalize else None
+        pin_n = new(B, PL) if (normalize and pin is not None) else None
+        start_pose, start_cost = (new(B, PL), new(B)) if par.init_mode else (None, None)
+        pose_opt_n, pose_cov, samples_n, logw = new(B, PL), new(B, d, d), new(S, B, PL), new(S, B)
+        cost = new(B) if with_cost else None
+        cost_init = new(B) if pin is not None else None
+        pose_opt, samples = (new(B, PL), new(S, B, PL)) if normalize else (None, None)     # caller's frame
+        p = _hip.ptr
+        _hip.call('epropnp_monte_carlo_forward', C.byref(prob.c), C.byref(par), p(pin), p(nz), p(x3d_c), p(offset), p(pin_n),
+                  p(start_pose), p(start_cost), p(pose_opt_n), p(pose_cov), p(cost), p(samples_n), p(logw), p(cost_init),
+                  p(pose_opt), p(samples), prob.stream)
+        if normalize:      # the backward differentiates the cost in the solver frame: same problem, centred points
+            bprob = _hip.Problem.from_buffer_copy(prob.c)
+            bprob.x3d = x3d_c.data_ptr()
+        else:
+            bprob = prob.c
+        ctx.set_materialize_grads(False)
+        ctx.prob, ctx.bprob, ctx.keep = prob, bprob, (x3d_c, pin_n if normalize else pin)
+        ctx.save_for_backward(samples_n)
+        ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
+        ctx.mark_non_differentiable(*[t for t in (pose_opt_n, samples_n, cost, pose_opt, samples, x3d_c, offset) if t is not None])
+        return pose_opt_n, samples_n, logw, cost, cost_init, pose_opt, samples, x3d_c, offset
+
+    @staticmethod
+    def backward(ctx, _gpn, _gsn, g_logw, _gc, g_cost_init, _gp, _gs, _gx, _go):
+        (samples_n,) = ctx.saved_tensors
+        prob = ctx.prob
+        if g_logw is None and g_cost_init is None:
+            return (None,) * 9
+        if g_logw is None:
+            g_logw = torch.zeros(samples_n.shape[:2], dtype=torch.float32, device=samples_n.device)
+        pin = ctx.keep[1]
+        gx3d, gx2d, gw2d, gdel = amis_backward(prob, samples_n, g_logw, pin if g_cost_init is not None else None,
+                                               g_cost_init, cstruct=ctx.bprob)
+        gdelta = None
+        if ctx.delta_shape is not None and ctx.needs_input_grad[3]:
+            gdelta = gdel.sum() if len(ctx.delta_shape) == 0 else gdel.reshape(ctx.delta_shape)
+        return (gx3d if ctx.needs_input_grad[0] else None, gx2d if ctx.needs_input_grad[1] else None,
+                gw2d if ctx.needs_input_grad[2] else None, gdelta, None, None, None, None, None)
+
+
+def fused_monte_carlo(x3d, x2d, w2d, delta, prob, pose_init, par, noise, with_cost):
+    """-> pose_opt, pose_samples, logweights, cost | None, cost_init | None, and the solver frame: pose_opt_n,
+    (x3d_centered, offset) | (None, None)"""
+    pose_opt_n, samples_n, logw, cost, cost_init, pose_opt, samples, x3d_c, offset = _FusedMonteCarlo.apply(
+        x3d, x2d, w2d, delta, prob, pose_init, par, noise, with_cost)
+    if pose_opt is None:
+        pose_opt, samples = pose_opt_n, samples_n
+    return pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset
 
 
 class _AdaptiveDelta(torch.autograd.Function):

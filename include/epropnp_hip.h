@@ -28,7 +28,7 @@ extern "C" {
 #define EPROPNP_ELAUNCH (-2)  /* HIP launch/runtime error                                         */
 #define EPROPNP_ENODEV (-3)   /* no HIP device / not a gfx950 code object                         */
 
-#define EPROPNP_ABI_VERSION 2
+#define EPROPNP_ABI_VERSION 3
 
 /* Correspondences + camera + robust-cost parameters of one batch of objects.
  * Mirrors the state of PerspectiveCamera (epropnp/camera.py:35-62) and HuberPnPCost.delta
@@ -45,7 +45,21 @@ typedef struct epropnp_problem {
   int32_t num_obj;       /* B */
   int32_t num_pts;       /* N */
   int32_t dof;           /* 6 or 4 */
+  float huber_eps;       /* HuberPnPCost.eps (cost_fun.py:18-22,29): floor of |r| in the robust rescaling
+                            sqrt(min(delta / max(|r|, eps), 1)); <= 0 selects the reference default 1e-10            */
+  int32_t* status;       /* optional DEVICE int32[2] (or NULL): kernels OR EPROPNP_ST_* flags into status[0] and
+                            atomicMin the first offending object index into status[1] (initialise to {0, INT32_MAX}).
+                            Lets a caller reproduce, after a synchronisation of its choosing, the RuntimeError that
+                            torch.linalg.solve / torch.inverse raise in the reference (levenberg_marquardt.py:15-19,
+                            :178-181) instead of receiving NaN poses silently.                                        */
 } epropnp_problem;
+
+/* status[0] flags */
+#define EPROPNP_ST_LM_NOT_SPD 1        /* a damped normal-equation system had no Cholesky factor (singular / NaN input) */
+#define EPROPNP_ST_NONFINITE_POSE 2    /* lm_solve / rslm_solve / gn_step produced a non-finite pose                    */
+#define EPROPNP_ST_CHOL_FALLBACK 4     /* a proposal covariance was replaced by its default (cholesky_wrapper,
+                                          epropnp.py:16-33: what the reference does silently as well)                  */
+#define EPROPNP_ST_NONFINITE_WEIGHT 8  /* an AMIS log-weight is NaN / +inf                                              */
 
 /* Trust-region parameters of LMSolver.__init__ (epropnp/levenberg_marquardt.py:31-53). */
 typedef struct epropnp_lm_params {
@@ -71,6 +85,39 @@ typedef struct epropnp_amis_params {
   const uint64_t* offset_dev; /* optional DEVICE counter added to `offset` when the kernel runs: lets a captured hipGraph
                                  draw fresh samples on every replay (the caller increments it inside the graph) */
 } epropnp_amis_params;
+
+/* Everything EProPnPBase.monte_carlo_forward does between its arguments and its return tuple
+ * (epropnp/epropnp.py:87-196): one host call that enqueues, in order,
+ *   [pnp_normalize: centre x3d, shift pose_init (common.py:103-124)] -> cost of pose_init (:121-124) ->
+ *   [RSLM initialiser, and per object the cheaper of {pose_init, RSLM pose} (levenberg_marquardt.py:115-130)] ->
+ *   LM solve with covariance (:132-190) -> AMIS loop (:132-182) -> [pnp_denormalize of pose_opt and the samples]. */
+typedef struct epropnp_mc_params {
+  epropnp_lm_params lm;          /* the main solve                                                                   */
+  epropnp_amis_params amis;
+  int32_t normalize;             /* 1: EProPnPBase(normalize=True)                                                   */
+  int32_t init_mode;             /* 0: start LM from pose_init; 1: RSLM only (pose_init NULL);
+                                    2: force_init_solve=True with pose_init: per object the cheaper of the two      */
+  epropnp_lm_params rslm_lm;     /* RSLMSolver's own LM parameters (sub-problems)                                   */
+  int32_t rslm_points, rslm_proposals;
+  uint64_t rslm_seed, rslm_offset;
+  const uint64_t* rslm_offset_dev;
+  const int64_t* rslm_inds;      /* injected sub-sample indices (P,B,n) or NULL                                      */
+  const float* rslm_rot;         /* injected initial rotations or NULL                                               */
+} epropnp_mc_params;
+
+/*   pose_init (B,pose_len) or NULL (init_mode 1); noise as in epropnp_amis_forward
+ *   scratch the caller owns (it must outlive the backward): x3d_centered (B,N,3) + offset (B,3) + pose_init_n
+ *     (B,pose_len) when normalize, NULL otherwise; start_pose (B,pose_len) + start_cost (B,) when init_mode != 0
+ *   -> in the (normalised) solver frame: pose_opt_n (B,pose_len), pose_cov (B,dof,dof), cost (B,) or NULL,
+ *      pose_samples_n (S,B,pose_len), logweights (S,B), cost_init (B,) (NULL iff pose_init NULL)
+ *   -> in the caller's frame (only when normalize; otherwise pass NULL and use the _n buffers):
+ *      pose_opt (B,pose_len), pose_samples (S,B,pose_len).
+ * The backward is epropnp_amis_backward on the problem with x3d = x3d_centered and pose_samples_n / pose_init_n. */
+int epropnp_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_params* par, const float* pose_init,
+                                const float* noise, float* x3d_centered, float* offset, float* pose_init_n,
+                                float* start_pose, float* start_cost, float* pose_opt_n, float* pose_cov, float* cost,
+                                float* pose_samples_n, float* logweights, float* cost_init, float* pose_opt,
+                                float* pose_samples, void* stream);
 
 int epropnp_abi_version(void);
 const char* epropnp_last_error(void);
@@ -113,6 +160,8 @@ int epropnp_amis_forward(const epropnp_problem* prob, const epropnp_amis_params*
 /* Backward of  sum_b [ g_init[b]*cost(pose_init[b]) + sum_j g_logw[j,b]*logw[j,b] ]  w.r.t. x3d, x2d, w2d, delta:
  * what autograd replays through evaluate_pnp in the reference, recomputed
  * from the points instead of stored activations.  logw = -cost - const  =>  weight of sample j is -g_logw[j,b].
+ * Samples whose TOTAL |weight| is below 2^-24 of the object's total (one fp32 rounding of the sum) are skipped;
+ * environment EPROPNP_BWD_DROP=<fraction> changes that budget, 0 evaluates every non-zero sample (exact).
  *   pose_samples (S,B,pose_len), grad_logweights (S,B), pose_init (B,pose_len) or NULL, grad_cost_init (B,) or NULL
  *   -> grad_x3d (B,N,3), grad_x2d (B,N,2), grad_w2d (B,N,2), grad_delta (B,) */
 int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,

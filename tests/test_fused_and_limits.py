@@ -1,0 +1,162 @@
+"""The one-call forward (csrc/mc_forward.hip), the device-side status word, N beyond the register-resident limit and a
+non-default HuberPnPCost.eps."""
+import pytest
+import torch
+
+import epropnp_oracle as orc
+from helpers import make_layer_objects, pack_noise
+
+
+def _layer(dof, S, K, L, normalize, rslm):
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+    init = RSLMSolver(dof=dof, num_points=8, num_proposals=12, num_iter=3) if rslm else None
+    return (EProPnP6DoF if dof == 6 else EProPnP4DoF)(mc_samples=S, num_iter=K, normalize=normalize,
+                                                      solver=LMSolver(dof=dof, num_iter=L, init_solver=init))
+
+
+@pytest.mark.parametrize('dof,normalize,rslm,plus,bounds', [(6, False, False, False, None), (4, True, True, True, 'tensor'),
+                                                             (6, True, False, True, 'tight'), (4, False, True, False, None),
+                                                             (6, False, True, True, None)])
+def test_fused_forward_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bounds):
+    """epropnp_monte_carlo_forward enqueues the same kernels the separate calls do: outputs and input gradients are
+    bit-identical to the composite path (EPROPNP_NO_FUSED_FORWARD=1), with and without pnp_normalize, RSLM
+    initialisation (injected draws), pose_opt_plus and projection bounds; force_init_solve picks per object."""
+    B, N, S, K, L = 5, 70, 32, 2, 3
+    prob = orc.make_problem(B, N, dof, seed=3, bounds=bounds)
+    prob['pose_init'][0, :3] += 3.0                        # object 0: a bad pose_init, so RSLM's start wins there
+    noise = pack_noise(orc.make_noise(B, S, K, dof, seed=4), dof).to(backend)
+    rn = orc.make_rslm_noise(prob, dof, 8, 12, seed=5)
+    outs = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv('EPROPNP_NO_FUSED_FORWARD', raising=False)
+        else:
+            monkeypatch.setenv('EPROPNP_NO_FUSED_FORWARD', '1')
+        p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
+        x3d, x2d, w2d = (p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+        cf.set_param(x2d.detach(), w2d)
+        layer = _layer(dof, S, K, L, normalize, rslm)
+        if rslm:
+            layer.solver.init_solver.draw = lambda w: (rn['inds'].to(backend), rn['rot'].float().to(backend))
+        assert layer._fusable(x3d, x2d, w2d, p['pose_init'], rslm, dict(with_pose_opt_plus=plus)) == fused
+        out = layer.monte_carlo_forward(x3d, x2d, w2d, cam, cf, pose_init=p['pose_init'], force_init_solve=rslm,
+                                        with_pose_opt_plus=plus, with_cost=True, noise=noise)
+        pose_opt, cost, pplus, samples, logw, cost_init = out
+        loss = (cost_init + torch.logsumexp(logw, 0)).mean()
+        if plus:
+            loss = loss + 0.1 * pplus.sum()
+        loss.backward()
+        outs.append([t.detach().cpu() for t in (pose_opt, cost, samples, logw, cost_init, x3d.grad, x2d.grad, w2d.grad)]
+                    + ([pplus.detach().cpu()] if plus else []))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_fused_forward_without_pose_init_and_fallback_paths(backend):
+    """pose_init=None (RSLM only: no cost_init) through the fused entry; a solver the fused entry does not cover (a
+    subclass) takes the composite path and still works."""
+    from epropnp.levenberg_marquardt import LMSolver
+    B, N, S, K = 4, 64, 32, 2
+    prob = orc.make_problem(B, N, 4, seed=6)
+    p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
+    cf.set_param(p['x2d'], p['w2d'])
+    layer = _layer(4, S, K, 3, True, True)
+    out = layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf)
+    assert out[5] is None and out[1] is None and out[3].shape == (S, B, 4) and torch.isfinite(out[4]).all()
+    assert (out[0][:, :3].cpu() - prob['pose_gt'][:, :3]).norm(dim=-1).median() < 1.0
+
+    class MySolver(LMSolver):
+        pass
+    layer.solver = MySolver(dof=4, num_iter=3, init_solver=layer.solver.init_solver)
+    assert not layer._fusable(p['x3d'], p['x2d'], p['w2d'], None, True, {})
+    out2 = layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf)
+    assert out2[3].shape == (S, B, 4)
+
+
+def test_numerics_check_reports_what_the_reference_raises(backend):
+    """A NaN 3D point makes the damped normal equations non-finite: the reference's torch.linalg.solve raises
+    (levenberg_marquardt.py:15-19); here the kernels record it in the device status word and `numerics_check` raises
+    after ONE synchronisation, naming the first offending object.  Healthy inputs pass; strict mode also reports the
+    Cholesky fallback the reference takes silently."""
+    from epropnp import functional as F
+    from epropnp.levenberg_marquardt import LMSolver
+    B, N = 6, 40
+    prob = orc.make_problem(B, N, 6, seed=8)
+    p, cam, cf = make_layer_objects(prob, backend)
+    solver = LMSolver(dof=6, num_iter=3)
+    with F.numerics_check():
+        solver.solve(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], with_pose_cov=True)
+    bad = p['x3d'].clone()
+    bad[4, 7, 0] = float('nan')
+    with pytest.raises(RuntimeError, match='object 4'):
+        with F.numerics_check():
+            solver.solve(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])
+    # unchecked, the failure is silent: every trust-region step of that object is rejected (NaN comparisons are false),
+    # so it comes back at its starting pose while the other objects are solved
+    pose_opt = solver.solve(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])[0]
+    assert torch.equal(pose_opt[4], p['pose_init'][4]) and not torch.equal(pose_opt[3], p['pose_init'][3])
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6)
+    po, cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
+    cov = cov.clone()
+    cov[2, 0, 0] = -1.0
+    with F.numerics_check():                                  # tolerated, as in the reference
+        F.amis_forward(F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6), po, cov, 32, 2, seed=1)
+    with pytest.raises(RuntimeError, match='cholesky.*object 2'):
+        with F.numerics_check(strict=True):
+            F.amis_forward(F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6), po, cov, 32, 2, seed=1)
+
+
+def test_lm_and_normal_equations_beyond_the_resident_limit(backend):
+    """N = 8300 > 8192 points per object: the LM solve and the normal-equation sweep stream the points instead of
+    refusing (the reference accepts any N)."""
+    from epropnp import functional as F
+    B, N = 2, 8300
+    prob = orc.make_problem(B, N, 6, seed=9)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6)
+    pose, cov, cost = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True, with_cost=True)
+    o = orc.lm_solve(prob['x3d'], prob['x2d'], prob['w2d'], orc.Cam(prob['cam_mats'], 0.1), prob['delta'], prob['pose_init'],
+                     with_pose_cov=True, with_cost=True, num_iter=3)
+    assert (pose.cpu() - o[0]).abs().max() <= 1e-4
+    torch.testing.assert_close(cost.cpu(), o[2], rtol=1e-4, atol=1e-5)
+    jtj, jtr, c = F.normal_equations(hp, p['pose_init'])
+    res, cc, jac = orc.evaluate(*(prob[k].double() for k in ('x3d', 'x2d', 'w2d', 'pose_init')),
+                                orc.Cam(prob['cam_mats'].double(), 0.1), prob['delta'].double(), True, True)
+    ref = jac.transpose(-1, -2) @ jac
+    assert ((jtj.cpu().double() - ref).abs() / ref.abs().amax(dim=(-1, -2), keepdim=True)).max() < 5e-5
+    torch.testing.assert_close(c.cpu().double(), cc, rtol=1e-5, atol=1e-6)
+
+
+def test_non_default_huber_eps(backend):
+    """HuberPnPCost(eps=...) (cost_fun.py:18-22,29): the floor of |r| in the robust rescaling.  It only binds when the
+    threshold delta is itself below eps -- then sqrt(min(delta / max(rho, eps), 1)) < 1 for every point."""
+    from epropnp import functional as F
+    from epropnp.cost_fun import HuberPnPCost
+    B, N, eps = 3, 50, 5.0
+    prob = orc.make_problem(B, N, 6, seed=10)
+    prob['delta'] = torch.full((B,), 0.5)
+    p, cam, _ = make_layer_objects(prob, backend)
+    cf = HuberPnPCost(delta=p['delta'], eps=eps)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6)
+    jtj, jtr, _ = F.normal_equations(hp, p['pose_init'])
+    for e, should_match in ((eps, True), (1e-10, False)):
+        res, _, jac = orc.evaluate(*(prob[k].double() for k in ('x3d', 'x2d', 'w2d', 'pose_init')),
+                                   orc.Cam(prob['cam_mats'].double(), 0.1), prob['delta'].double(), True, True, eps=e)
+        ref = jac.transpose(-1, -2) @ jac
+        err = ((jtj.cpu().double() - ref).abs() / ref.abs().amax(dim=(-1, -2), keepdim=True)).max().item()
+        assert (err < 5e-5) == should_match, (e, err)
+    # gn_step with the same eps: value and gradient w.r.t. w2d against autograd of the oracle
+    w2d = p['w2d'].clone().requires_grad_(True)
+    hq = F.PnPProblem(p['x3d'], p['x2d'], w2d, cam, cf, 6)
+    step = F.gn_step(p['x3d'], p['x2d'], w2d, None, hq, p['pose_init'], 1e-5)
+    up = torch.linspace(0.5, 1.5, 6)
+    (step * up.to(backend)).sum().backward()
+    wr = prob['w2d'].double().clone().requires_grad_(True)
+    res, _, jac = orc.evaluate(prob['x3d'].double(), prob['x2d'].double(), wr, prob['pose_init'].double(),
+                               orc.Cam(prob['cam_mats'].double(), 0.1), prob['delta'].double(), True, True, eps=eps)
+    jt = jac.transpose(-1, -2)
+    ref_step = -torch.linalg.solve(jt @ jac + 1e-5 * torch.eye(6, dtype=torch.float64), jt @ res.unsqueeze(-1)).squeeze(-1)
+    (ref_step * up.double()).sum().backward()
+    assert (step.detach().cpu().double() - ref_step.detach()).abs().max() < 2e-4 * ref_step.abs().max()
+    assert ((w2d.grad.cpu().double() - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-3
