@@ -39,7 +39,7 @@ def _run(cmd):
     return r.stdout + r.stderr
 
 
-def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=(), file_flags=()):
+def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=(), file_flags=(), arch=None):
     deps_common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, 'include', 'epropnp_hip.h')]
     if emu:
         out_dir = os.path.join(ROOT, 'tests', 'emu', '_build')
@@ -52,7 +52,8 @@ def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=(),
         out_dir = os.path.join(HERE, 'lib') if not tag else os.path.join(HERE, 'lib', 'variants', tag)
         lib = os.path.join(out_dir, 'libepropnp_hip.so')
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        cc = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value']
+        arch = arch or os.environ.get('EPROPNP_OFFLOAD_ARCH', 'gfx950')     # the kernels are written for gfx950 (MI355X)
+        cc = [hipcc, f'--offload-arch={arch}', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value']
         cc += ['-D' + d for d in defines] + list(flags)
     os.makedirs(out_dir, exist_ok=True)
     per_file = {k: list(v) for k, v in FILE_FLAGS.items()}
@@ -72,7 +73,7 @@ def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=(),
                 if verbose and out.strip():
                     print(out)
     if jobs or force or _stale(lib, objs):
-        link = (['g++'] if emu else [cc[0], '--offload-arch=gfx950']) + ['-shared', '-fPIC', '-o', lib] + objs
+        link = (['g++'] if emu else cc[:2]) + ['-shared', '-fPIC', '-o', lib] + objs
         _run(link)
     return lib
 
@@ -86,5 +87,6 @@ if __name__ == '__main__':
     ap.add_argument('--tag', default=None, help='build into lib/variants/<tag>/ (tuning variants)')
     ap.add_argument('--flag', dest='flags', action='append', default=[], help='extra compiler flag for a tuning variant')
     ap.add_argument('--file-flag', dest='file_flags', action='append', default=[], help='<source>=<flag> for a tuning variant')
+    ap.add_argument('--offload-arch', default=None, help='GPU architecture (default gfx950 = MI355X, or $EPROPNP_OFFLOAD_ARCH)')
     a = ap.parse_args()
-    print(build(a.emu, a.force, a.verbose, a.defines, a.tag, a.flags, a.file_flags))
+    print(build(a.emu, a.force, a.verbose, a.defines, a.tag, a.flags, a.file_flags, a.offload_arch))

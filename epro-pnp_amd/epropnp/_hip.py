@@ -9,8 +9,11 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# EPROPNP_LIB: alternative build of the SAME HIP library (kernel-tuning variants, tools/tune.py)
-LIB_PATH = os.environ.get('EPROPNP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libepropnp_hip.so')
+# EPROPNP_LIB: alternative build of the SAME HIP library (kernel-tuning variants, tools/tune.py); otherwise the in-tree
+# build (epro-pnp_amd/lib, `python epro-pnp_amd/build.py`) or the copy a `pip install .` places inside the package
+_IN_TREE = os.path.join(os.path.dirname(_HERE), 'lib', 'libepropnp_hip.so')
+_INSTALLED = os.path.join(_HERE, '_lib', 'libepropnp_hip.so')
+LIB_PATH = os.environ.get('EPROPNP_LIB') or (_INSTALLED if (os.path.exists(_INSTALLED) and not os.path.exists(_IN_TREE)) else _IN_TREE)
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)

@@ -109,10 +109,21 @@ class EProPnPBase(torch.nn.Module):
         """Weighted pose samples from the pose distribution defined by the correspondences.
 
         x3d (B,N,3), x2d (B,N,2), w2d (B,N,2); pose_init (B,4|7) optional (the target pose for the MC loss).
+        fp32 tensors on a HIP device only (no CPU / fp64 path); differentiable w.r.t. x3d, x2d, w2d and a tensor-valued
+        cost_fun.delta -- not w.r.t. pose_init or camera.cam_mats (a warning is issued if those require grad).
+        Limits: mc_samples * (pose_len + 3) * 4 B + tables must fit the 160 KiB of LDS (6-DoF: mc_samples <~ 3700); the
+        RSLM initialiser's one-launch kernel takes <= 16 points per proposal and <= 512 points per object (beyond that
+        the composite of the same kernels runs); any num_pts otherwise (LM streams beyond 8192 points).
         Returns: pose_opt (B,4|7), cost (B,)|None, pose_opt_plus (B,4|7)|None, pose_samples (S,B,4|7),
                  pose_sample_logweights (S,B) [differentiable], cost_init (B,)|None [differentiable].
         """
         assert x3d.dim() == x2d.dim() == w2d.dim() == 3
+        if torch.is_grad_enabled() and ((pose_init is not None and pose_init.requires_grad)
+                                        or (isinstance(camera.cam_mats, torch.Tensor) and camera.cam_mats.requires_grad)):
+            import warnings       # the reference's cost_init = evaluate_pnp(pose=pose_init) is differentiable w.r.t. these too
+            warnings.warn('EProPnP.monte_carlo_forward: gradients flow to x3d, x2d, w2d and cost_fun.delta only; pose_init / '
+                          'camera.cam_mats require grad but receive none from the HIP path (detach them, or use '
+                          'epropnp.common.evaluate_pnp for a differentiable cost of pose_init)', stacklevel=2)
         if self._fusable(x3d, x2d, w2d, pose_init, force_init_solve, kwargs):
             return self._fused_forward(x3d, x2d, w2d, camera, cost_fun, pose_init, force_init_solve, noise, **kwargs)
         if self.normalize:

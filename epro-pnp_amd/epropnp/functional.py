@@ -148,6 +148,20 @@ class PnPProblem:
         return other
 
 
+def _guard_inputs(ctx, prob):
+    """Remember the version counters of the tensors the recompute backward will read again (the nodes keep raw device
+    pointers, not autograd-saved tensors, so autograd's own in-place check does not see them)."""
+    ctx.guarded = [(t, t._version) for t in (prob.x3d, prob.x2d, prob.w2d, prob.delta, prob.cam)]
+
+
+def _check_inputs(ctx):
+    for t, v in ctx.guarded:
+        if t._version != v:
+            raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace '
+                               'operation (EPro-PnP recomputes its backward from x3d / x2d / w2d / delta / cam_mats: they '
+                               'must stay unchanged between forward and backward)')
+
+
 _shared = threading.local()
 
 
@@ -294,6 +308,7 @@ class _MonteCarloCost(torch.autograd.Function):
         samples, logw = amis_forward(prob, pose_opt, pose_cov, **cfg)
         ctx.set_materialize_grads(False)      # no (S,B,7) zero tensor for the non-differentiable samples output
         ctx.prob, ctx.pose_init = prob, pose_init
+        _guard_inputs(ctx, prob)
         ctx.save_for_backward(samples)
         ctx.mark_non_differentiable(samples)
         ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
@@ -307,6 +322,7 @@ class _MonteCarloCost(torch.autograd.Function):
         prob = ctx.prob
         if g_logw is None and g_cost_init is None:
             return (None,) * 10
+        _check_inputs(ctx)
         if g_logw is None:
             g_logw = torch.zeros(samples.shape[:2], dtype=torch.float32, device=samples.device)
         gx3d, gx2d, gw2d, gdel = amis_backward(prob, samples, g_logw, ctx.pose_init, g_cost_init)
@@ -363,6 +379,7 @@ class _FusedMonteCarlo(torch.autograd.Function):
             bprob = prob.c
         ctx.set_materialize_grads(False)
         ctx.prob, ctx.bprob, ctx.keep = prob, bprob, (x3d_c, pin_n if normalize else pin)
+        _guard_inputs(ctx, prob)
         ctx.save_for_backward(samples_n)
         ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
         ctx.mark_non_differentiable(*[t for t in (pose_opt_n, samples_n, cost, pose_opt, samples, x3d_c, offset) if t is not None])
@@ -374,6 +391,7 @@ class _FusedMonteCarlo(torch.autograd.Function):
         prob = ctx.prob
         if g_logw is None and g_cost_init is None:
             return (None,) * 9
+        _check_inputs(ctx)
         if g_logw is None:
             g_logw = torch.zeros(samples_n.shape[:2], dtype=torch.float32, device=samples_n.device)
         pin = ctx.keep[1]
@@ -573,6 +591,7 @@ class _GnStep(torch.autograd.Function):
         _hip.call('epropnp_gn_step_forward', C.byref(prob.c), float(eps), _hip.ptr(ps), _hip.ptr(step), prob.stream)
         ctx.set_materialize_grads(False)
         ctx.prob, ctx.eps = prob, float(eps)
+        _guard_inputs(ctx, prob)
         ctx.save_for_backward(ps)
         ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
         return step
@@ -581,6 +600,7 @@ class _GnStep(torch.autograd.Function):
     def backward(ctx, g):
         if g is None:
             return (None,) * 7
+        _check_inputs(ctx)
         (ps,) = ctx.saved_tensors
         prob = ctx.prob
         B, N = prob.B, prob.N
@@ -610,6 +630,7 @@ class _PoseOptPlus(torch.autograd.Function):
         _hip.call('epropnp_pose_opt_plus_forward', C.byref(prob.c), float(eps), _hip.ptr(ps), _hip.ptr(plus), prob.stream)
         ctx.set_materialize_grads(False)
         ctx.prob, ctx.eps = prob, float(eps)
+        _guard_inputs(ctx, prob)
         ctx.save_for_backward(ps)
         ctx.delta_shape = delta.shape if isinstance(delta, torch.Tensor) else None
         return plus
@@ -618,6 +639,7 @@ class _PoseOptPlus(torch.autograd.Function):
     def backward(ctx, g):
         if g is None:
             return (None,) * 7
+        _check_inputs(ctx)
         (ps,) = ctx.saved_tensors
         prob = ctx.prob
         B, N = prob.B, prob.N

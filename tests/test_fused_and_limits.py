@@ -160,3 +160,23 @@ def test_non_default_huber_eps(backend):
     (ref_step * up.double()).sum().backward()
     assert (step.detach().cpu().double() - ref_step.detach()).abs().max() < 2e-4 * ref_step.abs().max()
     assert ((w2d.grad.cpu().double() - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-3
+
+
+def test_inplace_edit_between_forward_and_backward_is_detected(backend):
+    """The backward recomputes from x3d / x2d / w2d / delta: editing one of them in place after the forward must raise
+    (as autograd does for saved tensors in the reference), not yield silently wrong gradients."""
+    from epropnp.epropnp import EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver
+    prob = orc.make_problem(3, 40, 6, seed=12)
+    p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
+    x3d = p['x3d'].clone().requires_grad_(True)
+    x2d = p['x2d'].clone()
+    cf.set_param(x2d, p['w2d'])
+    layer = EProPnP6DoF(mc_samples=32, num_iter=2, solver=LMSolver(dof=6, num_iter=3))
+    out = layer.monte_carlo_forward(x3d, x2d, p['w2d'], cam, cf, pose_init=p['pose_init'], force_init_solve=False)
+    x2d.add_(1.0)
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        (out[5] + torch.logsumexp(out[4], 0)).sum().backward()
+    pi = p['pose_init'].clone().requires_grad_(True)
+    with pytest.warns(UserWarning, match='pose_init'):
+        layer.monte_carlo_forward(x3d, p['x2d'], p['w2d'], cam, cf, pose_init=pi, force_init_solve=False)
