@@ -62,15 +62,22 @@ def assert_within_spread(err, spread, bar, k=2.0, what=''):
     `spread` (orc.rounding_spread / the fixtures' `spread.*`) is how far the reference's own fp32 result moves per object
     when its inputs move by <= 3 ulp (plus its fp32-vs-fp64 drift).  It is ~0 for well-conditioned objects and large
     where a trust-region decision sits on a knife edge or the LM valley is flat -- but WHICH object of a batch trips
-    depends on the individual roundings, so errors and spreads are matched by rank, not by object index."""
+    depends on the individual roundings, so errors and spreads are matched by rank, not by object index.  HOW MANY trip
+    is a count of rare independent events: if `n_trip` objects have a spread above the bar, two correct implementations
+    differ in that count by ~sqrt(2 n_trip), so the error of rank i is held against the spread of rank
+    i - (1 + ceil(sqrt(2 n_trip))); with no such object (n_trip = 0) the match is strict."""
+    import math
     e = torch.sort(err.detach().flatten().double().cpu(), descending=True).values
     s = torch.sort(spread.detach().flatten().double().cpu(), descending=True).values
     assert e.numel() == s.numel(), (e.shape, s.shape)
-    lim = bar + k * s
+    n_trip = int((s > bar).sum())
+    slack = 0 if n_trip == 0 else 1 + math.ceil(math.sqrt(2 * n_trip))
+    idx = (torch.arange(e.numel()) - slack).clamp(min=0)
+    lim = bar + k * s[idx]
     bad = e > lim
-    assert not bool(bad.any()), (f'{what}: {int(bad.sum())} of {e.numel()} order statistics above bar {bar:g} + {k:g} x spread; '
-                                 f'worst: err {e[bad][0].item():.3e} vs limit {lim[bad][0].item():.3e} (rank {int(bad.nonzero()[0])})')
-
+    assert not bool(bad.any()), (f'{what}: {int(bad.sum())} of {e.numel()} order statistics above bar {bar:g} + {k:g} x spread '
+                                 f'(rank slack {slack}); worst: err {e[bad][0].item():.3e} vs limit {lim[bad][0].item():.3e} '
+                                 f'(rank {int(bad.nonzero()[0])})')
 
 def rel_per_object(a, b):
     """max |a - b| over an object's entries relative to the object's largest |b| -> (B,)"""

@@ -26,6 +26,13 @@ for set in "FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "WRITE_SIZE SQ_BUSY_CU
 done
 python /root/repo/tools/pmc_traffic.py /tmp/pmc1 /tmp/pmc2 C2:B4096:N512:S512:K4:L3 $O/${TAG}_pmc_traffic.json
 cd /root/repo
+(timeout 900 python tools/bench_configs.py 2>&1 | grep "^{") > $O/${TAG}_other_configs.json
+cat $O/${TAG}_other_configs.json
+(python tools/host_phases.py c4 2>&1 | tail -1; python tools/host_phases.py c3 2>&1 | tail -1) > $O/${TAG}_host_phases.txt
+cat $O/${TAG}_host_phases.txt
+(EPROPNP_NO_FUSED_FORWARD=1 python tools/host_phases.py c4 2>&1 | tail -1 | sed 's/^/composite path (EPROPNP_NO_FUSED_FORWARD=1) /') >> $O/${TAG}_host_phases.txt
+(TUNE_VARIANTS="bwd_exact:EPROPNP_BWD_DROP=0" python tools/tune.py 2>&1) > $O/${TAG}_tune.txt
+cat $O/${TAG}_tune.txt
 for c in C4 C5; do
   (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --config $c --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1) > $O/${TAG}_bench_$c.json
   cut -c1-900 $O/${TAG}_bench_$c.json
