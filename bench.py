@@ -68,32 +68,6 @@ def synth_problem(B, N, device, seed, dof=6):
     return dict(x3d=x3d.contiguous(), x2d=x2d.contiguous(), w2d=w2d.contiguous(), cam_mats=K, pose_init=pose_init)
 
 
-class KernelTimer:
-    """HIP events (on the stream the kernels are launched on = torch's current stream) around one entry point of the
-    C ABI; sums the per-launch durations inside the timed region."""
-
-    def __init__(self, module, name):
-        self.module, self.name, self.orig = module, name, getattr(module, name)
-        self.events, self.enabled = [], False
-        timer = self
-
-        def wrapped(*a, **k):
-            if not timer.enabled:
-                return timer.orig(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = timer.orig(*a, **k)
-            e1.record()
-            timer.events.append((e0, e1))
-            return out
-        setattr(module, name, wrapped)
-
-    def mean_ms(self):
-        if not self.events:
-            return float('nan')
-        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
-
-
 def cpu_baseline(N, S, K, L, sample_objects, budget_s=25.0):
     """The oracle (oracle/epropnp_oracle.py) timed on the host cores on `sample_objects` objects of the same
     workload: monte_carlo_forward + MC loss + backward.  Test/baseline infrastructure -- never the product path.
@@ -254,8 +228,9 @@ def main():
         layer = EProPnP6DoF(mc_samples=S, num_iter=K, solver=LMSolver(dof=6, num_iter=L), seed=1 + rank)
         loss_mod, force_init = None, False
 
-    timers = {n: KernelTimer(F, n) for n in ('lm_solve', 'amis_forward', 'amis_backward', 'evaluate_cost')}
-    # (the adaptive-delta and Monte-Carlo-loss kernels are part of the step as well, untimed individually)
+    from epropnp import _hip
+    # per-kernel times: HIP events on the launch stream, recorded INSIDE the library around each kernel stage
+    # (epropnp_profile_*): the forward is one host call (epropnp_monte_carlo_forward), its stages are not visible from here
     coll_events = []
     gathered = {}
 
@@ -290,13 +265,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    for t in timers.values():
-        t.enabled = True
+    _hip.profile(enable=True, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
+    _hip.profile(enable=False)
     loss_val = float(loss.detach())
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -308,10 +283,11 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
-        t_lm = timers['lm_solve'].mean_ms()
-        t_fw = timers['amis_forward'].mean_ms()
-        t_bw = timers['amis_backward'].mean_ms()
-        t_ci = timers['evaluate_cost'].mean_ms()
+        stage_ms = {n: _hip.profile_read(n) for n in ('evaluate_cost', 'rslm_solve', 'lm_solve', 'amis_forward', 'amis_backward',
+                                                       'adaptive_delta', 'mc_loss_forward', 'mc_loss_backward',
+                                                       'center_points', 'shift_poses')}
+        t_lm, t_fw, t_bw, t_ci = (stage_ms[n][0] for n in ('lm_solve', 'amis_forward', 'amis_backward', 'evaluate_cost'))
+        assert stage_ms['lm_solve'][1] == args.steps and stage_ms['amis_backward'][1] == args.steps, stage_ms
         sweeps = 1 + L
         p_len, d = (7, 6) if dof == 6 else (4, 4)
         lm_bytes = sweeps * 28.0 * B * N + B * 4.0 * (p_len + 9 + 1) + B * 4.0 * (p_len + d * d + 1)
@@ -360,8 +336,7 @@ def main():
                 'amis_backward_mfma_kernel': {'bound': 'valu_fp32', 'achieved': round(bw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
                                          'unit': 'TFLOP/s', 'frac': round(bw_tf / FP32_VECTOR_PEAK_TF, 4),
                                          'flops_per_point_pose': 80, 'launch_ms': round(t_bw, 4)}},
-            'kernel_ms': {'evaluate_cost': round(t_ci, 4), 'lm_solve': round(t_lm, 4), 'amis_forward': round(t_fw, 4),
-                          'amis_backward': round(t_bw, 4)},
+            'kernel_ms': {n: round(v[0] * (v[1] / args.steps), 4) for n, v in stage_ms.items() if v[1]},   # per step
             'loss': round(loss_val, 5),
         }
         if strong:

@@ -1,4 +1,9 @@
 // c_api.hip -- extern "C" surface of libepropnp_hip.so (declared in include/epropnp_hip.h).
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
 #include "pnp_host.h"
 
 namespace pnp {
@@ -10,6 +15,49 @@ char* last_error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
 }
+
+// ---- per-stage HIP-event timing ------------------------------------------------------------------------------------
+#ifndef EPROPNP_EMU
+namespace {
+struct StageRec { const char* stage; hipEvent_t e0, e1; bool closed; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<StageRec> g_prof;          // records in use
+std::vector<hipEvent_t> g_pool;        // events created ahead of time: no hipEventCreate inside a timed region
+constexpr size_t kMaxStageRecs = 1 << 15;
+void fill_pool(size_t want) {
+  while (g_pool.size() < want) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) break;
+    g_pool.push_back(e);
+  }
+}
+void drop_records() {
+  for (auto& r : g_prof) { g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
+  g_prof.clear();
+}
+}  // namespace
+bool profile_begin(const char* stage, hipStream_t st) {
+  if (!g_prof_on) return false;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof.size() >= kMaxStageRecs) return false;
+  if (g_pool.size() < 2) fill_pool(64);
+  if (g_pool.size() < 2) return false;
+  StageRec r{stage, g_pool[g_pool.size() - 1], g_pool[g_pool.size() - 2], false};
+  g_pool.resize(g_pool.size() - 2);
+  (void)hipEventRecord(r.e0, st);
+  g_prof.push_back(r);
+  return true;
+}
+void profile_end(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (size_t i = g_prof.size(); i-- > 0;)
+    if (!g_prof[i].closed) { (void)hipEventRecord(g_prof[i].e1, st); g_prof[i].closed = true; break; }
+}
+#else
+bool profile_begin(const char*, hipStream_t) { return false; }
+void profile_end(hipStream_t) {}
+#endif
 }  // namespace pnp
 
 extern "C" {
@@ -31,22 +79,26 @@ int epropnp_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_pa
 }
 
 int epropnp_evaluate_cost(const epropnp_problem* prob, const float* poses, int32_t num_poses, float* cost, void* stream) {
+  pnp::StageScope prof_("evaluate_cost", (hipStream_t)stream);
   return pnp::launch_evaluate_cost(prob, poses, num_poses, cost, (hipStream_t)stream);
 }
 
 int epropnp_normal_equations(const epropnp_problem* prob, const float* pose, int32_t clip_jac, float* jtj, float* jtr,
                              float* cost, void* stream) {
+  pnp::StageScope prof_("normal_equations", (hipStream_t)stream);
   return pnp::launch_normal_equations(prob, pose, clip_jac, jtj, jtr, cost, (hipStream_t)stream);
 }
 
 int epropnp_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
                      float* pose_cov, float* cost, int32_t* accept_mask, void* stream) {
+  pnp::StageScope prof_("lm_solve", (hipStream_t)stream);
   return pnp::launch_lm_solve(prob, lm, pose_init, pose_opt, pose_cov, cost, accept_mask, (hipStream_t)stream);
 }
 
 int epropnp_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
                          const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
                          float* proposals, void* stream) {
+  pnp::StageScope prof_("amis_forward", (hipStream_t)stream);
   return pnp::launch_amis_forward(prob, amis, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
                                   (hipStream_t)stream);
 }
@@ -54,6 +106,7 @@ int epropnp_amis_forward(const epropnp_problem* prob, const epropnp_amis_params*
 int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
                           int32_t mc_samples, const float* pose_init, const float* grad_cost_init, float* grad_x3d,
                           float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream) {
+  pnp::StageScope prof_("amis_backward", (hipStream_t)stream);
   return pnp::launch_amis_backward(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init, grad_x3d,
                                    grad_x2d, grad_w2d, grad_delta, (hipStream_t)stream);
 }
@@ -61,6 +114,7 @@ int epropnp_amis_backward(const epropnp_problem* prob, const float* pose_samples
 int epropnp_amis_backward_split(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
                                 int32_t mc_samples, const float* pose_init, const float* grad_cost_init, int32_t num_split,
                                 float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta_parts, void* stream) {
+  pnp::StageScope prof_("amis_backward", (hipStream_t)stream);
   return pnp::launch_amis_backward_split(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init,
                                          num_split, grad_x3d, grad_x2d, grad_w2d, grad_delta_parts, (hipStream_t)stream);
 }
@@ -68,17 +122,20 @@ int epropnp_amis_backward_split(const epropnp_problem* prob, const float* pose_s
 
 int epropnp_adaptive_delta(const float* x2d, const float* w2d, int32_t num_obj, int32_t num_pts, float relative_delta,
                            float* delta, float* stats, void* stream) {
+  pnp::StageScope prof_("adaptive_delta", (hipStream_t)stream);
   return pnp::launch_adaptive_delta(x2d, w2d, num_obj, num_pts, relative_delta, delta, stats, (hipStream_t)stream);
 }
 
 int epropnp_mc_loss_forward(const float* logweights, const float* cost_target, int32_t mc_samples, int32_t num_obj,
                             float* loss, float* lse, void* stream) {
+  pnp::StageScope prof_("mc_loss_forward", (hipStream_t)stream);
   return pnp::launch_mc_loss_forward(logweights, cost_target, mc_samples, num_obj, loss, lse, (hipStream_t)stream);
 }
 
 int epropnp_mc_loss_backward(const float* logweights, const float* lse, const float* loss, const float* grad_loss,
                              int32_t mc_samples, int32_t num_obj, float* grad_logweights, float* grad_cost_target,
                              void* stream) {
+  pnp::StageScope prof_("mc_loss_backward", (hipStream_t)stream);
   return pnp::launch_mc_loss_backward(logweights, lse, loss, grad_loss, mc_samples, num_obj, grad_logweights,
                                       grad_cost_target, (hipStream_t)stream);
 }
@@ -90,11 +147,13 @@ int epropnp_rslm_draw(const float* w2d, int32_t num_obj, int32_t num_pts, int32_
 }
 
 int epropnp_gn_step_forward(const epropnp_problem* prob, float eps, const float* pose, float* step, void* stream) {
+  pnp::StageScope prof_("gn_step_forward", (hipStream_t)stream);
   return pnp::launch_gn_step_forward(prob, eps, pose, step, nullptr, (hipStream_t)stream);
 }
 
 int epropnp_gn_step_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_step,
                              float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream) {
+  pnp::StageScope prof_("gn_step_backward", (hipStream_t)stream);
   return pnp::launch_gn_step_backward(prob, eps, pose, grad_step, nullptr, grad_x3d, grad_x2d, grad_w2d, grad_delta,
                                       (hipStream_t)stream);
 }
@@ -107,11 +166,13 @@ int epropnp_shift_poses_backward(const float* pose, const float* offset, const f
 
 int epropnp_pose_opt_plus_forward(const epropnp_problem* prob, float eps, const float* pose, float* pose_plus,
                                   void* stream) {
+  pnp::StageScope prof_("gn_step_forward", (hipStream_t)stream);
   return pnp::launch_gn_step_forward(prob, eps, pose, nullptr, pose_plus, (hipStream_t)stream);
 }
 
 int epropnp_pose_opt_plus_backward(const epropnp_problem* prob, float eps, const float* pose, const float* grad_pose_plus,
                                    float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta, void* stream) {
+  pnp::StageScope prof_("gn_step_backward", (hipStream_t)stream);
   return pnp::launch_gn_step_backward(prob, eps, pose, nullptr, grad_pose_plus, grad_x3d, grad_x2d, grad_w2d, grad_delta,
                                       (hipStream_t)stream);
 }
@@ -119,17 +180,20 @@ int epropnp_pose_opt_plus_backward(const epropnp_problem* prob, float eps, const
 int epropnp_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int32_t num_proposals,
                        int32_t num_points, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                        const int64_t* inds, const float* rot, float* pose, float* cost, void* stream) {
+  pnp::StageScope prof_("rslm_solve", (hipStream_t)stream);
   return pnp::launch_rslm_solve(prob, lm, num_proposals, num_points, seed, offset, (const unsigned long long*)offset_dev,
                                 (const long long*)inds, rot, pose, cost, (hipStream_t)stream);
 }
 
 int epropnp_center_points(const float* x3d, int32_t num_obj, int32_t num_pts, float* offset, float* x3d_centered,
                           void* stream) {
+  pnp::StageScope prof_("center_points", (hipStream_t)stream);
   return pnp::launch_center_points(x3d, num_obj, num_pts, offset, x3d_centered, (hipStream_t)stream);
 }
 
 int epropnp_shift_poses(const float* pose, const float* offset, int32_t num_poses, int32_t num_obj, int32_t dof,
                         float sign, float* out, void* stream) {
+  pnp::StageScope prof_("shift_poses", (hipStream_t)stream);
   return pnp::launch_shift_poses(pose, offset, num_poses, num_obj, dof, sign, out, (hipStream_t)stream);
 }
 
@@ -163,6 +227,45 @@ int epropnp_prepare_dense_backward(const float* noc_map, const float* dim, const
   return pnp::launch_prepare_dense_backward(noc_map, dim, logit_map, scale, (const long long*)inds, stats, grad_x3d, grad_w2d,
                                             num_obj, num_pts, height, width, mode, grad_noc_map, grad_dim, grad_logit_map,
                                             grad_scale, (hipStream_t)stream);
+}
+
+int epropnp_profile_enable(int on) {
+#ifndef EPROPNP_EMU
+  std::lock_guard<std::mutex> lk(pnp::g_prof_mu);
+  if (on) pnp::fill_pool(8192);        // 4096 stage launches before anything is created inside a timed region
+  pnp::g_prof_on = on != 0;
+#else
+  (void)on;
+#endif
+  return EPROPNP_OK;
+}
+
+int epropnp_profile_reset(void) {
+#ifndef EPROPNP_EMU
+  std::lock_guard<std::mutex> lk(pnp::g_prof_mu);
+  pnp::drop_records();
+#endif
+  return EPROPNP_OK;
+}
+
+int epropnp_profile_read(const char* stage, float* mean_ms, int32_t* count) {
+  if (!stage || !mean_ms || !count) return pnp::fail(EPROPNP_EINVAL, "profile_read: NULL argument");
+  *mean_ms = 0.f;
+  *count = 0;
+#ifndef EPROPNP_EMU
+  std::lock_guard<std::mutex> lk(pnp::g_prof_mu);
+  double sum = 0.0;
+  for (auto& r : pnp::g_prof) {
+    if (!r.closed || strcmp(r.stage, stage) != 0) continue;
+    if (hipEventSynchronize(r.e1) != hipSuccess) return pnp::fail(EPROPNP_ELAUNCH, "profile_read: event synchronise failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    sum += ms;
+    ++*count;
+  }
+  if (*count > 0) *mean_ms = (float)(sum / *count);
+#endif
+  return EPROPNP_OK;
 }
 
 #ifdef PNP_TUNING

@@ -47,16 +47,21 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
   const float* pinit = pose_init;
   int rc;
   if (par->normalize) {       // pnp_normalize (common.py:103-124)
-    if ((rc = launch_center_points(prob->x3d, B, prob->num_pts, offset, x3d_centered, st))) return rc;
+    { StageScope ps("center_points", st); if ((rc = launch_center_points(prob->x3d, B, prob->num_pts, offset, x3d_centered, st))) return rc; }
     q.x3d = x3d_centered;
     if (pose_init) {
+      StageScope ps("shift_poses", st);
       if ((rc = launch_shift_poses(pose_init, offset, 1, B, prob->dof, +1.0f, pose_init_n, st))) return rc;
       pinit = pose_init_n;
     }
   }
-  if (pinit && (rc = launch_evaluate_cost(&q, pinit, 1, cost_init, st))) return rc;        // cost of pose_init (:121-124)
+  if (pinit) {                // cost of pose_init (:121-124)
+    StageScope ps("evaluate_cost", st);
+    if ((rc = launch_evaluate_cost(&q, pinit, 1, cost_init, st))) return rc;
+  }
   const float* start = pinit;
   if (par->init_mode != 0) {  // random-sample initialiser (levenberg_marquardt.py:115-130,283-353)
+    StageScope ps("rslm_solve", st);
     if ((rc = launch_rslm_solve(&q, &par->rslm_lm, par->rslm_proposals, par->rslm_points, par->rslm_seed, par->rslm_offset,
                                 (const unsigned long long*)par->rslm_offset_dev, (const long long*)par->rslm_inds,
                                 par->rslm_rot, start_pose, start_cost, st)))
@@ -68,10 +73,10 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
     }
     start = start_pose;
   }
-  if ((rc = launch_lm_solve(&q, &par->lm, start, pose_opt_n, pose_cov, cost, nullptr, st))) return rc;
-  if ((rc = launch_amis_forward(&q, &par->amis, pose_opt_n, pose_cov, noise, pose_samples_n, logweights, nullptr, st)))
-    return rc;
+  { StageScope ps("lm_solve", st); if ((rc = launch_lm_solve(&q, &par->lm, start, pose_opt_n, pose_cov, cost, nullptr, st))) return rc; }
+  { StageScope ps("amis_forward", st); if ((rc = launch_amis_forward(&q, &par->amis, pose_opt_n, pose_cov, noise, pose_samples_n, logweights, nullptr, st))) return rc; }
   if (par->normalize) {       // pnp_denormalize (common.py:127-136)
+    StageScope ps("shift_poses", st);
     if ((rc = launch_shift_poses(pose_opt_n, offset, 1, B, prob->dof, -1.0f, pose_opt, st))) return rc;
     if ((rc = launch_shift_poses(pose_samples_n, offset, S, B, prob->dof, -1.0f, pose_samples, st))) return rc;
   }

@@ -95,6 +95,17 @@ inline float backward_drop_eps() {
   return 5.9604644775390625e-08f;
 }
 
+// Optional per-stage timing (epropnp_profile_*, include/epropnp_hip.h): HIP events on the launch stream around each
+// kernel stage, recorded inside the library so that stages launched from epropnp_monte_carlo_forward are visible too.
+bool profile_begin(const char* stage, hipStream_t st);     // false (and no work) unless profiling is enabled
+void profile_end(hipStream_t st);
+struct StageScope {
+  hipStream_t st;
+  bool on;
+  StageScope(const char* stage, hipStream_t s) : st(s), on(profile_begin(stage, s)) {}
+  ~StageScope() { if (on) profile_end(st); }
+};
+
 // launchers (one per .hip translation unit)
 int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_params* par, const float* pose_init,
                                const float* noise, float* x3d_centered, float* offset, float* pose_init_n,

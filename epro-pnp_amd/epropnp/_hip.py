@@ -55,6 +55,8 @@ def _declare(lib):
     lib.epropnp_abi_version.restype = C.c_int
     lib.epropnp_last_error.restype = C.c_char_p
     lib.epropnp_noise_stride.argtypes = [C.c_int]
+    lib.epropnp_profile_enable.argtypes = [C.c_int]
+    lib.epropnp_profile_read.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     lib.epropnp_monte_carlo_forward.argtypes = [C.POINTER(Problem), C.POINTER(McParams)] + [vp] * 16
     lib.epropnp_evaluate_cost.argtypes = [C.POINTER(Problem), vp, i32, vp, vp]
     lib.epropnp_normal_equations.argtypes = [C.POINTER(Problem), vp, i32, vp, vp, vp, vp]
@@ -86,7 +88,8 @@ def _declare(lib):
     return lib
 
 
-EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 'epropnp_evaluate_cost',
+EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 'epropnp_profile_enable',
+           'epropnp_profile_reset', 'epropnp_profile_read', 'epropnp_evaluate_cost',
            'epropnp_normal_equations', 'epropnp_lm_solve', 'epropnp_amis_forward', 'epropnp_amis_backward',
            'epropnp_adaptive_delta', 'epropnp_mc_loss_forward', 'epropnp_mc_loss_backward', 'epropnp_rslm_draw',
            'epropnp_gn_step_forward', 'epropnp_gn_step_backward', 'epropnp_rslm_solve',
@@ -137,6 +140,22 @@ def stream_of(t):
     if _raw_stream is not None:
         return _raw_stream(cur)
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def profile(enable=None, reset=False):
+    """Per-stage HIP-event timing inside the library (epropnp_profile_*): switch it on / off, optionally dropping what was
+    recorded so far."""
+    if reset:
+        lib().epropnp_profile_reset()
+    if enable is not None:
+        lib().epropnp_profile_enable(int(bool(enable)))
+
+
+def profile_read(stage):
+    """(mean ms per launch, number of launches) of `stage` since the last reset; synchronises on the recorded events."""
+    ms, n = C.c_float(0), C.c_int32(0)
+    lib().epropnp_profile_read(stage.encode(), C.byref(ms), C.byref(n))
+    return (ms.value if n.value else float('nan')), n.value
 
 
 def call(fn_name, *args):

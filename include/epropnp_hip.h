@@ -122,6 +122,16 @@ int epropnp_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_pa
 int epropnp_abi_version(void);
 const char* epropnp_last_error(void);
 
+/* Optional per-stage timing: while enabled, every kernel stage this library launches -- also the ones inside
+ * epropnp_monte_carlo_forward -- is bracketed by two HIP events on its launch stream.  epropnp_profile_read synchronises
+ * on the recorded events of `stage` ("evaluate_cost", "normal_equations", "lm_solve", "rslm_solve", "amis_forward",
+ * "amis_backward", "adaptive_delta", "mc_loss_forward", "mc_loss_backward", "gn_step_forward", "gn_step_backward",
+ * "center_points", "shift_poses") and returns their mean duration and count; bench.py's per-kernel times and roofline
+ * figures come from here.  Not for use inside a hipGraph capture. */
+int epropnp_profile_enable(int on);
+int epropnp_profile_reset(void);
+int epropnp_profile_read(const char* stage, float* mean_ms, int32_t* count);
+
 /* Floats per (iteration, sample, object) of an injected-noise buffer for the given dof (8 for 6-DoF:
  * [z0,z1,z2, chi2, g0..g3]; 4 + 3*16 for 4-DoF: [z0,z1,z2, chi2, u | 16x(u1,u2,u3)]). */
 int epropnp_noise_stride(int dof);
