@@ -78,6 +78,32 @@ def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=(),
     return lib
 
 
+def build_torch_binding(force=False, verbose=False):
+    """csrc/torch_binding.cpp -> lib/_epropnp_torch.so: the C++ autograd nodes over the C ABI (host code only: g++ against
+    the torch headers, linked to libepropnp_hip.so through an $ORIGIN rpath so the pair travels together)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    out_dir = os.path.join(HERE, 'lib')
+    lib = os.path.join(out_dir, '_epropnp_torch.so')
+    src = os.path.join(CSRC, 'torch_binding.cpp')
+    hip_lib = os.path.join(out_dir, 'libepropnp_hip.so')
+    if not force and not _stale(lib, [src, os.path.join(ROOT, 'include', 'epropnp_hip.h'), hip_lib]):
+        return lib
+    cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-attributes', src, '-o', lib,
+           '-DTORCH_EXTENSION_NAME=_epropnp_torch', '-DTORCH_API_INCLUDE_EXTENSION_H',
+           f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}', '-I' + sysconfig.get_paths()['include']]
+    cmd += ['-isystem' + p for p in ce.include_paths()]
+    cmd += ['-L' + out_dir, '-lepropnp_hip', '-Wl,-rpath,$ORIGIN']
+    for d in ce.library_paths():
+        cmd += ['-L' + d, '-Wl,-rpath,' + d]
+    cmd += ['-lc10', '-ltorch_cpu', '-ltorch', '-ltorch_python']
+    out = _run(cmd)
+    if verbose and out.strip():
+        print(out)
+    return lib
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--emu', action='store_true')
@@ -90,3 +116,5 @@ if __name__ == '__main__':
     ap.add_argument('--offload-arch', default=None, help='GPU architecture (default gfx950 = MI355X, or $EPROPNP_OFFLOAD_ARCH)')
     a = ap.parse_args()
     print(build(a.emu, a.force, a.verbose, a.defines, a.tag, a.flags, a.file_flags, a.offload_arch))
+    if not a.emu and not a.tag:
+        print(build_torch_binding(a.force, a.verbose))

@@ -114,6 +114,28 @@ def lib():
     return _lib
 
 
+_torch_ext = False      # not tried yet
+
+
+def torch_ext():
+    """The C++ autograd nodes (lib/_epropnp_torch.so, csrc/torch_binding.cpp: same C ABI, no interpreter in the backward)
+    or None when the module was not built / EPROPNP_NO_TORCH_EXT is set / another library build is selected with
+    EPROPNP_LIB (the module is linked to the default one).  Either way the kernels are the library's."""
+    global _torch_ext
+    if _torch_ext is False:
+        _torch_ext = None
+        path = os.path.join(os.path.dirname(LIB_PATH), '_epropnp_torch.so')
+        if os.path.exists(path) and not os.environ.get('EPROPNP_NO_TORCH_EXT') and not os.environ.get('EPROPNP_LIB'):
+            import importlib.util
+            lib()                        # the HIP library first: a missing / mismatching build fails with a clear message
+            spec = importlib.util.spec_from_file_location('_epropnp_torch', path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() == ABI_VERSION and mod.mc_params_size() == C.sizeof(McParams):
+                _torch_ext = mod
+    return _torch_ext
+
+
 def check_device(t, name):
     if not t.is_cuda:
         raise RuntimeError(f'{name} must live on a HIP device (got {t.device}); the EPro-PnP HIP path has no CPU fallback')

@@ -407,8 +407,21 @@ class _FusedMonteCarlo(torch.autograd.Function):
 def fused_monte_carlo(x3d, x2d, w2d, delta, prob, pose_init, par, noise, with_cost):
     """-> pose_opt, pose_samples, logweights, cost | None, cost_init | None, and the solver frame: pose_opt_n,
     (x3d_centered, offset) | (None, None)"""
-    pose_opt_n, samples_n, logw, cost, cost_init, pose_opt, samples, x3d_c, offset = _FusedMonteCarlo.apply(
-        x3d, x2d, w2d, delta, prob, pose_init, par, noise, with_cost)
+    ext = _hip.torch_ext()
+    if ext is not None:      # C++ autograd node over the same entry point (csrc/torch_binding.cpp)
+        if noise is not None:
+            assert noise.shape == (prob.B, par.amis.num_iter, par.amis.mc_samples // par.amis.num_iter, noise_stride(prob.dof)), \
+                f'noise shape {tuple(noise.shape)}'
+            _f32c(noise, 'noise')
+        if pose_init is not None:
+            _f32c(pose_init, 'pose_init')
+        pose_opt_n, samples_n, logw, cost, cost_init, pose_opt, samples, x3d_c, offset = ext.fused_monte_carlo(
+            x3d, x2d, w2d, delta, prob.x3d, prob.x2d, prob.w2d, prob.cam, prob.lb, prob.ub, prob.delta, prob.status,
+            prob.z_min, prob.huber_eps, prob.dof, pose_init, noise, bytes(par), bool(with_cost),
+            backward_split(prob.B, prob.N, par.amis.mc_samples), int(prob.stream or 0))
+    else:
+        pose_opt_n, samples_n, logw, cost, cost_init, pose_opt, samples, x3d_c, offset = _FusedMonteCarlo.apply(
+            x3d, x2d, w2d, delta, prob, pose_init, par, noise, with_cost)
     if pose_opt is None:
         pose_opt, samples = pose_opt_n, samples_n
     return pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset
@@ -448,6 +461,10 @@ class _AdaptiveDelta(torch.autograd.Function):
 
 
 def adaptive_delta(x2d, w2d, relative_delta):
+    ext = _hip.torch_ext()
+    if ext is not None:
+        _f32c(x2d, 'x2d'), _f32c(w2d, 'w2d')
+        return ext.adaptive_delta(x2d, w2d, float(relative_delta), int(_hip.stream_of(x2d) or 0))
     return _AdaptiveDelta.apply(x2d, w2d, relative_delta)
 
 
@@ -481,6 +498,12 @@ class _McPoseLoss(torch.autograd.Function):
 
 
 def mc_pose_loss(logweights, cost_target):
+    ext = _hip.torch_ext()
+    if ext is not None:
+        _f32c(logweights, 'pose_sample_logweights')
+        if cost_target is not None:
+            _f32c(cost_target, 'cost_target')
+        return ext.mc_pose_loss(logweights, cost_target, int(_hip.stream_of(logweights) or 0))
     return _McPoseLoss.apply(logweights, cost_target)
 
 

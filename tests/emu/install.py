@@ -20,7 +20,7 @@ def install(path):
     from epropnp import _hip
     if _saved:
         uninstall()
-    for name in ('_lib', 'check_device', 'on_hip_path', 'stream_of'):
+    for name in ('_lib', 'check_device', 'on_hip_path', 'stream_of', 'torch_ext'):
         _saved[name] = getattr(_hip, name)
 
     def check_device(t, name):
@@ -32,6 +32,7 @@ def install(path):
 
     _hip._lib = _hip._declare(C.CDLL(path))
     _hip.check_device, _hip.on_hip_path, _hip.stream_of = check_device, on_hip_path, (lambda t: None)
+    _hip.torch_ext = lambda: None        # the C++ autograd nodes are linked to the HIP library: ctypes nodes under emulation
 
 
 def uninstall():
