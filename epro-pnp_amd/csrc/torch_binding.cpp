@@ -242,7 +242,119 @@ struct FusedMonteCarlo : public torch::autograd::Function<FusedMonteCarlo> {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// pose_opt_plus = pose (+) gn_step(pose)  (LMSolver.forward :70-72 -> gn_step :243-253 -> pose_add :255-265), with_plus
+// false: the bare step.  Differentiable w.r.t. x3d, x2d, w2d, delta (the pose is not differentiated, as in the reference).
+struct GnStep : public torch::autograd::Function<GnStep> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x3d, const Tensor& x2d, const Tensor& w2d, const OptTensor& delta,
+                        const Tensor& x3d_c, const Tensor& x2d_c, const Tensor& w2d_c, const Tensor& cam_c,
+                        const OptTensor& lb_c, const OptTensor& ub_c, const Tensor& delta_c, const OptTensor& status,
+                        double z_min, double huber_eps, int64_t dof, const Tensor& pose, double eps, bool with_plus,
+                        int64_t stream) {
+    (void)x3d; (void)x2d; (void)w2d;
+    ProblemTensors pt;
+    pt.x3d = x3d_c; pt.x2d = x2d_c; pt.w2d = w2d_c; pt.cam = cam_c; pt.delta = delta_c;
+    if (lb_c.has_value() && ub_c.has_value()) { pt.lb = *lb_c; pt.ub = *ub_c; }
+    if (status.has_value()) pt.status = *status;
+    pt.z_min = z_min; pt.huber_eps = huber_eps; pt.dof = dof;
+    const epropnp_problem prob = pt.c();
+    const Tensor ps = pose.detach().contiguous();
+    const int64_t B = prob.num_obj;
+    Tensor out = torch::empty({B, with_plus ? (dof == 6 ? 7 : 4) : dof}, x2d_c.options());
+    check(with_plus ? epropnp_pose_opt_plus_forward(&prob, (float)eps, fptr(ps), fptr(out), (void*)stream)
+                    : epropnp_gn_step_forward(&prob, (float)eps, fptr(ps), fptr(out), (void*)stream), "epropnp_gn_step_forward");
+    ctx->save_for_backward({ps});
+    ctx->saved_data["x3d"] = x3d_c; ctx->saved_data["x2d"] = x2d_c; ctx->saved_data["w2d"] = w2d_c;
+    ctx->saved_data["cam"] = cam_c; ctx->saved_data["delta"] = delta_c;
+    ctx->saved_data["lb"] = pt.lb.defined() ? c10::IValue(pt.lb) : c10::IValue();
+    ctx->saved_data["ub"] = pt.ub.defined() ? c10::IValue(pt.ub) : c10::IValue();
+    ctx->saved_data["z_min"] = z_min; ctx->saved_data["huber_eps"] = huber_eps; ctx->saved_data["dof"] = dof;
+    ctx->saved_data["eps"] = eps; ctx->saved_data["with_plus"] = with_plus; ctx->saved_data["stream"] = stream;
+    ctx->saved_data["delta_dim"] = (delta.has_value() && delta->defined()) ? (int64_t)delta->dim() : (int64_t)-1;
+    std::vector<int64_t> vers;
+    for (const Tensor* t : {&x3d_c, &x2d_c, &w2d_c, &delta_c, &cam_c}) vers.push_back((int64_t)t->_version());
+    ctx->saved_data["versions"] = vers;
+    ctx->set_materialize_grads(false);
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    variable_list out(19);
+    if (!grads[0].defined()) return out;
+    ProblemTensors pt;
+    pt.x3d = ctx->saved_data["x3d"].toTensor(); pt.x2d = ctx->saved_data["x2d"].toTensor();
+    pt.w2d = ctx->saved_data["w2d"].toTensor(); pt.cam = ctx->saved_data["cam"].toTensor();
+    pt.delta = ctx->saved_data["delta"].toTensor();
+    if (!ctx->saved_data["lb"].isNone()) { pt.lb = ctx->saved_data["lb"].toTensor(); pt.ub = ctx->saved_data["ub"].toTensor(); }
+    pt.z_min = ctx->saved_data["z_min"].toDouble(); pt.huber_eps = ctx->saved_data["huber_eps"].toDouble();
+    pt.dof = ctx->saved_data["dof"].toInt();
+    const auto vers = ctx->saved_data["versions"].toIntVector();
+    const Tensor* ts[5] = {&pt.x3d, &pt.x2d, &pt.w2d, &pt.delta, &pt.cam};
+    for (int i = 0; i < 5; ++i)
+      TORCH_CHECK((int64_t)ts[i]->_version() == vers[i],
+                  "one of the variables needed for gradient computation has been modified by an inplace operation "
+                  "(EPro-PnP recomputes its backward from x3d / x2d / w2d / delta / cam_mats: they must stay unchanged "
+                  "between forward and backward)");
+    const epropnp_problem q = pt.c();
+    const Tensor ps = ctx->get_saved_variables()[0], g = grads[0].contiguous();
+    const int64_t B = q.num_obj, N = q.num_pts;
+    const auto opt = ps.options();
+    Tensor gx3d = torch::empty({B, N, 3}, opt), gx2d = torch::empty({B, N, 2}, opt), gw2d = torch::empty({B, N, 2}, opt),
+           gdel = torch::empty({B}, opt);
+    const float eps = (float)ctx->saved_data["eps"].toDouble();
+    void* st = (void*)ctx->saved_data["stream"].toInt();
+    check(ctx->saved_data["with_plus"].toBool()
+              ? epropnp_pose_opt_plus_backward(&q, eps, fptr(ps), fptr(g), fptr(gx3d), fptr(gx2d), fptr(gw2d), fptr(gdel), st)
+              : epropnp_gn_step_backward(&q, eps, fptr(ps), fptr(g), fptr(gx3d), fptr(gx2d), fptr(gw2d), fptr(gdel), st),
+          "epropnp_gn_step_backward");
+    if (ctx->needs_input_grad(0)) out[0] = gx3d;
+    if (ctx->needs_input_grad(1)) out[1] = gx2d;
+    if (ctx->needs_input_grad(2)) out[2] = gw2d;
+    const int64_t ddim = ctx->saved_data["delta_dim"].toInt();
+    if (ddim >= 0 && ctx->needs_input_grad(3)) out[3] = (ddim == 0) ? gdel.sum() : gdel;
+    return out;
+  }
+};
+
+// pose translation += sign * R(pose) offset (pnp_normalize / pnp_denormalize, common.py:118-136); differentiable w.r.t. pose
+struct ShiftPoses : public torch::autograd::Function<ShiftPoses> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& pose, const Tensor& offset, double sign, int64_t stream) {
+    const Tensor ps = pose.detach().contiguous(), off = offset.detach().contiguous();
+    const int64_t B = ps.size(-2), PL = ps.size(-1), P = ps.numel() / (B * PL);
+    Tensor out = torch::empty_like(ps);
+    check(epropnp_shift_poses(fptr(ps), fptr(off), (int32_t)P, (int32_t)B, PL == 7 ? 6 : 4, (float)sign, fptr(out),
+                              (void*)stream), "epropnp_shift_poses");
+    ctx->save_for_backward({ps, off});
+    ctx->saved_data["sign"] = sign; ctx->saved_data["stream"] = stream;
+    ctx->set_materialize_grads(false);
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    if (!grads[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor()};
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &ps = saved[0], &off = saved[1];
+    const Tensor g = grads[0].contiguous();
+    const int64_t B = ps.size(-2), PL = ps.size(-1), P = ps.numel() / (B * PL);
+    Tensor gp = torch::empty_like(ps);
+    check(epropnp_shift_poses_backward(fptr(ps), fptr(off), fptr(g), (int32_t)P, (int32_t)B, PL == 7 ? 6 : 4,
+                                       (float)ctx->saved_data["sign"].toDouble(), fptr(gp),
+                                       (void*)ctx->saved_data["stream"].toInt()), "epropnp_shift_poses_backward");
+    return {gp, Tensor(), Tensor(), Tensor()};
+  }
+};
+
 // ---- Python-facing wrappers ------------------------------------------------------------------------------------------
+Tensor gn_step(const Tensor& x3d, const Tensor& x2d, const Tensor& w2d, const OptTensor& delta, const Tensor& x3d_c,
+               const Tensor& x2d_c, const Tensor& w2d_c, const Tensor& cam_c, const OptTensor& lb_c, const OptTensor& ub_c,
+               const Tensor& delta_c, const OptTensor& status, double z_min, double huber_eps, int64_t dof, const Tensor& pose,
+               double eps, bool with_plus, int64_t stream) {
+  return GnStep::apply(x3d, x2d, w2d, delta, x3d_c, x2d_c, w2d_c, cam_c, lb_c, ub_c, delta_c, status, z_min, huber_eps, dof, pose,
+                       eps, with_plus, stream);
+}
+
+Tensor shift_poses(const Tensor& pose, const Tensor& offset, double sign, int64_t stream) {
+  return ShiftPoses::apply(pose, offset, sign, stream);
+}
+
 Tensor adaptive_delta(const Tensor& x2d, const Tensor& w2d, double rel, int64_t stream) {
   return AdaptiveDelta::apply(x2d, w2d, rel, stream);
 }
@@ -274,4 +386,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("adaptive_delta", &adaptive_delta);
   m.def("mc_pose_loss", &mc_pose_loss);
   m.def("fused_monte_carlo", &fused_monte_carlo);
+  m.def("gn_step", &gn_step);
+  m.def("shift_poses", &shift_poses);
 }

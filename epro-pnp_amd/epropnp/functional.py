@@ -570,6 +570,10 @@ class _ShiftPoses(torch.autograd.Function):
 def shift_poses(pose, offset, sign):
     """pose (...,B,pose_len) translation += sign * R(pose) offset (B,3); differentiable w.r.t. the pose."""
     if pose.requires_grad and torch.is_grad_enabled():
+        ext = _hip.torch_ext()
+        if ext is not None:
+            _f32c(pose, 'pose'), _f32c(offset, 'offset')
+            return ext.shift_poses(pose, offset, float(sign), int(_hip.stream_of(pose) or 0))
         return _ShiftPoses.apply(pose, offset, sign)
     ps, off = _f32c(pose.detach(), 'pose'), _f32c(offset.detach(), 'offset')
     B, pl = ps.shape[-2], ps.shape[-1]
@@ -638,7 +642,16 @@ class _GnStep(torch.autograd.Function):
                 gw2d if ctx.needs_input_grad[2] else None, gdelta, None, None, None)
 
 
+def _ext_gn_step(ext, x3d, x2d, w2d, delta, prob, pose, eps, with_plus):
+    _f32c(pose, 'pose')
+    return ext.gn_step(x3d, x2d, w2d, delta, prob.x3d, prob.x2d, prob.w2d, prob.cam, prob.lb, prob.ub, prob.delta, prob.status,
+                       prob.z_min, prob.huber_eps, prob.dof, pose, float(eps), with_plus, int(prob.stream or 0))
+
+
 def gn_step(x3d, x2d, w2d, delta, prob, pose, eps):
+    ext = _hip.torch_ext()
+    if ext is not None:
+        return _ext_gn_step(ext, x3d, x2d, w2d, delta, prob, pose, eps, False)
     return _GnStep.apply(x3d, x2d, w2d, delta, prob, pose, eps)
 
 
@@ -678,4 +691,7 @@ class _PoseOptPlus(torch.autograd.Function):
 
 
 def pose_opt_plus(x3d, x2d, w2d, delta, prob, pose, eps):
+    ext = _hip.torch_ext()
+    if ext is not None:
+        return _ext_gn_step(ext, x3d, x2d, w2d, delta, prob, pose, eps, True)
     return _PoseOptPlus.apply(x3d, x2d, w2d, delta, prob, pose, eps)
