@@ -85,3 +85,49 @@ def test_shapes_outside_the_fused_kernel_fall_back(backend):
         F.rslm_solve(prob, 4, 16, 2)            # N = 600 > 512
     with pytest.raises(RuntimeError):
         F.rslm_solve(F.PnPProblem(d['x3d'][:, :64], d['x2d'][:, :64], d['w2d'][:, :64], cam, cf, 6), 4, 17, 2)
+
+
+@pytest.mark.parametrize('dof,N,P,n,bounds', [(4, 128, 64, 16, 'tensor'), (6, 96, 16, 16, None), (6, 200, 24, 8, 'tight')])
+def test_fused_rslm_matches_oracle_on_injected_draws(backend, dof, N, P, n, bounds):
+    """The one-launch initialiser against the ORACLE's restatement of RSLMSolver.solve (levenberg_marquardt.py:283-353,
+    pinned to the reference by the fixtures mc6_demo / mc4_rslm / mc4_det) on the same injected sub-sample indices and
+    initial rotations: the minimum full-set cost agrees; the winning pose agrees wherever the oracle's best and
+    second-best proposals are not tied to rounding."""
+    from epropnp import functional as F
+    B, L = 10, 3
+    prob = orc.make_problem(B, N, dof, seed=70 + N, bounds=bounds)
+    rn = orc.make_rslm_noise(prob, dof, n, P, seed=71)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose, cost = F.rslm_solve(hp, P, n, L, inds=rn['inds'].to(backend), rot=rn['rot'].float().to(backend))
+    ocam = orc.Cam(prob['cam_mats'], 0.1, prob.get('lb'), prob.get('ub'))
+    o_pose, o_cost = orc.rslm_solve(prob['x3d'], prob['x2d'], prob['w2d'], ocam, prob['delta'], rn['inds'], rn['rot'].float(), dof,
+                                    num_iter=L)
+    torch.testing.assert_close(cost.cpu(), o_cost, rtol=5e-4, atol=1e-5)
+    same = (pose.cpu() - o_pose).abs().max(-1).values < 1e-3
+    assert int(same.sum()) >= B - 1, (pose.cpu() - o_pose).abs().max(-1).values
+
+
+def test_rslm_draw_inclusion_probabilities_match_multinomial(backend):
+    """The whole draw, not just its first pick: the probability that point i is among the n indices of a row equals that of
+    torch.multinomial(weights, n, replacement=False) -- the reference's sampler (levenberg_marquardt.py:305-308) -- for
+    very unequal weights, where sequential sampling without replacement differs most from independent draws."""
+    from epropnp import functional as F
+    B, N, n = 2, 12, 5
+    P = 40000 if backend.type == 'cuda' else 2500
+    w = torch.tensor([[8., 4, 2, 1, 1, 1, .5, .5, .25, .25, .1, 0.], [1.] * 6 + [3.] * 6]).unsqueeze(-1).expand(B, N, 2).contiguous()
+    inds = F.rslm_draw(w.to(backend), P, n, seed=17, offset=2).cpu()                     # (P,B,n)
+    g = torch.Generator().manual_seed(0)
+    M = 400000
+    for b in range(B):
+        ref = torch.multinomial(w[b, :, 0].expand(M, N), n, replacement=False, generator=g)
+        p_ref = torch.bincount(ref.flatten(), minlength=N).double() / M
+        p_got = torch.bincount(inds[:, b].flatten(), minlength=N).double() / P
+        sigma = (p_ref * (1 - p_ref) / P).sqrt()
+        assert ((p_got - p_ref).abs() <= 5 * sigma + 3.0 / P).all(), (p_got, p_ref)
+        # and the order statistics of the sequential draw: P(first pick = i, second pick = j) for the two heaviest points
+        i, j = (0, 1) if b == 0 else (6, 7)
+        pij_ref = ((ref[:, 0] == i) & (ref[:, 1] == j)).double().mean()
+        pij_got = ((inds[:, b, 0] == i) & (inds[:, b, 1] == j)).double().mean()
+        assert abs(pij_got - pij_ref) <= 5 * (pij_ref * (1 - pij_ref) / P).sqrt() + 3.0 / P
+    assert not (inds[:, 0] == 11).any()                                                  # zero weight: never drawn
