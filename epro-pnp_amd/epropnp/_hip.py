@@ -128,11 +128,15 @@ def torch_ext():
         if os.path.exists(path) and not os.environ.get('EPROPNP_NO_TORCH_EXT') and not os.environ.get('EPROPNP_LIB'):
             import importlib.util
             lib()                        # the HIP library first: a missing / mismatching build fails with a clear message
-            spec = importlib.util.spec_from_file_location('_epropnp_torch', path)
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            if mod.abi_version() == ABI_VERSION and mod.mc_params_size() == C.sizeof(McParams):
-                _torch_ext = mod
+            try:
+                spec = importlib.util.spec_from_file_location('_epropnp_torch', path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                if mod.abi_version() == ABI_VERSION and mod.mc_params_size() == C.sizeof(McParams):
+                    _torch_ext = mod
+            except (ImportError, OSError) as e:      # built against another torch: same kernels through the ctypes nodes
+                import warnings
+                warnings.warn(f'{path} could not be loaded ({e}); using the ctypes binding of the same library')
     return _torch_ext
 
 
