@@ -1,16 +1,16 @@
 #!/usr/bin/env python
-"""BUILD CONTAINER ONLY (needs /root/reference): the UNMODIFIED reference (oracle/ref_runner.py) and the oracle
+"""TEST INFRASTRUCTURE, BUILD CONTAINER ONLY (needs /root/reference): the UNMODIFIED reference (oracle/ref_runner.py) and the oracle
 restatement (oracle/epropnp_oracle.py) timed side by side on the sample bench.py's `cpu_baseline` leg uses -- 64 objects
 of the C2 workload (N=512, S=512, K=4, L=3), monte_carlo_forward + MC loss + backward, same injected noise.
-Shows that `cpu_baseline.kind: "port"` costs what the reference costs.  -> profiles/r02_cpu_reference_vs_oracle.txt"""
+Shows that `cpu_baseline.kind: "port"` costs what the reference costs.  -> profiles/r02_cpu_reference_vs_oracle.txt
+    python oracle/time_reference_vs_oracle.py"""
 import os
 import sys
 import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, 'oracle')]
+sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
 import epropnp_oracle as orc  # noqa: E402
 import ref_runner as ref  # noqa: E402
 

@@ -10,9 +10,24 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'epro-pnp_amd'))
-sys.path.insert(0, os.path.join(ROOT, 'oracle'))      # the PyTorch composite being compared against is test infrastructure
 from epropnp.preprocess import box_grid_params, prepare_dense_correspondences  # noqa: E402
-from preprocess_oracle import prepare_dense_ref as _reference_dense  # noqa: E402
+
+
+def _reference_dense(noc_map, dim, logit_map, scale, box, inds, mode):
+    """The PyTorch composite the fused op replaces, as a caller would write it (EPro-PnP-6DoF/lib/train.py:141-166):
+    meshgrid, flatten / transpose / index gathers, mean-normalised exp.  Timing comparator only."""
+    import math
+    B, _, H, W = logit_map.shape
+    ar_w = torch.arange(W, device=logit_map.device, dtype=torch.float32)
+    ar_h = torch.arange(H, device=logit_map.device, dtype=torch.float32)
+    y, x = torch.meshgrid(ar_h, ar_w, indexing='ij')
+    x2d = torch.stack((box[:, 0, None, None] + x * box[:, 2, None, None], box[:, 1, None, None] + y * box[:, 2, None, None]), dim=1)
+    bi = torch.arange(B, device=logit_map.device)[:, None]
+    pick = lambda m: m.flatten(2).transpose(-1, -2)[bi, inds]
+    x3d = pick(noc_map * dim[..., None, None])
+    lg = pick(logit_map)
+    w = (lg - lg.mean(dim=-2, keepdim=True) - math.log(lg.size(-2))).exp() if mode == 'mean_exp' else lg.softmax(dim=-2)
+    return x3d, pick(x2d), w * scale.unsqueeze(-2)
 
 
 def main():
