@@ -58,14 +58,20 @@ __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
 }
 #endif
 
+// max(x, lo) for lo >= 0 as ONE v_max_i32 on the bit patterns: non-negative floats order like their bits and every
+// negative x (sign bit set) is a negative integer, so it yields lo (check_problem rejects z_min < 0).  fmaxf on an MFMA
+// result is expanded to a canonicalising v_max(x, x) plus the max (IEEE mode).  It has to be an instruction the compiler
+// can see: the hazard recogniser pads MFMA -> VALU reads with s_nop, which it cannot do around inline asm -- a
+// hand-written v_max_f32 here happened to work behind v_mfma_f32_16x16x4_f32 and read stale registers behind the
+// shorter v_mfma_f32_16x16x32_bf16 (profiles/r02_tune_fwd_bf16_split.txt).
 __device__ __forceinline__ float clamp_below(float x, float lo) {
-#ifndef EPROPNP_EMU
-  float r;      // the builtin max is expanded to a canonicalising v_max(x, x) + v_max: emit the single instruction
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo));
+  int xi, li;
+  memcpy(&xi, &x, 4);
+  memcpy(&li, &lo, 4);
+  const int mi = max(xi, li);
+  float r;
+  memcpy(&r, &mi, 4);
   return r;
-#else
-  return (x > lo) ? x : lo;
-#endif
 }
 
 // Huber costs of the 4 poses a lane holds for one point (MFMA outputs hx, hy, hz) added to acc2 = {poses 0,1}, {2,3}
@@ -79,8 +85,7 @@ __device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& h
   const f32x2 mhalf = {-0.5f, -0.5f};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    // z = max(h_z, z_min) as ONE v_max_f32: fmaxf on an MFMA result is expanded to a canonicalising v_max(x, x)
-    // plus the max (IEEE mode), and compare+select measured 3.4 ns per pair against 1.8 ns (tools/ubench)
+    // z = max(h_z, z_min) as one instruction (compare+select measured 3.4 ns per pair against 1.8 ns, tools/ubench)
     const float z0 = clamp_below(hz[2 * h], zmin_v), z1 = clamp_below(hz[2 * h + 1], zmin_v);
     const f32x2 rz2 = {fast_rcp(z0), fast_rcp(z1)};
     const f32x2 hx2 = {hx[2 * h], hx[2 * h + 1]}, hy2 = {hy[2 * h], hy[2 * h + 1]};

@@ -33,6 +33,7 @@ inline int check_problem(const epropnp_problem* p) {
   if (p->num_obj > 0 && p->num_pts > 0 &&
       (!p->x3d || !p->x2d || !p->w2d || !p->cam_mats || !p->delta))
     return fail(EPROPNP_EINVAL, "NULL device pointer in problem");
+  if (!(p->z_min >= 0.f)) return fail(EPROPNP_EINVAL, "z_min must be >= 0 (a depth clamp), got %g", (double)p->z_min);
   return EPROPNP_OK;
 }
 

@@ -98,6 +98,8 @@ class PnPProblem:
         self.device = dev
         self.huber_eps = float(getattr(cost_fun, 'eps', 1e-10))
         self.z_min = float(camera.z_min)
+        if not self.z_min >= 0.0:
+            raise ValueError(f'camera.z_min must be >= 0 (a depth clamp), got {self.z_min}')
         # contiguous (B,3,3) intrinsics and (B,2) bounds: callers pass an expanded view of one matrix / plain floats, and
         # a step builds several PnPProblems from the same camera object -- materialise them once per camera state
         srcs = (camera.cam_mats, camera.lb, camera.ub)

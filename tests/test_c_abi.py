@@ -51,6 +51,20 @@ def test_argument_validation_without_launch(lib):
     prob = _hip.Problem(None, None, None, None, None, None, None, 0.1, 4, 16, 6)
     rc = lib.epropnp_evaluate_cost(ctypes.byref(prob), None, 1, None, None)
     assert rc == -1 and b'NULL' in lib.epropnp_last_error()
+    # z_min is a depth clamp: the forward sweep's one-instruction max(z, z_min) relies on z_min >= 0
+    prob = _hip.Problem(None, None, None, None, None, None, None, -0.1, 0, 16, 6)
+    rc = lib.epropnp_evaluate_cost(ctypes.byref(prob), None, 1, None, None)
+    assert rc == -1 and b'z_min' in lib.epropnp_last_error()
+
+
+def test_negative_z_min_is_refused_by_the_python_layer(backend):
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import HuberPnPCost
+    z = lambda *s: torch.zeros(*s, device=backend)
+    cam = PerspectiveCamera(cam_mats=torch.eye(3, device=backend).expand(2, 3, 3), z_min=-0.1)
+    with pytest.raises(ValueError, match='z_min'):
+        F.PnPProblem(z(2, 8, 3), z(2, 8, 2), z(2, 8, 2), cam, HuberPnPCost(delta=1.0), 6)
 
 
 def test_product_path_refuses_cpu_tensors():
