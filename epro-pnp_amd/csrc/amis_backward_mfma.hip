@@ -61,7 +61,11 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   float Kc[9], delta;
   Bounds bd;
   load_camera<BOUNDS>(p, b, Kc, bd, delta);
-  const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
+  // Residuals in units of delta (weights pre-multiplied by 1 / delta, huber_scale): min(rho, delta) becomes the clamp
+  // modifier of a full-rate multiply (sat_mul); the Huber weight `coef` is unchanged, the accumulators come out scaled
+  // by 1 / delta (A1, d/d delta) or 1 / delta^2 (A2, the back-projection) and are rescaled once per point at the end.
+  const HuberScale hs = huber_scale(delta);
+  const float zmin_v = to_vgpr(p.z_min), one_v = to_vgpr(1.0f);
 #ifndef PNP_BWD_NO_FOLD
   const float tiny_v = to_vgpr(1e-30f);     // keeps rsq finite at a zero residual; folded into the norm's first fma
 #endif
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
     for (int i = 0; i < NPT; ++i) {
       const Point q = load_point(p, b, c0 + (wv + W * i) * 16 + col);      // zero weight beyond N
       rB[i] = (kk == 0) ? q.X : (kk == 1) ? q.Y : (kk == 2) ? q.Z : 1.0f;
-      rW[i] = make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
+      const float wu = q.wu * hs.inv_delta, wv = q.wv * hs.inv_delta;
+      rW[i] = make_float4(wu, wv, -q.u * wu, -q.v * wv);
       A1x[i] = A1y[i] = A2x[i] = A2y[i] = 0.f;
       gXv[i] = gYv[i] = gZv[i] = 0.f;
     }
@@ -183,9 +188,9 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
           const float rs = fast_rsqrt(fmaxf(s2, 1e-30f));
 #endif
           const float rho = s2 * rs;
-          const float mm = fminf(rho, delta_v);
+          const float mm = sat_mul(rho, one_v);                // min(rho, delta) / delta
           const float coef = aw[r] * mm * rs;                  // a * min(1, delta / rho)
-          gd = fmaf(aw[r], rho - mm, gd);                      // d huber / d delta = max(rho - delta, 0)
+          gd = fmaf(aw[r], rho - mm, gd);                      // d huber / d delta = max(rho - delta, 0)   (/ delta)
           const float crx = coef * rx, cry = coef * ry;
           // d/dw = crx * (px - u) = crx * rx / w and d/du = -crx * w: the per-point factors are applied once at the end
           A2x[i] = fmaf(crx, rx, A2x[i]);
@@ -210,15 +215,15 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       bwd_floatx4 D1 = zero;
-      D1 = bwd_mfma(gXv[i], ind0, D1);
-      D1 = bwd_mfma(gYv[i], ind1, D1);
-      D1 = bwd_mfma(gZv[i], ind2, D1);
+      D1 = bwd_mfma(gXv[i] * hs.delta_sq, ind0, D1);
+      D1 = bwd_mfma(gYv[i] * hs.delta_sq, ind1, D1);
+      D1 = bwd_mfma(gZv[i] * hs.delta_sq, ind2, D1);
       const float4 w4 = rW[i];
       bwd_floatx4 D2 = zero;
-      D2 = bwd_mfma(-w4.x * A1x[i], ind0, D2);                               // d/du
-      D2 = bwd_mfma(-w4.y * A1y[i], ind1, D2);                               // d/dv
-      D2 = bwd_mfma((w4.x != 0.f) ? A2x[i] / w4.x : 0.f, ind2, D2);          // d/dwu
-      D2 = bwd_mfma((w4.y != 0.f) ? A2y[i] / w4.y : 0.f, ind3, D2);          // d/dwv
+      D2 = bwd_mfma(-w4.x * A1x[i] * hs.delta_sq, ind0, D2);                            // d/du
+      D2 = bwd_mfma(-w4.y * A1y[i] * hs.delta_sq, ind1, D2);                            // d/dv
+      D2 = bwd_mfma((w4.x != 0.f) ? A2x[i] * hs.delta / w4.x : 0.f, ind2, D2);          // d/dwu
+      D2 = bwd_mfma((w4.y != 0.f) ? A2y[i] * hs.delta / w4.y : 0.f, ind3, D2);          // d/dwv
       const int nb = c0 + (wv + W * i) * 16 + g4;     // D rows: points nb + r; column = lane & 15
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
       }
     }
   }
-  float one[1] = {gd};
+  float one[1] = {gd * hs.delta};
   block_sum<1>(one, red);
   if (tid == 0) gdelta[v] = one[0];
 }

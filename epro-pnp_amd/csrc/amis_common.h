@@ -10,6 +10,30 @@ namespace pnp {
 #define PNP_SWEEP_PIPELINE 0
 #endif
 
+// min(x, 1) for x >= 0 through the clamp output modifier of a multiply by an opaque 1.0 (v_mul_f32 ... clamp, a full-rate
+// instruction; v_min_f32 issues at half that rate on gfx950, tools/ubench)
+__device__ __forceinline__ float sat_mul(float x, float one_v) {
+#if defined(PNP_FWD_NO_SAT)
+  return fminf(x, one_v);
+#elif !defined(EPROPNP_EMU)
+  return __builtin_amdgcn_fmed3f(x * one_v, 0.0f, 1.0f);
+#else
+  const float y = x * one_v;
+  return (y != y) ? 0.0f : fminf(fmaxf(y, 0.0f), 1.0f);       // dx10_clamp: NaN -> 0
+#endif
+}
+
+// Residuals in units of the object's Huber threshold: the weights are pre-multiplied by 1 / delta, capped so that a zero or
+// denormal threshold stays finite (min(rho, delta) is then min(rho, 1e-15): below the resolution of any sum it enters).
+struct HuberScale { float inv_delta, delta, delta_sq; };
+__device__ __forceinline__ HuberScale huber_scale(float delta) {
+  HuberScale h;
+  h.inv_delta = fminf(1.0f / delta, 1e15f);
+  h.delta = (h.inv_delta < 1e15f) ? delta : 1e-15f;
+  h.delta_sq = h.delta * h.delta;
+  return h;
+}
+
 constexpr int kPropStride = 40;   // floats per fitted proposal (layout below)
 // proposal record:  [0..2] t-mode | [3..8] L_t (lower, row-major packed) | [9..14] L_t^-1 | [15] Student-t log-norm
 //   6-DoF: [16..25] L_r (lower 4x4 packed) | [26..35] L_r^-1 | [36] sum log diag L_r

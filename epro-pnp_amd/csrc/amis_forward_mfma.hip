@@ -75,11 +75,14 @@ __device__ __forceinline__ float clamp_below(float x, float lo) {
 }
 
 // Huber costs of the 4 poses a lane holds for one point (MFMA outputs hx, hy, hz) added to acc2 = {poses 0,1}, {2,3}
+// The weights in w4 (and those folded into hx, hy) are pre-divided by the object's Huber threshold delta, so the
+// residual norm rho is in units of delta, huber / delta^2 = m (rho - m / 2) with m = min(rho, 1), and the caller scales
+// the pose's sum by delta^2 once.
 // FOLDED: hx, hy are the MFMA results against the point's B operand pre-scaled by wu / wv (register mode without a
 // projection clamp), so the residual is ONE fma per coordinate: r = (wu h_x) / z - u wu.
 template <bool BOUNDS, bool FOLDED = false>
 __device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& hy, const floatx4& hz, const float4& w4,
-                                             float zmin_v, float delta_v, const Bounds& bd, f32x2 (&acc2)[2]) {
+                                             float zmin_v, float one_v, const Bounds& bd, f32x2 (&acc2)[2]) {
   static_assert(!(BOUNDS && FOLDED), "the clamp acts on the un-weighted projection");
   const f32x2 wu2 = {w4.x, w4.x}, wv2 = {w4.y, w4.y}, cu2 = {w4.z, w4.z}, cv2 = {w4.w, w4.w};
   const f32x2 mhalf = {-0.5f, -0.5f};
@@ -104,8 +107,8 @@ __device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& h
     }
     const f32x2 s2 = fma2(rx2, rx2, ry2 * ry2);
     const f32x2 rho2 = {fast_sqrt(s2[0]), fast_sqrt(s2[1])};
-    const f32x2 m2 = {fminf(rho2[0], delta_v), fminf(rho2[1], delta_v)};
-    acc2[h] = fma2(m2, fma2(mhalf, m2, rho2), acc2[h]);       // huber = m (rho - m / 2), m = min(rho, delta)
+    const f32x2 m2 = {sat_mul(rho2[0], one_v), sat_mul(rho2[1], one_v)};
+    acc2[h] = fma2(m2, fma2(mhalf, m2, rho2), acc2[h]);       // huber / delta^2 = m (rho - m / 2), m = min(rho, 1)
   }
 }
 
@@ -162,7 +165,10 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   float Kc[9], delta;
   Bounds bd;
   load_camera<BOUNDS>(p, b, Kc, bd, delta);
-  const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
+  const float zmin_v = to_vgpr(p.z_min), one_v = to_vgpr(1.0f);
+  // residuals in units of delta (huber_cost_4, huber_scale)
+  const HuberScale hs = huber_scale(delta);
+  const float inv_delta = hs.inv_delta, delta_sq = hs.delta_sq;
 
   AmisCtx cx;
   cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
@@ -177,7 +183,8 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
     for (int n = tid; n < cnt; n += T) {
       const Point q = load_point(p, b, c0 + n);          // zero weight beyond N
       reinterpret_cast<float4*>(pB)[n] = make_float4(q.X, q.Y, q.Z, 1.0f);
-      reinterpret_cast<float4*>(pW)[n] = make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
+      const float wu = q.wu * inv_delta, wv = q.wv * inv_delta;
+      reinterpret_cast<float4*>(pW)[n] = make_float4(wu, wv, -q.u * wu, -q.v * wv);
     }
   };
   // register mode: this wave's point tiles q = wv + W * i, lane = (point column, k)
@@ -190,8 +197,8 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
       const int k4 = lane >> 4;
       rB[i] = (k4 == 0) ? q.X : (k4 == 1) ? q.Y : (k4 == 2) ? q.Z : 1.0f;
       // without a projection clamp the weights are folded into the B operands of the x and y rows (same 5 VGPRs)
-      rW[i] = kFold ? make_float4(rB[i] * q.wu, rB[i] * q.wv, -q.u * q.wu, -q.v * q.wv)
-                    : make_float4(q.wu, q.wv, -q.u * q.wu, -q.v * q.wv);
+      const float wu = q.wu * inv_delta, wv = q.wv * inv_delta;
+      rW[i] = kFold ? make_float4(rB[i] * wu, rB[i] * wv, -q.u * wu, -q.v * wv) : make_float4(wu, wv, -q.u * wu, -q.v * wv);
     }
   } else if (nchunk == 1) {
     load_chunk(0);
@@ -213,6 +220,8 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
     } else
 #endif
     if (kRegs) {
+      // (issuing the next pose tile's first MFMAs ahead of the current tile's VALU work, to fill the wait states at the
+      // head of this loop, was measured: 0.655 vs 0.641 ms at C2 -- the hand-off copies cost more than the s_nops)
       const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
       for (int t = 0; t < (s16 >> 4); ++t) {
         const float* arow = ptab + 12 * (t * 16 + col) + kk;
@@ -223,14 +232,14 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
           const floatx4 hx = mfma_16x16x4(ax, kFold ? rW[i].x : rB[i], zero);
           const floatx4 hy = mfma_16x16x4(ay, kFold ? rW[i].y : rB[i], zero);
           const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
-          huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, delta_v, bd, acc2);
+          huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, one_v, bd, acc2);
         }
         float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
         if (col == 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) cpart[wv * s16 + t * 16 + g4 + r] = acc[r];
+          for (int r = 0; r < 4; ++r) cpart[wv * s16 + t * 16 + g4 + r] = acc[r] * delta_sq;
         }
       }
     } else
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
           const floatx4 hxn = mfma_16x16x4(ax, bn, zero);
           const floatx4 hyn = mfma_16x16x4(ay, bn, zero);
           const floatx4 hzn = mfma_16x16x4(az, bn, zero);
-          huber_cost_4<BOUNDS>(hx, hy, hz, w4, zmin_v, delta_v, bd, acc2);
+          huber_cost_4<BOUNDS>(hx, hy, hz, w4, zmin_v, one_v, bd, acc2);
           hx = hxn; hy = hyn; hz = hzn; w4 = wn;
         }
         float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int pose = t * 16 + g4 + r;
-            cpart[pose] = (ch == 0) ? acc[r] : cpart[pose] + acc[r];
+            cpart[pose] = (ch == 0) ? acc[r] * delta_sq : fmaf(acc[r], delta_sq, cpart[pose]);
           }
         }
       }

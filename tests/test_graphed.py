@@ -68,7 +68,10 @@ def _graphed_body():
         torch.testing.assert_close(pose_opt, pose_e, rtol=0, atol=0)
         torch.testing.assert_close(loss, loss_e.detach(), rtol=1e-6, atol=1e-7)
         for a, b in zip(new, ref):
-            torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-8)
+            # the replay runs the captured backward at upstream 1 and scales the result; eager carries `scale` through
+            # the kernels: same arithmetic, different rounding, so elements that are sums of cancelling per-sample terms
+            # agree norm-wise (a few fp32 ulps of the largest entry), not element-relative
+            torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=2e-6 * float(b.grad.abs().max()))
         assert not pose_opt.requires_grad and not samples.requires_grad
     stale, _, _ = graphed(*new, d['pose_init'])
     graphed(*new, d['pose_init'])
