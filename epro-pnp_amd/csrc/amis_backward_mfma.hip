@@ -66,6 +66,10 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   // by 1 / delta (A1, d/d delta) or 1 / delta^2 (A2, the back-projection) and are rescaled once per point at the end.
   const HuberScale hs = huber_scale(delta);
   const float zmin_v = to_vgpr(p.z_min), one_v = to_vgpr(1.0f);
+  // "in front of the depth clamp" as a 0/1 factor from ONE full-rate instruction: clamp((h_z - z_lo) * 2^60, 0, 1) with z_lo
+  // the float just below z_min is 1 exactly when h_z >= z_min (compare + two selects issue at half rate, tools/ubench)
+  const float front_scale = to_vgpr(0x1p60f);
+  const float front_off = to_vgpr(-nextafterf(p.z_min, -1.0f) * 0x1p60f);
 #ifndef PNP_BWD_NO_FOLD
   const float tiny_v = to_vgpr(1e-30f);     // keeps rsq finite at a zero residual; folded into the norm's first fma
 #endif
@@ -170,8 +174,14 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
         const float4 w4 = rW[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool front = hz[r] >= zmin_v;
-          const float zc = front ? hz[r] : zmin_v;
+#ifdef PNP_BWD_SELECT_FRONT
+          const bool frontb = hz[r] >= zmin_v;
+          const float front = frontb ? 1.f : 0.f;
+          const float zc = frontb ? hz[r] : zmin_v;
+#else
+          const float front = sat_fma(hz[r], front_scale, front_off);
+          const float zc = clamp_below(hz[r], zmin_v);
+#endif
           const float rz = fast_rcp(zc);
           const float ppx = hx[r] * rz, ppy = hy[r] * rz;          // un-clamped projection
           float px = ppx, py = ppy;
@@ -203,8 +213,11 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
             gpy = (ppy < bd.lby || ppy > bd.uby) ? 0.f : gpy;
           }
           const float ghx = gpx * rz, ghy = gpy * rz;
-          float ghz = fmaf(-ghx, ppx, -(ghy * ppy));
-          ghz = front ? ghz : 0.f;
+#ifdef PNP_BWD_SELECT_FRONT
+          const float ghz = frontb ? fmaf(-ghx, ppx, -(ghy * ppy)) : 0.f;
+#else
+          const float ghz = fmaf(-ghx, ppx, -(ghy * ppy)) * front;
+#endif
           gXv[i] = fmaf(krx[r].x, ghx, fmaf(kry[r].x, ghy, fmaf(krz[r].x, ghz, gXv[i])));
           gYv[i] = fmaf(krx[r].y, ghx, fmaf(kry[r].y, ghy, fmaf(krz[r].y, ghz, gYv[i])));
           gZv[i] = fmaf(krx[r].z, ghx, fmaf(kry[r].z, ghy, fmaf(krz[r].z, ghz, gZv[i])));

@@ -23,6 +23,32 @@ __device__ __forceinline__ float sat_mul(float x, float one_v) {
 #endif
 }
 
+// clamp(a * b + c, 0, 1) as one v_fma_f32 ... clamp
+__device__ __forceinline__ float sat_fma(float a, float b, float c) {
+#ifndef EPROPNP_EMU
+  return __builtin_amdgcn_fmed3f(fmaf(a, b, c), 0.0f, 1.0f);
+#else
+  const float y = fmaf(a, b, c);
+  return (y != y) ? 0.0f : fminf(fmaxf(y, 0.0f), 1.0f);
+#endif
+}
+
+// max(x, lo) for lo >= 0 as ONE v_max_i32 on the bit patterns: non-negative floats order like their bits and every
+// negative x (sign bit set) is a negative integer, so it yields lo (check_problem rejects z_min < 0).  fmaxf on an MFMA
+// result is expanded to a canonicalising v_max(x, x) plus the max (IEEE mode).  It has to be an instruction the compiler
+// can see: the hazard recogniser pads MFMA -> VALU reads with s_nop, which it cannot do around inline asm -- a
+// hand-written v_max_f32 here happened to work behind v_mfma_f32_16x16x4_f32 and read stale registers behind the
+// shorter v_mfma_f32_16x16x32_bf16 (profiles/r02_tune_fwd_bf16_split.txt).
+__device__ __forceinline__ float clamp_below(float x, float lo) {
+  int xi, li;
+  memcpy(&xi, &x, 4);
+  memcpy(&li, &lo, 4);
+  const int mi = max(xi, li);
+  float r;
+  memcpy(&r, &mi, 4);
+  return r;
+}
+
 // Residuals in units of the object's Huber threshold: the weights are pre-multiplied by 1 / delta, capped so that a zero or
 // denormal threshold stays finite (min(rho, delta) is then min(rho, 1e-15): below the resolution of any sum it enters).
 struct HuberScale { float inv_delta, delta, delta_sq; };

@@ -58,22 +58,6 @@ __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
 }
 #endif
 
-// max(x, lo) for lo >= 0 as ONE v_max_i32 on the bit patterns: non-negative floats order like their bits and every
-// negative x (sign bit set) is a negative integer, so it yields lo (check_problem rejects z_min < 0).  fmaxf on an MFMA
-// result is expanded to a canonicalising v_max(x, x) plus the max (IEEE mode).  It has to be an instruction the compiler
-// can see: the hazard recogniser pads MFMA -> VALU reads with s_nop, which it cannot do around inline asm -- a
-// hand-written v_max_f32 here happened to work behind v_mfma_f32_16x16x4_f32 and read stale registers behind the
-// shorter v_mfma_f32_16x16x32_bf16 (profiles/r02_tune_fwd_bf16_split.txt).
-__device__ __forceinline__ float clamp_below(float x, float lo) {
-  int xi, li;
-  memcpy(&xi, &x, 4);
-  memcpy(&li, &lo, 4);
-  const int mi = max(xi, li);
-  float r;
-  memcpy(&r, &mi, 4);
-  return r;
-}
-
 // Huber costs of the 4 poses a lane holds for one point (MFMA outputs hx, hy, hz) added to acc2 = {poses 0,1}, {2,3}
 // The weights in w4 (and those folded into hx, hy) are pre-divided by the object's Huber threshold delta, so the
 // residual norm rho is in units of delta, huber / delta^2 = m (rho - m / 2) with m = min(rho, 1), and the caller scales
