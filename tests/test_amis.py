@@ -65,6 +65,25 @@ def test_monte_carlo_forward_backward_matches_reference(backend, name):
     assert (r['pose_samples'] - ref['pose_samples']).abs().max().item() <= 2e-2
 
 
+def _mixture_logq(samples, props, dof, K):
+    """log of the equal-weight mixture of the K fitted proposals (kernel's own records) at `samples` (S,B,pose_len)."""
+    def tril(v, n):
+        L = torch.zeros(v.shape[:-1] + (n, n))
+        idx = torch.tril_indices(n, n)
+        L[..., idx[0], idx[1]] = v
+        return L
+    lq = []
+    for j in range(K):
+        rec = props[:, j]
+        lp = orc.student_t_logprob(samples[..., :3], rec[:, 0:3], tril(rec[:, 3:9], 3))
+        if dof == 6:
+            lp = lp + orc.acg_logprob(samples[..., 3:], tril(rec[:, 16:26], 4))
+        else:
+            lp = lp + orc.vm_mix_logprob(samples[..., 3:], rec[:, 16:17], rec[:, 17:18]).squeeze(-1)
+        lq.append(lp)
+    return torch.logsumexp(torch.stack(lq, 0), 0) - torch.log(torch.tensor(float(K)))
+
+
 @pytest.mark.parametrize('dof,S,K,N', [(6, 64, 4, 96), (4, 64, 4, 96), (6, 60, 3, 70), (6, 200, 2, 130), (4, 100, 1, 33),
                                        (6, 320, 2, 600), (6, 48, 2, 1300), (6, 32, 2, 2300), (6, 32, 2, 512), (4, 32, 2, 2040)])
 def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
@@ -82,23 +101,7 @@ def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
     samples, logw, props = samples.cpu(), logw.cpu(), props.cpu()
     ocam = orc.Cam(prob['cam_mats'], 0.1)
     cost = orc.evaluate(prob['x3d'], prob['x2d'], prob['w2d'], samples, ocam, prob['delta'], want_cost=True)[1]
-    s = S // K
-
-    def tril(v, n):
-        L = torch.zeros(v.shape[:-1] + (n, n))
-        idx = torch.tril_indices(n, n)
-        L[..., idx[0], idx[1]] = v
-        return L
-    lq = []
-    for j in range(K):
-        rec = props[:, j]
-        lp = orc.student_t_logprob(samples[..., :3], rec[:, 0:3], tril(rec[:, 3:9], 3))
-        if dof == 6:
-            lp = lp + orc.acg_logprob(samples[..., 3:], tril(rec[:, 16:26], 4))
-        else:
-            lp = lp + orc.vm_mix_logprob(samples[..., 3:], rec[:, 16:17], rec[:, 17:18]).squeeze(-1)
-        lq.append(lp)
-    mix = torch.logsumexp(torch.stack(lq, 0), 0) - torch.log(torch.tensor(float(K)))
+    mix = _mixture_logq(samples, props, dof, K)
     expect = -cost - mix
     assert (logw - expect).abs().max().item() <= 2e-4 * max(1.0, expect.abs().max().item())
 
@@ -140,6 +143,48 @@ def test_backward_matches_autograd_of_oracle_at_fixed_samples(backend, monkeypat
                                                  g_init.to(backend))
         for mine, ref in ((gx3d, x3d.grad), (gx2d, x2d.grad), (gw2d, w2d.grad), (gdel, delta.grad)):
             assert _rel(mine.cpu(), ref) <= 2e-4, (dof, bounds, _rel(mine.cpu(), ref))
+
+
+@pytest.mark.parametrize('delta,z_min', [(1e-4, 0.1), (3e3, 0.1), (0.7, 0.0), (0.7, 1e-6), (0.7, 4.5), (0.0, 0.1)])
+def test_sweeps_over_the_range_of_delta_and_z_min(backend, delta, z_min):
+    """Both AMIS sweeps carry the residuals in units of the Huber threshold (weights pre-divided by delta, min(rho, delta)
+    through a clamp modifier) and take the depth clamp / its gradient mask from integer-max and clamped-fma tricks that
+    assume z_min >= 0: cover a tiny and a huge threshold, z_min = 0 / tiny / beyond most of the points, and delta = 0
+    (cost identically 0: finite outputs, no NaN from 1 / delta)."""
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import HuberPnPCost
+    B, N, S, K, dof = 3, 150, 48, 2, 6
+    prob = orc.make_problem(B, N, dof, seed=23)
+    prob['delta'] = torch.full((B,), delta)
+    p, _, _ = make_layer_objects(prob, backend)
+    cam = PerspectiveCamera(cam_mats=p['cam_mats'], z_min=z_min)
+    cf = HuberPnPCost(delta=p['delta'])
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    # z_min = 0 divides by the raw depth: keep the proposal tight enough that no point crosses the image plane there
+    # (the reference returns inf / nan for such samples as well)
+    tz_var = 0.3 if z_min > 0 else 1e-3
+    cov = (torch.eye(6) * torch.tensor([0.02, 0.02, tz_var, 1e-3, 1e-3, 1e-3])).expand(B, 6, 6).contiguous()
+    noise = orc.make_noise(B, S, K, dof, seed=24)
+    samples, logw, props = F.amis_forward(hp, p['pose_gt'], cov.to(backend), S, K, noise=pack_noise(noise, dof).to(backend),
+                                          with_proposals=True)
+    samples, logw, props = samples.cpu(), logw.cpu(), props.cpu()
+    assert bool(torch.isfinite(logw).all())
+    x3d, x2d, w2d, dl = (prob[k].double().clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta'))
+    ocam = orc.Cam(prob['cam_mats'].double(), z_min)
+    cost = orc.evaluate(x3d, x2d, w2d, samples.double(), ocam, dl, want_cost=True)[1]
+    expect = -cost.detach().float() - _mixture_logq(samples, props, dof, K)
+    assert (logw - expect).abs().max().item() <= 2e-4 * max(1.0, expect.abs().max().item())
+    g = torch.Generator().manual_seed(3)
+    g_logw = torch.randn(S, B, generator=g)
+    ((-cost) * g_logw.double()).sum().backward()
+    grads = F.amis_backward(hp, samples.to(backend), g_logw.to(backend), None, None)
+    for i, (mine, ref) in enumerate(zip(grads, (x3d.grad, x2d.grad, w2d.grad, dl.grad))):
+        assert bool(torch.isfinite(mine).all())
+        if delta > 0 or i == 3:       # d cost / d delta = max(rho - delta, 0) does not vanish at delta = 0
+            assert _rel(mine.cpu().double(), ref) <= GRAD_TOL, (delta, z_min, i, _rel(mine.cpu().double(), ref))
+        else:                         # delta = 0 is carried as 1e-15 (huber_scale): gradients of that size instead of exact zeros
+            assert mine.abs().max().item() <= 1e-8
 
 
 @pytest.mark.parametrize('dof,bounds,N,S', [(6, None, 300, 70), (4, 'tight', 128, 33), (6, 'tight', 512, 40)])
