@@ -5,6 +5,12 @@
 
 namespace pnp {
 
+// precision of the single-lane proposal fits (tuning builds: -DPNP_FIT_T=float measures what fp64 costs there)
+#ifndef PNP_FIT_T
+#define PNP_FIT_T double
+#endif
+typedef PNP_FIT_T fit_t;
+
 
 #ifndef PNP_SWEEP_PIPELINE
 #define PNP_SWEEP_PIPELINE 0
@@ -96,20 +102,20 @@ __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) 
 // ---- reference's fp32 LAPACK path are at least not made worse) ----------------------------------------------
 
 // pack Cholesky factor / its inverse / log-normaliser of a 3x3 translation covariance into rec[3..15]
-PNP_FIT_FN void fit_translation(double (&C)[3][3], const float* fallback_diag, float* rec) {
-  double invd[3];
-  const bool ok = cholesky<3, double>(C, invd);
+PNP_FIT_FN void fit_translation(fit_t (&C)[3][3], const float* fallback_diag, float* rec) {
+  fit_t invd[3];
+  const bool ok = cholesky<3, fit_t>(C, invd);
   rec[37] = ok ? 0.f : 1.f;
   if (!ok) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) C[i][j] = (i == j) ? (double)fallback_diag[i] : 0.0;
-      invd[i] = 1.0 / (double)fallback_diag[i];
+      for (int j = 0; j < 3; ++j) C[i][j] = (i == j) ? (fit_t)fallback_diag[i] : fit_t(0);
+      invd[i] = fit_t(1) / (fit_t)fallback_diag[i];
     }
   }
-  double Li[3][3];
-  tri_inverse<3, double>(C, invd, Li);
+  fit_t Li[3][3];
+  tri_inverse<3, fit_t>(C, invd, Li);
   float sl = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -124,32 +130,32 @@ PNP_FIT_FN void fit_translation(double (&C)[3][3], const float* fallback_diag, f
 }
 
 // rot_cov (4x4 SPD, trace ~ 1) -> + det^(1/4) * dispersion * I -> Cholesky -> rec[16..36]   (epropnp.py:301-302,341-342)
-PNP_FIT_FN void fit_rotation_acg(double (&Rc)[4][4], float dispersion, float* rec) {
-  double Lc[4][4];
+PNP_FIT_FN void fit_rotation_acg(fit_t (&Rc)[4][4], float dispersion, float* rec) {
+  fit_t Lc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) Lc[i][j] = Rc[i][j];
-  double invd[4];
-  bool ok = cholesky<4, double>(Lc, invd);
+  fit_t invd[4];
+  bool ok = cholesky<4, fit_t>(Lc, invd);
   // det^(1/4) = sqrt(prod of the Cholesky pivots).  reference: torch.det on a possibly indefinite matrix; in the
   // non-SPD case any value leads to the Cholesky fallback below, so the SPD determinant is all that matters
   const float pivots = (float)(Lc[0][0] * Lc[1][1] * Lc[2][2] * Lc[3][3]);
-  const double add = ok ? (double)(sqrtf(pivots) * dispersion) : 0.0;
+  const fit_t add = ok ? (fit_t)(sqrtf(pivots) * dispersion) : fit_t(0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) Rc[i][i] += add;
-  ok = cholesky<4, double>(Rc, invd) && ok;
+  ok = cholesky<4, fit_t>(Rc, invd) && ok;
   rec[38] = ok ? 0.f : 1.f;
   if (!ok) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Rc[i][j] = (i == j) ? 1.0 : 0.0;
-      invd[i] = 1.0;
+      for (int j = 0; j < 4; ++j) Rc[i][j] = (i == j) ? fit_t(1) : fit_t(0);
+      invd[i] = fit_t(1);
     }
   }
-  double Li[4][4];
-  tri_inverse<4, double>(Rc, invd, Li);
+  fit_t Li[4][4];
+  tri_inverse<4, fit_t>(Rc, invd, Li);
   float sl = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -168,11 +174,11 @@ template <int DOF>
 PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, float dispersion, float* rec) {
   rec[0] = pose_opt[0]; rec[1] = pose_opt[1]; rec[2] = pose_opt[2];
   rec[37] = rec[38] = rec[39] = 0.f;
-  double Ct[3][3];
+  fit_t Ct[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) Ct[i][j] = (double)cov[i * DOF + j];
+    for (int j = 0; j < 3; ++j) Ct[i][j] = (fit_t)cov[i * DOF + j];
   if (DOF == 4) {
     const float dflt[3] = {1.0f, 1.0f, 4.0f};
     fit_translation(Ct, dflt, rec);
@@ -183,18 +189,18 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
   } else {
     const float dflt[3] = {1.0f, 1.0f, 1.0f};
     fit_translation(Ct, dflt, rec);
-    double Cr[3][3], Ci[3][3];
+    fit_t Cr[3][3], Ci[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) Cr[i][j] = (double)cov[(3 + i) * 6 + 3 + j];
-    double invd4[4];
+      for (int j = 0; j < 3; ++j) Cr[i][j] = (fit_t)cov[(3 + i) * 6 + 3 + j];
+    fit_t invd4[4];
     // the reference inverts this block with LU (torch.inverse, epropnp.py:297): a true inverse also when the block is
     // indefinite.  Adjugate / determinant in fp64 does the same (NaN in -> NaN out -> identity fallback below).
     {
-      const double c00 = Cr[1][1] * Cr[2][2] - Cr[1][2] * Cr[2][1], c01 = Cr[1][2] * Cr[2][0] - Cr[1][0] * Cr[2][2],
+      const fit_t c00 = Cr[1][1] * Cr[2][2] - Cr[1][2] * Cr[2][1], c01 = Cr[1][2] * Cr[2][0] - Cr[1][0] * Cr[2][2],
                    c02 = Cr[1][0] * Cr[2][1] - Cr[1][1] * Cr[2][0];
-      const double idet = 1.0 / (Cr[0][0] * c00 + Cr[0][1] * c01 + Cr[0][2] * c02);
+      const fit_t idet = fit_t(1) / (Cr[0][0] * c00 + Cr[0][1] * c01 + Cr[0][2] * c02);
       Ci[0][0] = c00 * idet; Ci[1][0] = c01 * idet; Ci[2][0] = c02 * idet;
       Ci[0][1] = (Cr[0][2] * Cr[2][1] - Cr[0][1] * Cr[2][2]) * idet;
       Ci[1][1] = (Cr[0][0] * Cr[2][2] - Cr[0][2] * Cr[2][0]) * idet;
@@ -203,9 +209,9 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
       Ci[1][2] = (Cr[0][2] * Cr[1][0] - Cr[0][0] * Cr[1][2]) * idet;
       Ci[2][2] = (Cr[0][0] * Cr[1][1] - Cr[0][1] * Cr[1][0]) * idet;
     }
-    const double w = pose_opt[3], qi = pose_opt[4], qj = pose_opt[5], qk = pose_opt[6];
-    const double T[4][3] = {{qi, qj, qk}, {-w, -qk, qj}, {qk, -w, -qi}, {-qj, qi, -w}};   // camera.py:158-165
-    double TC[4][3], A[4][4], Ai[4][4];
+    const fit_t w = pose_opt[3], qi = pose_opt[4], qj = pose_opt[5], qk = pose_opt[6];
+    const fit_t T[4][3] = {{qi, qj, qk}, {-w, -qk, qj}, {qk, -w, -qi}, {-qj, qi, -w}};   // camera.py:158-165
+    fit_t TC[4][3], A[4][4], Ai[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -214,12 +220,12 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        A[i][j] = TC[i][0] * T[j][0] + TC[i][1] * T[j][1] + TC[i][2] * T[j][2] + ((i == j) ? 1.0 : 0.0);
+        A[i][j] = TC[i][0] * T[j][0] + TC[i][1] * T[j][1] + TC[i][2] * T[j][2] + ((i == j) ? fit_t(1) : fit_t(0));
     // A = I + (rank <= 3) always has the eigenvalue 1, so a non-SPD A is indefinite, and so are its inverse and any
     // rescaling of it: the reference's Cholesky (epropnp.py:302) fails and falls back to I.  Same outcome here.
-    const bool a_spd = spd_inverse<4, double>(A, invd4, Ai);
-    if (!a_spd) Ai[0][0] = -1.0;
-    const double itr = 1.0 / (Ai[0][0] + Ai[1][1] + Ai[2][2] + Ai[3][3]);
+    const bool a_spd = spd_inverse<4, fit_t>(A, invd4, Ai);
+    if (!a_spd) Ai[0][0] = -fit_t(1);
+    const fit_t itr = fit_t(1) / (Ai[0][0] + Ai[1][1] + Ai[2][2] + Ai[3][3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -664,17 +670,17 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     for (int r = 1; r < a.mle_iter; ++r) {
       // Sigma^-1 of the previous fixed-point iterate (one lane, fp64), broadcast through LDS
       if (tid == 0) {
-        double Sg[4][4], Sgi[4][4], invd[4];
-        const double inorm = 1.0 / (double)acc[10];
+        fit_t Sg[4][4], Sgi[4][4], invd[4];
+        const fit_t inorm = fit_t(1) / (fit_t)acc[10];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j <= i; ++j) {
-            const double v = (double)acc[tri(i, j)] * inorm + ((i == j) ? (double)a.eps : 0.0);
+            const fit_t v = (fit_t)acc[tri(i, j)] * inorm + ((i == j) ? (fit_t)a.eps : fit_t(0));
             Sg[i][j] = v;
             Sg[j][i] = v;
           }
-        spd_inverse<4, double>(Sg, invd, Sgi);
+        spd_inverse<4, fit_t>(Sg, invd, Sgi);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -705,25 +711,25 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     PNP_REFIT_PHASE(1);
     if (tid == 0) {
       nrec[0] = mu0; nrec[1] = mu1; nrec[2] = mu2;
-      double Ct[3][3];
+      fit_t Ct[3][3];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
-          Ct[i][j] = (double)c6[tri(i, j)];
-          Ct[j][i] = (double)c6[tri(i, j)];
+          Ct[i][j] = (fit_t)c6[tri(i, j)];
+          Ct[j][i] = (fit_t)c6[tri(i, j)];
         }
       const float dflt[3] = {1.f, 1.f, 1.f};
       nrec[38] = nrec[39] = 0.f;
       fit_translation(Ct, dflt, nrec);
-      double Sg[4][4];
-      const double inorm = (a.mle_iter > 0) ? 1.0 / (double)acc[10] : 0.0;
+      fit_t Sg[4][4];
+      const fit_t inorm = (a.mle_iter > 0) ? fit_t(1) / (fit_t)acc[10] : fit_t(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
-          double v = (a.mle_iter > 0) ? (double)acc[tri(i, j)] * inorm + ((i == j) ? (double)a.eps : 0.0)
-                                      : ((i == j) ? 1.0 : 0.0);
+          fit_t v = (a.mle_iter > 0) ? (fit_t)acc[tri(i, j)] * inorm + ((i == j) ? (fit_t)a.eps : fit_t(0))
+                                      : ((i == j) ? fit_t(1) : fit_t(0));
           Sg[i][j] = v;
           Sg[j][i] = v;
         }
@@ -759,13 +765,13 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     c8[7] = mom[11] * invZ;
     if (tid == 0) {
       nrec[0] = mu0; nrec[1] = mu1; nrec[2] = mu2;
-      double Ct[3][3];
+      fit_t Ct[3][3];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
-          Ct[i][j] = (double)c8[tri(i, j)];
-          Ct[j][i] = (double)c8[tri(i, j)];
+          Ct[i][j] = (fit_t)c8[tri(i, j)];
+          Ct[j][i] = (fit_t)c8[tri(i, j)];
         }
       const float dflt[3] = {1.f, 1.f, 4.f};
       nrec[38] = nrec[39] = 0.f;

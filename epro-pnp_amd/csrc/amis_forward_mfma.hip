@@ -161,6 +161,9 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
 
   for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last tile
   if (tid == 0) initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop);
+#ifdef PNP_TUNING_DOUBLE_INIT    // what one initial fit costs: a second one, on the neighbour's data, into a slot the first refit overwrites
+  if (tid == 0 && K > 1) initial_fit<DOF>(pose_opt + (size_t)((b + 1) % p.B) * PL, pose_cov + (size_t)((b + 1) % p.B) * DOF * DOF, a.eps, a.dispersion, prop + kPropStride);
+#endif
   const int nchunk = kRegs ? 1 : (p.N + NC - 1) / NC;
   auto load_chunk = [&](int c0) {
     const int cnt = min(NC, ((p.N - c0 + 15) >> 4) << 4);
