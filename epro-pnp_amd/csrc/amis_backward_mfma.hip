@@ -76,11 +76,15 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
 
   const bool with_init = (pose_init != nullptr) && (g_init != nullptr);
   const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
+  // g_init[b] is wave-uniform, i.e. a SCALAR load: inside the per-lane (m >= S) arm below the compiler does not branch
+  // around it when no lane takes the arm (scalar loads ignore EXEC), and a NULL g_init faulted.  Fetch it under a
+  // uniform branch instead.
+  const float g_init_b = with_init ? g_init[b] : 0.f;
 
   // ---- weights, drop threshold (mass_drop_threshold, amis_common.h), compaction ----
   float amax = 0.f;
   for (int m = tid; m < P; m += T) {
-    const float w = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init[b];       // logw = -cost - const
+    const float w = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init_b;        // logw = -cost - const
     wraw[m] = w;
     if (m < S) amax = fmaxf(amax, fabsf(w));
   }
@@ -200,7 +204,10 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
           const float rho = s2 * rs;
           const float mm = sat_mul(rho, one_v);                // min(rho, delta) / delta
           const float coef = aw[r] * mm * rs;                  // a * min(1, delta / rho)
-          gd = fmaf(aw[r], rho - mm, gd);                      // d huber / d delta = max(rho - delta, 0)   (/ delta)
+          // d huber / d delta = max(rho - delta, 0) (/ delta).  The compiler contracts rho - mm with rho = s2 * rs into
+          // fma(s2, rs, -mm): for an inlier that is the rounding error of the product (<= ulp(rho) / 2), not exactly 0 as in
+          // the reference -- noise at the 1e-7 level of sum |a| rho; an un-fused subtract costs 2 % of this kernel
+          gd = fmaf(aw[r], rho - mm, gd);
           const float crx = coef * rx, cry = coef * ry;
           // d/dw = crx * (px - u) = crx * rx / w and d/du = -crx * w: the per-point factors are applied once at the end
           A2x[i] = fmaf(crx, rx, A2x[i]);

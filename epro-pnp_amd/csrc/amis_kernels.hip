@@ -205,6 +205,9 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
   const bool with_init = (pose_init != nullptr) && (g_init != nullptr);
   const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
   const int ntile = (P + 63) >> 6;
+  // wave-uniform, hence a scalar load: fetched under a uniform branch, not inside a per-lane conditional (scalar loads
+  // ignore EXEC; a NULL g_init would fault there even when no lane takes the arm)
+  const float g_init_b = with_init ? g_init[b] : 0.f;
 
   // Samples whose total |weight| is below drop_eps of the object's total are skipped (mass_drop_threshold,
   // amis_common.h): at the default 2^-24 that is under the fp32 rounding of the S-term sums; ~17 % of the AMIS samples
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
       const float* src = (m < S) ? pose_samples + ((size_t)m * p.B + b) * PL : pose_init + (size_t)b * PL;
 #pragma unroll
       for (int i = 0; i < PL; ++i) nps[i] = src[i];
-      naw = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init[b];     // logw = -cost - const
+      naw = (m < S) ? -g_logw[(size_t)m * p.B + b] : g_init_b;      // logw = -cost - const
       if (m < S && fabsf(naw) <= askip) naw = 0.f;
     }
   };
