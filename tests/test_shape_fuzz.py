@@ -1,0 +1,100 @@
+"""Seeded sweep over problem shapes and optional arguments: every launch-shape heuristic, template instantiation and
+NULL-pointer combination the hot path can take, checked with the comparisons that do not depend on the (chaotic) proposal
+refit -- LM pose against the oracle's LM, log-weights against the oracle's cost / densities at the kernel's OWN samples and
+fitted proposals, backward against autograd of the oracle at fixed samples.  (A NULL `pose_init` in the backward and a
+hazard behind the bf16 MFMA were both shape / argument combinations no fixed-size test had reached.)"""
+import random
+
+import pytest
+import torch
+
+import epropnp_oracle as orc
+from helpers import make_layer_objects, pack_noise
+from test_amis import GRAD_TOL, _mixture_logq, _rel
+
+
+def _cases(n, seed, n_max, s_max):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        dof = rng.choice((6, 6, 4))
+        K = rng.choice((1, 2, 3, 4))
+        s = rng.choice((8, 16, 20, 32, 48, 64, 128)) if s_max >= 512 else rng.choice((8, 16, 20, 32))
+        N = rng.choice((5, 16, 17, 33, 64, 100, 128, 129, 200, 256, 300, 511, 512, 513, 700, 1024, 1500, 2049, 2500))
+        while N > n_max:
+            N //= 2
+        B = rng.choice((1, 2, 3, 5, 7))
+        bounds = rng.choice((None, None, 'tensor', 'tight'))
+        with_init = rng.random() < 0.6
+        z_min = rng.choice((0.1, 0.1, 0.01, 2.0))
+        out.append(pytest.param(dof, B, N, s * K, K, bounds, with_init, z_min, 1000 * seed + i,
+                                id=f'{dof}dof-B{B}-N{N}-S{s * K}-K{K}-{bounds}-init{int(with_init)}-z{z_min}'))
+    return out
+
+
+def _check(backend, dof, B, N, S, K, bounds, with_init, z_min, seed):
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import HuberPnPCost
+    prob = orc.make_problem(B, N, dof, seed=seed, bounds=bounds)
+    p, _, _ = make_layer_objects(prob, backend)
+    cam = PerspectiveCamera(cam_mats=p['cam_mats'], z_min=z_min, lb=p.get('lb'), ub=p.get('ub'))
+    cf = HuberPnPCost(delta=p['delta'])
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    ocam = orc.Cam(prob['cam_mats'].double(), z_min, *(prob[k].double() if k in prob else None for k in ('lb', 'ub')))
+    d64 = {k: prob[k].double() for k in ('x3d', 'x2d', 'w2d', 'delta', 'pose_init')}
+
+    # ---- LM: pose and covariance against the oracle's solver (fp64) ----
+    pose_opt, pose_cov, cost = F.lm_solve(hp, p['pose_init'], 4, with_pose_cov=True, with_cost=True)
+    ref, _, ref_cost = orc.lm_solve(d64['x3d'], d64['x2d'], d64['w2d'], ocam, d64['delta'], d64['pose_init'], num_iter=4,
+                                    with_cost=True)[:3]
+    # 4 iterations do not converge a clipped (tight bounds) or barely determined problem: there the iterates of an fp32 and
+    # an fp64 solver drift apart along the flat direction while the cost they reach is the same
+    well_posed = N >= 64 and bounds != 'tight' and z_min <= 0.1      # (a depth clamp that binds puts kinks in the cost too)
+    assert (pose_opt.cpu().double() - ref).abs().max().item() <= (2e-4 if well_posed else 2e-2)
+    assert ((cost.cpu().double() - ref_cost).abs() <= 2e-3 * ref_cost.abs().clamp(min=1.0)).all()
+    assert bool(torch.isfinite(pose_opt).all()) and bool(torch.isfinite(pose_cov).all())
+
+    # ---- AMIS forward: log-weights against cost + mixture density at the kernel's own samples / proposals ----
+    noise = orc.make_noise(B, S, K, dof, seed=seed + 1)
+    samples, logw, props = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=pack_noise(noise, dof).to(backend),
+                                          with_proposals=True)
+    samples, logw, props = samples.cpu(), logw.cpu(), props.cpu()
+    leaves = {k: d64[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta')}
+    c_s = orc.evaluate(leaves['x3d'], leaves['x2d'], leaves['w2d'], samples.double(), ocam, leaves['delta'], want_cost=True)[1]
+    expect = -c_s.detach().float() - _mixture_logq(samples, props, dof, K)
+    fin = torch.isfinite(expect)
+    assert bool((torch.isfinite(logw) == fin).all())
+    assert (logw[fin] - expect[fin]).abs().max().item() <= 2e-4 * max(1.0, expect[fin].abs().max().item())
+
+    # ---- backward at those samples, softmax weights as the loss produces them, with / without the cost of pose_init ----
+    g_logw = torch.softmax(logw, 0) / B
+    g_init = torch.full((B,), 1.0 / B)
+    obj = ((-c_s) * g_logw.double()).sum()
+    if with_init:
+        c_i = orc.evaluate(leaves['x3d'], leaves['x2d'], leaves['w2d'], d64['pose_init'], ocam, leaves['delta'], want_cost=True)[1]
+        obj = obj + (c_i * g_init.double()).sum()
+    obj.backward()
+    grads = F.amis_backward(hp, samples.to(backend), g_logw.to(backend), p['pose_init'] if with_init else None,
+                            g_init.to(backend) if with_init else None)
+    for name, mine in zip(('x3d', 'x2d', 'w2d', 'delta'), grads):
+        want = leaves[name].grad
+        assert bool(torch.isfinite(mine).all()), name
+        if name == 'delta':      # sums of max(rho - delta, 0): a few point-poses near the threshold dominate; absolute floor
+            err = (mine.cpu().double() - want).abs().max().item()
+            assert err <= GRAD_TOL * want.abs().max().item() + 1e-6 * N, (name, err)
+        else:
+            assert _rel(mine.cpu().double(), want) <= GRAD_TOL, (name, _rel(mine.cpu().double(), want))
+
+
+@pytest.mark.parametrize('dof,B,N,S,K,bounds,with_init,z_min,seed', _cases(10, 1, 320, 128))
+def test_shape_sweep_small(backend, dof, B, N, S, K, bounds, with_init, z_min, seed):
+    _check(backend, dof, B, N, S, K, bounds, with_init, z_min, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dof,B,N,S,K,bounds,with_init,z_min,seed', _cases(80, 2, 4096, 512))
+def test_shape_sweep_gpu(dof, B, N, S, K, bounds, with_init, z_min, seed):
+    import install as emu
+    emu.uninstall()
+    _check(torch.device('cuda:0'), dof, B, N, S, K, bounds, with_init, z_min, seed)
