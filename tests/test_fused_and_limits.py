@@ -65,6 +65,11 @@ def test_fused_forward_without_pose_init_and_fallback_paths(backend):
     out = layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf)
     assert out[5] is None and out[1] is None and out[3].shape == (S, B, 4) and torch.isfinite(out[4]).all()
     assert (out[0][:, :3].cpu() - prob['pose_gt'][:, :3]).norm(dim=-1).median() < 1.0
+    # ... and its backward: no pose_init means no cost_init, so the backward kernels get NULL for both optional inputs
+    leaves = [p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d')]
+    out = layer.monte_carlo_forward(*leaves, cam, cf)
+    torch.logsumexp(out[4], 0).mean().backward()
+    assert all(t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().sum()) > 0 for t in leaves)
 
     class MySolver(LMSolver):
         pass
