@@ -3,6 +3,7 @@ NULL-pointer combination the hot path can take, checked with the comparisons tha
 refit -- LM pose against the oracle's LM, log-weights against the oracle's cost / densities at the kernel's OWN samples and
 fitted proposals, backward against autograd of the oracle at fixed samples.  (A NULL `pose_init` in the backward and a
 hazard behind the bf16 MFMA were both shape / argument combinations no fixed-size test had reached.)"""
+import os
 import random
 
 import pytest
@@ -45,14 +46,23 @@ def _check(backend, dof, B, N, S, K, bounds, with_init, z_min, seed):
     d64 = {k: prob[k].double() for k in ('x3d', 'x2d', 'w2d', 'delta', 'pose_init')}
 
     # ---- LM: pose and covariance against the oracle's solver (fp64) ----
-    pose_opt, pose_cov, cost = F.lm_solve(hp, p['pose_init'], 4, with_pose_cov=True, with_cost=True)
-    ref, _, ref_cost = orc.lm_solve(d64['x3d'], d64['x2d'], d64['w2d'], ocam, d64['delta'], d64['pose_init'], num_iter=4,
-                                    with_cost=True)[:3]
-    # 4 iterations do not converge a clipped (tight bounds) or barely determined problem: there the iterates of an fp32 and
-    # an fp64 solver drift apart along the flat direction while the cost they reach is the same
-    well_posed = N >= 64 and bounds != 'tight' and z_min <= 0.1      # (a depth clamp that binds puts kinks in the cost too)
-    assert (pose_opt.cpu().double() - ref).abs().max().item() <= (2e-4 if well_posed else 2e-2)
-    assert ((cost.cpu().double() - ref_cost).abs() <= 2e-3 * ref_cost.abs().clamp(min=1.0)).all()
+    pose_opt, pose_cov, cost = F.lm_solve(hp, p['pose_init'], 10, with_pose_cov=True, with_cost=True)
+    # The oracle in fp64 AND in fp32 (the reference's own precision): an accept / reject decision of the trust region that
+    # sits on a knife-edge falls one way or the other with the rounding (the parity tests handle that with the
+    # rounding-spread yardstick); per object the kernel has to agree with one of the two.  10 iterations, so that what is
+    # compared is the minimum reached.  A clipped (tight bounds, binding depth clamp) or barely determined problem keeps
+    # a flat direction along which solutions drift while reaching the same cost.
+    well_posed = N >= 64 and bounds != 'tight' and z_min <= 0.1
+    ocam32 = orc.Cam(prob['cam_mats'], z_min, prob.get('lb'), prob.get('ub'))
+    refs = [orc.lm_solve(d64['x3d'], d64['x2d'], d64['w2d'], ocam, d64['delta'], d64['pose_init'], num_iter=10, with_cost=True),
+            orc.lm_solve(prob['x3d'], prob['x2d'], prob['w2d'], ocam32, prob['delta'], prob['pose_init'], num_iter=10,
+                         with_cost=True)]
+    # pose error relative to the object's distance (4-DoF problems sit at t_z ~ 10, where the depth is the flat direction)
+    perr = torch.stack([(pose_opt.cpu().double() - r[0].double()).abs().amax(-1) / (r[0].double().abs().amax(-1) / 4).clamp(min=1.0)
+                        for r in refs]).amin(0)
+    cerr = torch.stack([(cost.cpu().double() - r[2].double()).abs() / r[2].double().abs().clamp(min=1.0) for r in refs]).amin(0)
+    assert perr.max().item() <= (2e-4 if well_posed else 2e-2), perr
+    assert cerr.max().item() <= 2e-3, cerr
     assert bool(torch.isfinite(pose_opt).all()) and bool(torch.isfinite(pose_cov).all())
 
     # ---- AMIS forward: log-weights against cost + mixture density at the kernel's own samples / proposals ----
@@ -93,7 +103,7 @@ def test_shape_sweep_small(backend, dof, B, N, S, K, bounds, with_init, z_min, s
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dof,B,N,S,K,bounds,with_init,z_min,seed', _cases(80, 2, 4096, 512))
+@pytest.mark.parametrize('dof,B,N,S,K,bounds,with_init,z_min,seed', _cases(int(os.environ.get('EPROPNP_FUZZ_CASES', '80')), 2, 4096, 512))
 def test_shape_sweep_gpu(dof, B, N, S, K, bounds, with_init, z_min, seed):
     import install as emu
     emu.uninstall()
