@@ -22,7 +22,37 @@ def test_fused_forward_equals_composite(backend, monkeypatch, dof, normalize, rs
     """epropnp_monte_carlo_forward enqueues the same kernels the separate calls do: outputs and input gradients are
     bit-identical to the composite path (EPROPNP_NO_FUSED_FORWARD=1), with and without pnp_normalize, RSLM
     initialisation (injected draws), pose_opt_plus and projection bounds; force_init_solve picks per object."""
-    B, N, S, K, L = 5, 70, 32, 2, 3
+    _fused_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bounds, 5, 70, 32, 2, 3)
+
+
+def _sweep_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        dof = rng.choice((6, 4))
+        c = (dof, rng.random() < 0.5, rng.random() < 0.5, rng.random() < 0.5, rng.choice((None, 'tensor', 'tight')),
+             rng.choice((1, 2, 6, 9)), rng.choice((24, 64, 100, 130, 300)), rng.choice((8, 16, 24)) * rng.choice((1, 2, 4)),
+             0, rng.choice((1, 3, 5)))
+        K = rng.choice([k for k in (1, 2, 4) if c[7] % k == 0])
+        out.append(c[:8] + (K, c[9]))
+    return out
+
+
+@pytest.mark.parametrize('dof,normalize,rslm,plus,bounds,B,N,S,K,L', _sweep_cases(8, 11))
+def test_fused_forward_equals_composite_sweep(backend, monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L):
+    _fused_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dof,normalize,rslm,plus,bounds,B,N,S,K,L', _sweep_cases(40, 12))
+def test_fused_forward_equals_composite_sweep_gpu(monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L):
+    import install as emu
+    emu.uninstall()
+    _fused_equals_composite(torch.device('cuda:0'), monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L)
+
+
+def _fused_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L):
     prob = orc.make_problem(B, N, dof, seed=3, bounds=bounds)
     prob['pose_init'][0, :3] += 3.0                        # object 0: a bad pose_init, so RSLM's start wins there
     noise = pack_noise(orc.make_noise(B, S, K, dof, seed=4), dof).to(backend)
