@@ -186,6 +186,8 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
     const float kappa = 0.33f / fmaxf(cov[3 * 4 + 3], eps);
     rec[17] = kappa;
     rec[18] = log_i0(kappa);
+#pragma unroll
+    for (int i = 19; i < 37; ++i) rec[i] = 0.f;      // unused in the 4-DoF record: the records are an output, no stale LDS in them
   } else {
     const float dflt[3] = {1.0f, 1.0f, 1.0f};
     fit_translation(Ct, dflt, rec);
@@ -781,6 +783,8 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       const float kappa = 0.33f * fmaxf(sqrtf(r_sq), a.eps) * (2.f - r_sq) / fmaxf(1.f - r_sq, a.eps);
       nrec[17] = kappa;
       nrec[18] = log_i0(kappa);
+#pragma unroll
+      for (int i = 19; i < 37; ++i) nrec[i] = 0.f;
     }
   }
   __syncthreads();

@@ -69,6 +69,9 @@ def _check(backend, dof, B, N, S, K, bounds, with_init, z_min, seed):
     noise = orc.make_noise(B, S, K, dof, seed=seed + 1)
     samples, logw, props = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=pack_noise(noise, dof).to(backend),
                                           with_proposals=True)
+    again = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=pack_noise(noise, dof).to(backend), with_proposals=True)
+    for a, b in zip((samples, logw, props), again):      # fixed reduction order, no atomics: bit-reproducible (a race would not be)
+        assert torch.equal(a, b)
     samples, logw, props = samples.cpu(), logw.cpu(), props.cpu()
     leaves = {k: d64[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta')}
     c_s = orc.evaluate(leaves['x3d'], leaves['x2d'], leaves['w2d'], samples.double(), ocam, leaves['delta'], want_cost=True)[1]
@@ -87,7 +90,10 @@ def _check(backend, dof, B, N, S, K, bounds, with_init, z_min, seed):
     obj.backward()
     grads = F.amis_backward(hp, samples.to(backend), g_logw.to(backend), p['pose_init'] if with_init else None,
                             g_init.to(backend) if with_init else None)
-    for name, mine in zip(('x3d', 'x2d', 'w2d', 'delta'), grads):
+    again = F.amis_backward(hp, samples.to(backend), g_logw.to(backend), p['pose_init'] if with_init else None,
+                            g_init.to(backend) if with_init else None)
+    for name, mine, rerun in zip(('x3d', 'x2d', 'w2d', 'delta'), grads, again):
+        assert torch.equal(mine, rerun), name
         want = leaves[name].grad
         assert bool(torch.isfinite(mine).all()), name
         if name == 'delta':      # sums of max(rho - delta, 0): a few point-poses near the threshold dominate; absolute floor
