@@ -364,7 +364,8 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
     ppl /= 2;
   }
   int ov[3];   // WS, WP, PPL
-  if (env_ints("EPROPNP_FWD_SHAPE", ov, 3) && 64 * ov[1] * ov[2] >= d.N && ov[0] * ov[1] <= 16) {
+  if (env_ints("EPROPNP_FWD_SHAPE", ov, 3) && valid_shape_override(ov[1], ov[2], d.N) && ov[0] >= 1 && ov[0] * ov[1] <= 16 &&
+      (ov[0] & (ov[0] - 1)) == 0) {
     WS = ov[0]; WP = ov[1]; ppl = ov[2];
   }
   AmisParams k;
@@ -433,7 +434,7 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
   // measured on MI355X (profiles/): fewest waves per object wins (per-pose overhead amortised over 8 points/lane)
   Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/4096);
   int ov[2];
-  if (env_ints("EPROPNP_BWD_SHAPE", ov, 2) && 64 * ov[0] * ov[1] >= d.N) { s.waves = ov[0]; s.ppl = ov[1]; }
+  if (env_ints("EPROPNP_BWD_SHAPE", ov, 2) && valid_shape_override(ov[0], ov[1], d.N)) { s.waves = ov[0]; s.ppl = ov[1]; }
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((amis_backward_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),

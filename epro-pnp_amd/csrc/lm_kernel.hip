@@ -140,7 +140,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
   // the 1+L dependent sweeps (measured on MI355X at B = 32 / 256 / 600: 1 wave 38 / 30 / 30 us vs 86 / 62 / 41 us)
   Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/0);
   int ov[2];
-  if (env_ints("EPROPNP_LM_SHAPE", ov, 2) && 64 * ov[0] * ov[1] >= d.N) { s.waves = ov[0]; s.ppl = ov[1]; }
+  if (env_ints("EPROPNP_LM_SHAPE", ov, 2) && valid_shape_override(ov[0], ov[1], d.N)) { s.waves = ov[0]; s.ppl = ov[1]; }
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),

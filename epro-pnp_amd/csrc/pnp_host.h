@@ -72,6 +72,14 @@ inline Shape choose_shape(int B, int N, int max_ppl = 8, int want_waves_total = 
 }
 
 // Tuning knob: EPROPNP_<NAME>="a,b,c" overrides a launcher's automatic workgroup shape.
+// a (waves, points-per-lane) override from a tuning variable is taken only if it is one the kernels are instantiated for
+// and covers the object: anything else is ignored (a typo must not change results)
+inline bool valid_shape_override(int waves, int ppl, int N) {
+  const bool w_ok = waves == 1 || waves == 2 || waves == 4 || waves == 8 || waves == 16;
+  const bool p_ok = ppl == 1 || ppl == 2 || ppl == 4 || ppl == 8;
+  return w_ok && p_ok && 64L * waves * ppl >= N;
+}
+
 inline bool env_ints(const char* name, int* out, int n) {
   const char* v = getenv(name);
   if (!v || !*v) return false;

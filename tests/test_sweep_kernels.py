@@ -92,10 +92,14 @@ def test_normal_equations_launch_shapes_agree(backend, monkeypatch, dof, bounds,
                                   prob['delta'].double(), True, True)
     jtj = jac.transpose(-1, -2) @ jac
     jtr = (jac.transpose(-1, -2) @ res.unsqueeze(-1)).squeeze(-1)
-    ppl = 1
-    while 64 * ppl < N:
-        ppl *= 2
-    for shape in (None, f'2,{max(ppl // 2, 1)}', f'8,{max(ppl // 8, 1)}'):
+    shapes = [None, '2,16']         # (an override the kernels are not instantiated for is ignored, not half-applied)
+    for w in (2, 8, 16):
+        ppl = 1
+        while 64 * w * ppl < N:
+            ppl *= 2
+        if ppl <= 8:
+            shapes.append(f'{w},{ppl}')
+    for shape in shapes:
         if shape is None:
             monkeypatch.delenv('EPROPNP_NE_SHAPE', raising=False)
         else:
