@@ -104,6 +104,40 @@ def test_c2_properties(dev):
     assert abs(fd.item() - an.item()) <= 2e-2 * abs(an.item()) + 1e-3
 
 
+def test_many_objects_batch_composition(dev):
+    """70 001 objects in one call (not a multiple of the XCD count or of anything else; more workgroups than any other test
+    launches): objects from the ends and the middle of the batch come out as they do in a batch of their own -- forward,
+    loss gradient and the RSLM-free LM path alike.  Catches object <-> workgroup mapping and 32-bit index slips."""
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    B, N, S, K, L = 70001, 96, 64, 2, 3
+    prob = device_problem(B, N, 6, dev, seed=123)
+    noise = device_noise(B, S, K, dev, 21)
+    idx = torch.tensor([0, 1, 7, 8, 9, 4095, 4096, 32767, 32768, 35000, 65535, 65536, 69999, 70000], device=dev)
+
+    def run(sel):
+        d = {k: (prob[k] if sel is None else prob[k][sel].contiguous()) for k in ('x3d', 'x2d', 'w2d', 'cam_mats', 'pose_init')}
+        leaves = [d[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d')]
+        cam = PerspectiveCamera(cam_mats=d['cam_mats'])
+        cf = AdaptiveHuberPnPCost(relative_delta=0.5)
+        cf.set_param(leaves[1].detach(), leaves[2])
+        out = layer6(S, K, L).monte_carlo_forward(*leaves, cam, cf, pose_init=d['pose_init'], force_init_solve=False,
+                                                  noise=(noise if sel is None else noise[sel].contiguous()))
+        lse = torch.logsumexp(out[4], 0)
+        (out[5] + lse).sum().backward()              # per-object loss, summed: an object's gradient is its own
+        return out[0].detach(), lse.detach(), [t.grad for t in leaves]
+
+    pose_a, lse_a, grads_a = run(None)
+    pose_s, lse_s, grads_s = run(idx)
+    assert bool(torch.isfinite(pose_a).all()) and bool(torch.isfinite(lse_a).all())
+    assert (pose_a[idx] - pose_s).abs().max().item() < 1e-4
+    assert (lse_a[idx] - lse_s).abs().max().item() < 2e-3
+    for a, b in zip(grads_a, grads_s):
+        assert bool(torch.isfinite(a).all())
+        den = b.flatten(1).abs().amax(1).clamp(min=1e-12)
+        assert ((a[idx] - b).flatten(1).abs().amax(1) / den).max().item() < 5e-3
+
+
 def test_c3_linemod_shape_matches_oracle(dev):
     """32 objects x 4096 dense correspondences, Gauss-Newton fast mode 3 iterations, tensor bounds (lib/test.py:91-96)."""
     from epropnp.levenberg_marquardt import LMSolver
