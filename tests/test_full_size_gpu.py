@@ -138,6 +138,43 @@ def test_many_objects_batch_composition(dev):
         assert ((a[idx] - b).flatten(1).abs().amax(1) / den).max().item() < 5e-3
 
 
+def test_two_streams_run_independent_steps(dev):
+    """The library launches on the caller's current stream and keeps no device-side state between calls: two steps (forward,
+    loss, backward) enqueued back to back on two side streams, so that they overlap on the GPU, give what each gives alone."""
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+
+    def setup(seed, B, N):
+        prob = device_problem(B, N, 6, dev, seed=seed)
+        return prob, device_noise(B, 128, 4, dev, seed + 1)
+
+    def step(prob, noise):
+        leaves = [prob[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d')]
+        cam = PerspectiveCamera(cam_mats=prob['cam_mats'])
+        cf = AdaptiveHuberPnPCost(relative_delta=0.5)
+        cf.set_param(leaves[1].detach(), leaves[2])
+        out = layer6(128, 4, 3).monte_carlo_forward(*leaves, cam, cf, pose_init=prob['pose_init'], force_init_solve=False,
+                                                    noise=noise)
+        (out[5] + torch.logsumexp(out[4], 0)).mean().backward()
+        return [out[0].detach(), out[4].detach()] + [t.grad for t in leaves]
+
+    jobs = [setup(31, 1500, 256), setup(41, 900, 512)]
+    alone = [step(*j) for j in jobs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    together = []
+    for _ in range(3):                       # a few rounds so that the two streams really interleave
+        together = []
+        for st, j in zip(streams, jobs):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                together.append(step(*j))
+    torch.cuda.synchronize()
+    for a, t in zip(alone, together):
+        for x, y in zip(a, t):
+            assert torch.equal(x, y)
+
+
 def test_c3_linemod_shape_matches_oracle(dev):
     """32 objects x 4096 dense correspondences, Gauss-Newton fast mode 3 iterations, tensor bounds (lib/test.py:91-96)."""
     from epropnp.levenberg_marquardt import LMSolver
