@@ -190,8 +190,32 @@ def test_sweeps_over_the_range_of_delta_and_z_min(backend, delta, z_min):
             assert bool((err <= bound).all()), (delta, z_min, err, bound)
         elif delta > 0:
             assert _rel(mine.cpu().double(), ref) <= GRAD_TOL, (delta, z_min, i, _rel(mine.cpu().double(), ref))
-        else:                         # delta = 0 is carried as 1e-15 (huber_scale): gradients of that size instead of exact zeros
-            assert mine.abs().max().item() <= 1e-8
+        else:                         # delta = 0 is carried as 1e-12 (huber_scale): gradients of that size instead of exact zeros
+            assert mine.abs().max().item() <= 1e-5
+
+
+def test_degenerate_objects_stay_finite_and_do_not_disturb_their_neighbours(backend):
+    """One batch with a healthy object, an object whose weights are all zero (adaptive delta = 0), one with a single
+    weighted point (pose undetermined), one with coordinates of 1e4 and one whose image points coincide (delta = 0 with
+    non-zero residuals): nothing turns NaN / inf, and every object but the undetermined one matches the oracle."""
+    B, N, S, K = 5, 100, 64, 2
+    prob = orc.make_problem(B, N, 6, seed=5)
+    prob['w2d'][1] = 0.0
+    prob['w2d'][2] = 0.0
+    prob['w2d'][2, 3] = 1.0
+    prob['x3d'][3] *= 1e4
+    prob['x2d'][4] = prob['x2d'][4, :1]
+    noise = orc.make_noise(B, S, K, 6, seed=6)
+    mine = run_layer(backend, prob, noise, 6, S, K, 3)
+    ref = orc.run_mc(prob, noise, 6, S, K, 3)
+    for k, v in mine.items():
+        assert bool(torch.isfinite(v).all()), k
+    ok = torch.tensor([0, 1, 3, 4])
+    assert ((mine['loss_obj'][ok] - ref['loss_obj'][ok]).abs() <= 1e-4 * ref['loss_obj'][ok].abs() + 2e-3).all()
+    assert (mine['pose_opt'][ok] - ref['pose_opt'][ok]).abs().max().item() <= 2e-2      # (object 3 sits 1e4 away)
+    assert (mine['pose_opt'][0] - ref['pose_opt'][0]).abs().max().item() <= POSE_TOL
+    for k in ('gx3d', 'gx2d', 'gw2d'):
+        assert _rel(mine[k][0], ref[k][0]) <= 5e-3, k
 
 
 @pytest.mark.parametrize('impl,nsplit', [('mfma', 1), ('mfma', 2), ('valu', 1)])
