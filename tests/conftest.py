@@ -43,3 +43,20 @@ def backend(request):
         emu.install(_emu_lib())
         yield torch.device('cpu')
         emu.uninstall()
+
+
+@pytest.fixture
+def poisoned_empty(monkeypatch):
+    """torch.empty / empty_like return NaN- (float) or -7- (integer) filled tensors and the ctypes binding is used, so that
+    every output element a kernel does not write shows up in the caller's finiteness / equality checks (the 4-DoF proposal
+    records once carried 18 slots of stale LDS that way)."""
+    real_empty, real_like = torch.empty, torch.empty_like
+
+    def poison(t):
+        if t.numel():
+            t.fill_(float('nan') if t.is_floating_point() else -7)
+        return t
+    monkeypatch.setattr(torch, 'empty', lambda *a, **k: poison(real_empty(*a, **k)))
+    monkeypatch.setattr(torch, 'empty_like', lambda *a, **k: poison(real_like(*a, **k)))
+    monkeypatch.setenv('EPROPNP_NO_TORCH_EXT', '1')
+    yield

@@ -40,13 +40,13 @@ def _sweep_cases(n, seed):
 
 
 @pytest.mark.parametrize('dof,normalize,rslm,plus,bounds,B,N,S,K,L', _sweep_cases(8, 11))
-def test_fused_forward_equals_composite_sweep(backend, monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L):
+def test_fused_forward_equals_composite_sweep(backend, monkeypatch, poisoned_empty, dof, normalize, rslm, plus, bounds, B, N, S, K, L):
     _fused_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dof,normalize,rslm,plus,bounds,B,N,S,K,L', _sweep_cases(40, 12))
-def test_fused_forward_equals_composite_sweep_gpu(monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L):
+def test_fused_forward_equals_composite_sweep_gpu(monkeypatch, poisoned_empty, dof, normalize, rslm, plus, bounds, B, N, S, K, L):
     import install as emu
     emu.uninstall()
     _fused_equals_composite(torch.device('cuda:0'), monkeypatch, dof, normalize, rslm, plus, bounds, B, N, S, K, L)

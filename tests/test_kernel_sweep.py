@@ -63,13 +63,13 @@ def _run(backend, monkeypatch, kind, args):
 
 
 @pytest.mark.parametrize('kind,args', _cases(14, 5, 600))
-def test_kernel_sweep_small(backend, monkeypatch, kind, args):
+def test_kernel_sweep_small(backend, monkeypatch, poisoned_empty, kind, args):
     _run(backend, monkeypatch, kind, args)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('kind,args', _cases(int(os.environ.get('EPROPNP_FUZZ_CASES', '84')), 6, 9000))
-def test_kernel_sweep_gpu(monkeypatch, kind, args):
+def test_kernel_sweep_gpu(monkeypatch, poisoned_empty, kind, args):
     import install as emu
     emu.uninstall()
     _run(torch.device('cuda:0'), monkeypatch, kind, args)

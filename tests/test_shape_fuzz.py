@@ -104,13 +104,13 @@ def _check(backend, dof, B, N, S, K, bounds, with_init, z_min, seed):
 
 
 @pytest.mark.parametrize('dof,B,N,S,K,bounds,with_init,z_min,seed', _cases(10, 1, 320, 128))
-def test_shape_sweep_small(backend, dof, B, N, S, K, bounds, with_init, z_min, seed):
+def test_shape_sweep_small(backend, poisoned_empty, dof, B, N, S, K, bounds, with_init, z_min, seed):
     _check(backend, dof, B, N, S, K, bounds, with_init, z_min, seed)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dof,B,N,S,K,bounds,with_init,z_min,seed', _cases(int(os.environ.get('EPROPNP_FUZZ_CASES', '80')), 2, 4096, 512))
-def test_shape_sweep_gpu(dof, B, N, S, K, bounds, with_init, z_min, seed):
+def test_shape_sweep_gpu(poisoned_empty, dof, B, N, S, K, bounds, with_init, z_min, seed):
     import install as emu
     emu.uninstall()
     _check(torch.device('cuda:0'), dof, B, N, S, K, bounds, with_init, z_min, seed)
