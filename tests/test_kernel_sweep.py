@@ -68,7 +68,7 @@ def test_kernel_sweep_small(backend, monkeypatch, poisoned_empty, kind, args):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kind,args', _cases(int(os.environ.get('EPROPNP_FUZZ_CASES', '84')), 6, 9000))
+@pytest.mark.parametrize('kind,args', _cases(int(os.environ.get('EPROPNP_FUZZ_CASES', '84')), int(os.environ.get('EPROPNP_FUZZ_SEED', '6')), 9000))
 def test_kernel_sweep_gpu(monkeypatch, poisoned_empty, kind, args):
     import install as emu
     emu.uninstall()
