@@ -146,3 +146,44 @@ def test_standalone_program_on_gpu(tmp_path, lib):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'STANDALONE objects=64' in out.stdout and 'finite=1' in out.stdout
+
+
+def _integration_stub():
+    """The ctypes stub INTEGRATION.md shows a reference maintainer (section B), executed as written against the in-tree library."""
+    import re
+    from epropnp import _hip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    block = [b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'def lm_solve_hip' in b]
+    assert len(block) == 1
+    ns = {}
+    exec(block[0].replace("C.CDLL('libepropnp_hip.so')", f'C.CDLL({_hip.LIB_PATH!r})'), ns)
+    return ns
+
+
+def test_integration_stub_matches_the_abi(lib):
+    from epropnp import _hip
+    ns = _integration_stub()
+    for mine, doc in ((_hip.Problem, ns['_Problem']), (_hip.LmParams, ns['_LmParams'])):
+        assert ctypes.sizeof(mine) == ctypes.sizeof(doc)
+        assert [(n, getattr(mine, n).offset) for n, _ in mine._fields_] == [(n, getattr(doc, n).offset) for n, _ in doc._fields_]
+
+
+@pytest.mark.gpu
+def test_integration_stub_runs_lm_on_the_gpu():
+    import install as emu
+    import epropnp_oracle as orc
+    from helpers import make_layer_objects
+    from epropnp import functional as F
+    from epropnp.levenberg_marquardt import LMSolver
+    emu.uninstall()
+    dev = torch.device('cuda:0')
+    ns = _integration_stub()
+    prob = orc.make_problem(6, 200, 6, seed=8)
+    p, cam, cf = make_layer_objects(prob, dev)
+    solver = LMSolver(dof=6, num_iter=4)
+    pose, cov, cost = ns['lm_solve_hip'](solver, p['x3d'], p['x2d'], p['w2d'], cam, cf, p['pose_init'], True, True, False)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6)
+    ref = F.lm_solve(hp, p['pose_init'], 4, with_pose_cov=True, with_cost=True)
+    for a, b in zip((pose, cov, cost), ref):
+        assert torch.equal(a, b)
