@@ -187,3 +187,32 @@ def test_integration_stub_runs_lm_on_the_gpu():
     ref = F.lm_solve(hp, p['pose_init'], 4, with_pose_cov=True, with_cost=True)
     for a, b in zip((pose, cov, cost), ref):
         assert torch.equal(a, b)
+
+
+def test_struct_layouts_of_the_header_match_the_ctypes_binding(tmp_path):
+    """sizeof / offsetof of every struct in include/epropnp_hip.h, printed by a C program, against the ctypes Structures of
+    epropnp/_hip.py (the C++ binding includes the header itself)."""
+    import shutil
+    import subprocess
+    from epropnp import _hip
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    pairs = (('epropnp_problem', _hip.Problem), ('epropnp_lm_params', _hip.LmParams),
+             ('epropnp_amis_params', _hip.AmisParams), ('epropnp_mc_params', _hip.McParams))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "epropnp_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines) + '\n')
+    exe = tmp_path / 'layout'
+    r = subprocess.run(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got[f'{cname}.{f}']) == getattr(cls, f).offset, (cname, f)
+    assert _hip.torch_ext() is None or _hip.torch_ext().mc_params_size() == ctypes.sizeof(_hip.McParams)
