@@ -122,3 +122,19 @@ def test_shape_sweep_gpu(poisoned_empty, dof, B, N, S, K, bounds, with_init, z_m
     import install as emu
     emu.uninstall()
     _check(torch.device('cuda:0'), dof, B, N, S, K, bounds, with_init, z_min, seed)
+
+
+def test_many_samples_small(backend, poisoned_empty):
+    """More samples per iteration than the workgroup has lanes (several samples per lane in the draw, base noise no longer
+    aliased onto the pose table)."""
+    _check(backend, 6, 1, 40, 640, 1, None, True, 0.1, 4242)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dof,B,N,S,K', [(6, 2, 64, 2048, 4), (4, 2, 100, 2400, 3), (6, 1, 40, 1024, 1), (6, 2, 33, 2400, 4),
+                                         (4, 3, 512, 1536, 2), (6, 3, 700, 2048, 4), (6, 2, 50, 3200, 16)])
+def test_many_samples_gpu(poisoned_empty, dof, B, N, S, K):
+    """... up to the LDS limit of the sampler state (6-DoF: 40 S + 96 S / K bytes + 2 KiB <= 160 KiB)."""
+    import install as emu
+    emu.uninstall()
+    _check(torch.device('cuda:0'), dof, B, N, S, K, None, True, 0.1, 4242 + S)
