@@ -2,9 +2,11 @@
 //
 // Same algorithm and LDS-resident sampler state as amis_forward_kernel (amis_kernels.hip); only the cost sweep
 // differs.  The projection h = (K R | K t) (X,Y,Z,1)^T of 16 poses x 16 points is ONE v_mfma_f32_16x16x4_f32 per
-// image row (x, y, z): exact f32 (a k-ordered fmaf chain), issued on the matrix pipe, which runs concurrently with
-// the VALU.  That removes the 9 FMAs of the ~21 VALU instructions per point-pose; what stays on the VALU is the
-// perspective divide, the weighted residual and the Huber kernel (2 transcendentals + ~12 simple ops).
+// image row (x, y, z): exact f32 (a k-ordered fmaf chain).  The fp32 MFMA has the VALU's FMA rate and does not overlap
+// with it (tools/ubench/mfma_valu_overlap.hip), so what it buys is not a second pipe but issue slots and registers:
+// three instructions per 16 x 16 tile instead of 9 FMAs per lane and row, operands that are 5 VGPRs per resident point
+// tile.  What stays on the VALU is the perspective divide, the weighted residual and the Huber kernel
+// (2 transcendentals + ~10 simple ops per point-pose).
 //   A operand (16 poses x 4): lane l holds row[pose l&15][k = l>>4]       <- LDS pose table, x | y | z rows
 //   B operand (4 x 16 points): lane l holds (X,Y,Z,1)[k = l>>4] of point l&15 <- LDS point table
 //   D (16 x 16): lane l holds poses 4*(l>>4)+r, r = 0..3, at point l&15   -> 4 point-poses per lane per tile
