@@ -1,5 +1,7 @@
 """The one-call forward (csrc/mc_forward.hip), the device-side status word, N beyond the register-resident limit and a
 non-default HuberPnPCost.eps."""
+import os
+
 import pytest
 import torch
 
@@ -45,7 +47,8 @@ def test_fused_forward_equals_composite_sweep(backend, monkeypatch, poisoned_emp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dof,normalize,rslm,plus,bounds,B,N,S,K,L', _sweep_cases(40, 12))
+@pytest.mark.parametrize('dof,normalize,rslm,plus,bounds,B,N,S,K,L',
+                         _sweep_cases(int(os.environ.get('EPROPNP_FUZZ_CASES', '40')), int(os.environ.get('EPROPNP_FUZZ_SEED', '12'))))
 def test_fused_forward_equals_composite_sweep_gpu(monkeypatch, poisoned_empty, dof, normalize, rslm, plus, bounds, B, N, S, K, L):
     import install as emu
     emu.uninstall()

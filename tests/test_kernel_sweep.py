@@ -30,10 +30,10 @@ def _cases(n, seed, n_max):
         elif kind == 'normal_eq':
             args = (dof, bounds, rng.choice((1, 3, 10)), max(N, 16))
         elif kind == 'rslm_oracle':
-            n = rng.choice((4, 8, 12, 16))
+            n = rng.choice((4, 8, 12, 16)) if dof == 4 else rng.choice((8, 12, 16))
             args = (dof, min(max(N, 2 * n), 512), rng.choice((4, 16, 40, 64)), n, bounds)
         elif kind == 'rslm_composite':
-            n = rng.choice((4, 8, 16))
+            n = rng.choice((4, 8, 16)) if dof == 4 else rng.choice((8, 12, 16))     # 4 points barely determine 6 DoF: chaotic
             args = (dof, min(max(N, 2 * n), 512), rng.choice((4, 20, 48)), n, bounds, rng.random() < 0.3)
         elif kind == 'prepare':
             args = (rng.choice(('softmax', 'mean_exp')), rng.random() < 0.6, rng.random() < 0.6, min(max(N, 16), 2048))
