@@ -111,14 +111,20 @@ struct MfmaShape {
 #ifndef PNP_FWD_MINW
 #define PNP_FWD_MINW 4
 #endif
-template <int DOF, bool BOUNDS, int NPT>
+// SPILL (NPT == 0 only): the per-sample sampler state -- samples, costs, mixture densities, log-weights, (pose_len + 3) S
+// floats per object -- lives in a global scratch buffer instead of LDS, for mc_samples beyond what 160 KiB hold
+// (the reference has no such limit).  Same code: the arrays are reached through pointers either way, every hand-over
+// between threads goes through a workgroup barrier, and a workgroup's global accesses share one L1.
+template <int DOF, bool BOUNDS, int NPT, bool SPILL = false>
 __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
                                                                   const float* __restrict__ noise,
                                                                   float* __restrict__ pose_samples,
                                                                   float* __restrict__ logweights,
-                                                                  float* __restrict__ proposals) {
+                                                                  float* __restrict__ proposals,
+                                                                  float* __restrict__ spill) {
+  static_assert(!SPILL || NPT == 0, "the spill variant streams the points");
   constexpr int PL = PoseLen<DOF>::value;
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
@@ -138,11 +144,11 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   float* ptab = smem;                 // [s16][12]   x | y | z rows of (K R | K t)          (16-B aligned)
   float* pB = ptab + 12 * s16;        // [NC][4]     (X, Y, Z, 1)        (NC = 0 in register mode)
   float* pW = pB + 4 * NC;            // [NC][4]     (wu, wv, -u wu, -v wv)
-  float* smp = pW + 4 * NC;           // [PL][S]
+  float* smp = SPILL ? spill + (size_t)b * (PL + 3) * S : pW + 4 * NC;       // [PL][S]
   float* cst = smp + PL * S;          // [S]
   float* mixl = cst + S;              // [S]
   float* lgw = mixl + S;              // [S]
-  float* cpart = lgw + S;             // [WPs][s16]
+  float* cpart = SPILL ? pW + 4 * NC : lgw + S;                              // [WPs][s16]
   float* prop = cpart + WPs * s16;    // [K][kPropStride]
   float* red = prop + K * kPropStride;   // [256]
   float* nzb = (s <= T) ? ptab : red + 256;   // [s][8] base noise drawn ahead; shares the pose table's LDS when one
@@ -375,11 +381,53 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
-  const size_t smem = sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (size_t)PL * S + 3 * (size_t)S +
-                                       (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256 +
-                                       (s <= 64 * waves ? 0 : 8 * (size_t)s));
-  if (smem > 160 * 1024) return fail(EPROPNP_EINVAL, "amis_forward: mc_samples %d needs %zu B of LDS (> 160 KiB)", S, smem);
+  auto lds_bytes = [&](bool spilled) {
+    return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (size_t)(PL + 3) * S) +
+                            (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256 +
+                            (s <= 64 * waves ? 0 : 8 * (size_t)s));
+  };
+  size_t smem = lds_bytes(false);
+  float* spill = nullptr;
+  if (smem > 160 * 1024) {
+    // the sampler state does not fit LDS: stream the points (NPT = 0, 8 waves) and keep the per-sample arrays in a global
+    // scratch buffer, allocated and released in stream order
+    waves = 8; npt = 0;
+    sh.chunk = ((d.N + 15) / 16) * 16;
+    if (sh.chunk > kChunk) sh.chunk = kChunk;
+    const int tiles = sh.s16 / 16;
+    while (waves > 1 && waves > tiles) waves /= 2;
+    smem = lds_bytes(true);
+    if (smem > 160 * 1024)
+      return fail(EPROPNP_EINVAL, "amis_forward: %d samples per iteration need %zu B of LDS (> 160 KiB)", s, smem);
+#ifndef EPROPNP_EMU
+    if (hipMallocAsync((void**)&spill, sizeof(float) * (size_t)(PL + 3) * S * d.B, st) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(EPROPNP_ELAUNCH, "amis_forward: mc_samples %d needs a %zu B scratch buffer and hipMallocAsync failed "
+                  "(stream capture?)", S, sizeof(float) * (size_t)(PL + 3) * S * d.B);
+    }
+#else
+    spill = (float*)malloc(sizeof(float) * (size_t)(PL + 3) * S * d.B);
+#endif
+  }
   const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
+  if (spill != nullptr) {
+    dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+      auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, 0, true>;
+#ifndef EPROPNP_EMU
+      if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+      PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals, spill);
+      return 0;
+    });
+    const int rc = check_launch("amis_forward_mfma_kernel (sampler state in global scratch)");
+#ifndef EPROPNP_EMU
+    (void)hipFreeAsync(spill, st);
+#else
+    free(spill);
+#endif
+    return rc;
+  }
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     return dispatch_npt(npt, [&](auto NPT) -> int {
       auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
@@ -387,7 +435,8 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-      PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals);
+      PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
+                 (float*)nullptr);
       return 0;
     });
   });

@@ -130,11 +130,19 @@ def test_many_samples_small(backend, poisoned_empty):
     _check(backend, 6, 1, 40, 640, 1, None, True, 0.1, 4242)
 
 
+def test_sampler_state_beyond_lds(backend, poisoned_empty):
+    """mc_samples whose per-sample state no longer fits the 160 KiB of LDS: the forward keeps it in a global scratch buffer
+    (the reference has no limit on mc_samples); the backward takes the all-VALU kernel beyond ~2700 poses."""
+    _check(backend, 6, 1, 24, 4800, 8, None, True, 0.1, 777)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('dof,B,N,S,K', [(6, 2, 64, 2048, 4), (4, 2, 100, 2400, 3), (6, 1, 40, 1024, 1), (6, 2, 33, 2400, 4),
-                                         (4, 3, 512, 1536, 2), (6, 3, 700, 2048, 4), (6, 2, 50, 3200, 16)])
+                                         (4, 3, 512, 1536, 2), (6, 3, 700, 2048, 4), (6, 2, 50, 3200, 16),
+                                         (6, 2, 64, 4096, 4), (6, 3, 300, 6000, 4), (4, 2, 100, 4000, 4), (6, 1, 2100, 3000, 2)])
 def test_many_samples_gpu(poisoned_empty, dof, B, N, S, K):
-    """... up to the LDS limit of the sampler state (6-DoF: 40 S + 96 S / K bytes + 2 KiB <= 160 KiB)."""
+    """... up to and beyond the LDS limit of the sampler state (6-DoF: 40 S + 96 S / K bytes + 2 KiB <= 160 KiB; past it
+    the state moves to a global scratch buffer)."""
     import install as emu
     emu.uninstall()
     _check(torch.device('cuda:0'), dof, B, N, S, K, None, True, 0.1, 4242 + S)
