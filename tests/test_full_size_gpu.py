@@ -175,6 +175,31 @@ def test_two_streams_run_independent_steps(dev):
             assert torch.equal(x, y)
 
 
+def test_layer_with_more_samples_than_lds_holds(dev):
+    """EProPnP6DoF(mc_samples=4096) end to end through the one-call forward and the loss backward (sampler state in the
+    global scratch buffer, all-VALU backward): finite, and its Monte-Carlo estimate agrees with a 2048-sample run of the
+    LDS-resident kernel within Monte-Carlo error."""
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    B, N = 64, 128
+    prob = device_problem(B, N, 6, dev, seed=55)
+    out = {}
+    for S in (2048, 4096):
+        leaves = [prob[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d')]
+        cam = PerspectiveCamera(cam_mats=prob['cam_mats'])
+        cf = AdaptiveHuberPnPCost(relative_delta=0.5)
+        cf.set_param(leaves[1].detach(), leaves[2])
+        o = layer6(S, 4, 3, seed=9).monte_carlo_forward(*leaves, cam, cf, pose_init=prob['pose_init'], force_init_solve=False)
+        lse = torch.logsumexp(o[4], 0) - torch.log(torch.tensor(float(S), device=dev))
+        (o[5] + lse).mean().backward()
+        assert o[3].shape == (S, B, 7) and bool(torch.isfinite(o[4]).all())
+        assert all(bool(torch.isfinite(t.grad).all()) for t in leaves)
+        out[S] = (lse.detach(), leaves[0].grad)
+    assert (out[2048][0] - out[4096][0]).abs().mean().item() < 0.05
+    g2, g4 = out[2048][1], out[4096][1]
+    assert ((g2 - g4).norm() / g4.norm()).item() < 0.1
+
+
 def test_c3_linemod_shape_matches_oracle(dev):
     """32 objects x 4096 dense correspondences, Gauss-Newton fast mode 3 iterations, tensor bounds (lib/test.py:91-96)."""
     from epropnp.levenberg_marquardt import LMSolver
