@@ -58,10 +58,13 @@ __device__ __forceinline__ float clamp_below(float x, float lo) {
 // Residuals in units of the object's Huber threshold: the weights are pre-multiplied by 1 / delta.  The factor is capped at
 // 1e12 so that a zero or denormal threshold (degenerate input: all image points equal, all weights zero) neither divides
 // by zero nor overflows the squared norm for residuals below 1e7; min(rho, delta) is then min(rho, 1e-12), i.e. a cost
-// below 1e-12 rho where the reference has exactly 0.
+// below 1e-12 rho where the reference has exactly 0.  The threshold is capped at 1e12 on the large side as well: a huge or
+// infinite delta (the Huber kernel switched off) would make 1 / delta zero and delta^2 infinite, 0 * inf = NaN costs;
+// below rho = 1e12 pixels min(rho, delta) never binds, so the capped threshold computes the same pure quadratic.
 struct HuberScale { float inv_delta, delta, delta_sq; };
 __device__ __forceinline__ HuberScale huber_scale(float delta) {
   HuberScale h;
+  delta = fminf(delta, 1e12f);
   h.inv_delta = fminf(1.0f / delta, 1e12f);
   h.delta = (h.inv_delta < 1e12f) ? delta : 1e-12f;
   h.delta_sq = h.delta * h.delta;

@@ -367,7 +367,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   if (prob->dof == 4 && npt == 16) npt = 0;
   // few objects (less than two waves per SIMD otherwise): spread an object over 8 waves (B = 32: 86 vs 93 us)
   if (d.B < 512 && waves == 4 && npt == 8) { waves = 8; npt = 4; }
-  { int ov[2]; if (env_ints("EPROPNP_FWD_MFMA", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 0 || ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8 || ov[1] == 12 || ov[1] == 16) && (ov[1] == 0 || ov[0] * ov[1] >= ptiles)) { waves = ov[0]; npt = ov[1]; } }
+  { int ov[2]; if (env_ints("EPROPNP_FWD_MFMA", ov, 2) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && (ov[1] == 0 || ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8 || ov[1] == 12 || ov[1] == 16) && (ov[1] == 0 || ov[0] * ov[1] >= ptiles)) { waves = ov[0]; npt = ov[1]; } }
   if (npt == 0) {       // points stream through LDS in chunks; waves split the pose tiles
     sh.chunk = ((d.N + 15) / 16) * 16;
     if (sh.chunk > kChunk) sh.chunk = kChunk;

@@ -82,6 +82,7 @@ struct McPoseLoss : public torch::autograd::Function<McPoseLoss> {
           "epropnp_mc_loss_forward");
     ctx->save_for_backward({lw, lse, loss});
     ctx->saved_data["stream"] = stream;
+    ctx->saved_data["has_cost_target"] = ct.defined();
     ctx->set_materialize_grads(false);
     return loss;
   }
@@ -92,7 +93,8 @@ struct McPoseLoss : public torch::autograd::Function<McPoseLoss> {
     const Tensor g = grads[0].contiguous();
     const int64_t S = lw.size(0), B = lw.size(1);
     Tensor glw = torch::empty_like(lw), gct;
-    if (ctx->needs_input_grad(1)) gct = torch::empty_like(g);
+    // needs_input_grad indexes the edges of the tensor inputs actually passed: without a cost_target there is no edge 1
+    if (ctx->saved_data["has_cost_target"].toBool() && ctx->needs_input_grad(1)) gct = torch::empty_like(g);
     check(epropnp_mc_loss_backward(fptr(lw), fptr(lse), fptr(loss), fptr(g), (int32_t)S, (int32_t)B, fptr(glw), fptr(gct),
                                    (void*)ctx->saved_data["stream"].toInt()), "epropnp_mc_loss_backward");
     return {glw, gct, Tensor()};

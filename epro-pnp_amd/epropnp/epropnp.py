@@ -111,7 +111,8 @@ class EProPnPBase(torch.nn.Module):
         x3d (B,N,3), x2d (B,N,2), w2d (B,N,2); pose_init (B,4|7) optional (the target pose for the MC loss).
         fp32 tensors on a HIP device only (no CPU / fp64 path); differentiable w.r.t. x3d, x2d, w2d and a tensor-valued
         cost_fun.delta -- not w.r.t. pose_init or camera.cam_mats (a warning is issued if those require grad).
-        Limits: mc_samples * (pose_len + 3) * 4 B + tables must fit the 160 KiB of LDS (6-DoF: mc_samples <~ 3700); the
+        Limits: the samples of ONE iteration (mc_samples / num_iter) must fit the LDS pose table (<~ 1500); the total
+        mc_samples is unbounded (the sampler state moves from LDS to a global scratch buffer beyond ~2500).  The
         RSLM initialiser's one-launch kernel takes <= 16 points per proposal and <= 512 points per object (beyond that
         the composite of the same kernels runs); any num_pts otherwise (LM streams beyond 8192 points).
         Returns: pose_opt (B,4|7), cost (B,)|None, pose_opt_plus (B,4|7)|None, pose_samples (S,B,4|7),

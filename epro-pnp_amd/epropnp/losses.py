@@ -43,8 +43,11 @@ class MonteCarloPoseLoss(nn.Module):
                 reduction_override=None):
         if self.training:
             with torch.no_grad():
-                nf = torch.as_tensor(norm_factor, dtype=torch.float, device=self.norm_factor.device)
-                self.norm_factor.mul_(1 - self.momentum).add_(self.momentum * _world_mean(nf))
+                if hasattr(norm_factor, 'world_mean'):      # sharding.ObjectExchange: the scalar rode in the step's ONE
+                    nf = norm_factor.world_mean().to(self.norm_factor.device)       # collective (no all-reduce here)
+                else:
+                    nf = _world_mean(torch.as_tensor(norm_factor, dtype=torch.float, device=self.norm_factor.device))
+                self.norm_factor.mul_(1 - self.momentum).add_(self.momentum * nf)
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
         loss = monte_carlo_pose_loss(pose_sample_logweights, cost_target)

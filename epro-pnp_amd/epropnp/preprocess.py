@@ -146,9 +146,19 @@ def prepare_dense_correspondences(noc_map, dim, w2d_logit_map, scale, box, sampl
     assert (noc_map is None) == (dim is None)
     from . import _hip
     ts = [t for t in (noc_map, dim, w2d_logit_map, scale, box) if t is not None]
-    assert w2d_logit_map.dim() == 4 and w2d_logit_map.size(0) > 0 and sample_inds.size(1) > 0
+    assert w2d_logit_map.dim() == 4, 'w2d_logit_map must be (num_obj, 2, H, W)'
     if not _hip.on_hip_path(*ts) or sample_inds.device != w2d_logit_map.device:
         raise RuntimeError('prepare_dense_correspondences: fp32 tensors on a HIP device required (no CPU fallback)')
+    if w2d_logit_map.size(0) == 0 or sample_inds.size(1) == 0:
+        # empty detection batch / empty pixel subset: nothing to launch; correctly shaped empty tensors that stay connected to
+        # autograd, as prepare_correspondences does (DDP callers rely on it, deform_pnp_head.py:913-920)
+        B, N = w2d_logit_map.size(0), sample_inds.size(1)
+        ix = sample_inds.to(torch.int64)
+        gather = lambda m: m.flatten(2).gather(2, ix[:, None, :].expand(-1, m.size(1), -1)).transpose(1, 2)
+        w2d = gather(w2d_logit_map) if scale is None else gather(w2d_logit_map) * scale.unsqueeze(-2)
+        x2d = w2d_logit_map.new_zeros((B, N, 2))
+        x3d = None if noc_map is None else gather(noc_map) * dim.unsqueeze(-2)
+        return x3d, x2d, w2d
     out = _PrepareDense.apply(noc_map, dim, w2d_logit_map, scale, box, sample_inds, MODES[mode])
     return (None,) + tuple(out) if noc_map is None else out
 

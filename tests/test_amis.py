@@ -145,12 +145,14 @@ def test_backward_matches_autograd_of_oracle_at_fixed_samples(backend, monkeypat
             assert _rel(mine.cpu(), ref) <= 2e-4, (dof, bounds, _rel(mine.cpu(), ref))
 
 
-@pytest.mark.parametrize('delta,z_min', [(1e-4, 0.1), (3e3, 0.1), (0.7, 0.0), (0.7, 1e-6), (0.7, 4.5), (0.0, 0.1)])
+@pytest.mark.parametrize('delta,z_min', [(1e-4, 0.1), (3e3, 0.1), (0.7, 0.0), (0.7, 1e-6), (0.7, 4.5), (0.0, 0.1),
+                                         (1e20, 0.1), (float('inf'), 0.1)])
 def test_sweeps_over_the_range_of_delta_and_z_min(backend, delta, z_min):
     """Both AMIS sweeps carry the residuals in units of the Huber threshold (weights pre-divided by delta, min(rho, delta)
     through a clamp modifier) and take the depth clamp / its gradient mask from integer-max and clamped-fma tricks that
     assume z_min >= 0: cover a tiny and a huge threshold, z_min = 0 / tiny / beyond most of the points, and delta = 0
-    (cost identically 0: finite outputs, no NaN from 1 / delta)."""
+    (cost identically 0: finite outputs, no NaN from 1 / delta), and a threshold of 1e20 / inf (the Huber kernel switched off:
+    1 / delta would be 0 and delta^2 inf; huber_scale caps the threshold at 1e12, where min(rho, delta) never binds)."""
     from epropnp import functional as F
     from epropnp.camera import PerspectiveCamera
     from epropnp.cost_fun import HuberPnPCost
@@ -171,6 +173,8 @@ def test_sweeps_over_the_range_of_delta_and_z_min(backend, delta, z_min):
     samples, logw, props = samples.cpu(), logw.cpu(), props.cpu()
     assert bool(torch.isfinite(logw).all())
     x3d, x2d, w2d, dl = (prob[k].double().clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta'))
+    if delta == float('inf'):     # autograd of where(rho <= delta, ., delta rho - delta^2 / 2) is inf * 0 = NaN at delta = inf (in
+        dl = torch.full((B,), 1e20, dtype=torch.float64, requires_grad=True)    # the reference too): same quadratic at 1e20
     ocam = orc.Cam(prob['cam_mats'].double(), z_min)
     cost = orc.evaluate(x3d, x2d, w2d, samples.double(), ocam, dl, want_cost=True)[1]
     expect = -cost.detach().float() - _mixture_logq(samples, props, dof, K)
@@ -181,7 +185,11 @@ def test_sweeps_over_the_range_of_delta_and_z_min(backend, delta, z_min):
     grads = F.amis_backward(hp, samples.to(backend), g_logw.to(backend), None, None)
     for i, (mine, ref) in enumerate(zip(grads, (x3d.grad, x2d.grad, w2d.grad, dl.grad))):
         assert bool(torch.isfinite(mine).all())
-        if i == 3:
+        if i == 3 and delta > 1e12:
+            # every residual is an inlier: d cost / d delta is exactly 0 in the reference; the kernel leaves rounding residue
+            # of rho in units of the capped threshold
+            assert mine.abs().max().item() <= 1e-7 * 1e12 * N * S * 1e-6, (delta, mine)
+        elif i == 3:
             # d cost / d delta = sum a max(rho - delta, 0): does not vanish at delta = 0, and is exactly 0 in the reference
             # when every residual is an inlier (delta = 3e3), where the kernel's fused rho - min(rho, delta) leaves the
             # rounding error of rho (<= ulp / 2, rho <= delta) per point-pose instead

@@ -57,6 +57,13 @@ def _worker(rank, world, port, dof, ret):
         loss = MonteCarloPoseLoss(init_norm_factor=1.0, momentum=0.5)
         loss(logw_l, torch.zeros(hi - lo), torch.tensor(float(rank + 1)))       # world mean of (1, 2) = 1.5
         ok = ok and abs(loss.norm_factor.item() - 1.25) < 1e-6
+        # the same exchange as ONE collective: pose outputs and the loss's norm_factor scalar in one payload
+        ex = sharding.ObjectExchange(B).start(pose_l, torch.tensor(float(rank + 1)))
+        loss1 = MonteCarloPoseLoss(init_norm_factor=1.0, momentum=0.5)
+        loss1(logw_l, torch.zeros(hi - lo), ex)
+        ok = ok and abs(loss1.norm_factor.item() - 1.25) < 1e-6 and torch.equal(ex.objects(), pose)
+        ex.start(logw_l.t().contiguous())                               # reuse with another shape, no scalars
+        ok = ok and torch.equal(ex.objects().t(), logw)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -132,26 +139,43 @@ def test_object_sharding_all_gather_nccl():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('config', ['C4', 'C5'])
-def test_bench_multi_gpu_harness_under_torchrun(config):
-    """The command the driver launches on an 8-GPU node, here with one rank: bench.py --config C4 (600 objects split over
-    the ranks + all_gather_into_tensor of the pose outputs inside the timed region) / C5 (disjoint shards) under
-    torch.distributed.run on the nccl backend."""
+@pytest.mark.parametrize('form', ['torchrun', 'plain'])
+@pytest.mark.parametrize('config', ['C2', 'C4', 'C5'])
+def test_bench_multi_gpu_harness(config, form):
+    """The multi-GPU bench command in both forms -- `python -m torch.distributed.run ... bench.py --gpus N` and the plain
+    `python bench.py --gpus N`, which spawns its N ranks itself (the launch model of
+    EPro-PnP-Det/tools/train.py:123 replaced) -- on the nccl backend: 2 ranks when the box has two GPUs, one rank (through
+    the same launcher route, BENCH_SELF_LAUNCH=1) otherwise.  C4 = 600 objects split over the ranks + ONE
+    all_gather_into_tensor per step on a side stream inside the timed region, C2 / C5 = disjoint shards."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    extra = ['--objects', '512'] if config == 'C5' else []          # a slice of the 8192-object shard: keeps the test short
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
-           '--config', config, '--no-cpu-baseline', '--no-hipgraph'] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    extra = {'C5': ['--objects', '512'], 'C2': ['--objects', '256'], 'C4': []}[config]     # slices keep the test short
+    tail = [os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '3', '--warmup', '1', '--config', config,
+            '--no-cpu-baseline', '--no-hipgraph'] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    if form == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+               '127.0.0.1', '--master-port', str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+        env['BENCH_SELF_LAUNCH'] = '1'
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    assert line['n_gpus'] == 1 and line['config']['name'] == config and line['value'] > 0
-    assert line['roofline']['single_sweep']['achieved'] > 0
+    assert line['n_gpus'] == n and line['config']['name'] == config and line['value'] > 0
+    rk = line['ranks']
+    assert rk['launcher'] == 'torch.distributed.run' and rk['process_group'] == 'nccl'
+    assert rk['rccl_world_size'] == n and rk['all_reduce_of_ones'] == float(n) and sorted(rk['devices']) == list(range(n))
+    assert len(rk['ms_per_step_per_rank']) == n and rk['ms_per_step_min'] <= rk['ms_per_step_max']
+    assert line['roofline']['achieved'] > 0 and 'IC-cold' in line['roofline']['cache_state']
     if config == 'C4':
         assert line['scaling'] == 'strong' and line['config']['objects_total'] == 600
-        assert line['collective']['backend'].startswith('nccl') and line['collective']['bytes_per_rank'] == 600 * 4 * 4
+        assert line['collective']['backend'].startswith('nccl') and line['collective']['bytes_per_rank'] == 600 * 4 * 4 + 4
+        assert line['collective']['gathered_equals_local_bitwise'] is True
     else:
         assert line['scaling'] == 'weak' and 'collective' not in line

@@ -142,6 +142,24 @@ def test_prepare_matches_reference_fixtures(backend):
     torch.testing.assert_close(w2d.cpu(), d['w2d'], rtol=2e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('B,N', [(0, 8), (3, 0)])
+def test_prepare_dense_empty_batch_keeps_autograd(backend, B, N):
+    """An empty detection batch / empty pixel subset returns correctly shaped empty tensors connected to autograd (the
+    non-dense variant did already): DDP callers back-propagate through them (deform_pnp_head.py:913-920)."""
+    from epropnp.preprocess import prepare_dense_correspondences
+    H = W = 4
+    noc = torch.randn(B, 3, H, W, device=backend, requires_grad=True)
+    dim = torch.randn(B, 3, device=backend, requires_grad=True)
+    lg = torch.randn(B, 2, H, W, device=backend, requires_grad=True)
+    sc = torch.randn(B, 2, device=backend, requires_grad=True)
+    box = torch.zeros(B, 3, device=backend)
+    inds = torch.zeros(B, N, dtype=torch.int64, device=backend)
+    x3d, x2d, w2d = prepare_dense_correspondences(noc, dim, lg, sc, box, inds)
+    assert x3d.shape == (B, N, 3) and x2d.shape == (B, N, 2) and w2d.shape == (B, N, 2)
+    (x3d.sum() + w2d.sum()).backward()
+    assert all(t.grad is not None and t.grad.shape == t.shape for t in (noc, dim, lg, sc))
+
+
 def test_prepare_refuses_cpu_tensors():
     import install as emu
     from epropnp.preprocess import prepare_correspondences

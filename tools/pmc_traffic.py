@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""HBM bytes per launch from rocprofv3 PMC passes -> profiles/r02_pmc_traffic.json (read by bench.py's `roofline.traffic`).
+"""HBM bytes per launch from rocprofv3 PMC passes -> profiles/r03_pmc_traffic.json (read by bench.py's `roofline.traffic`).
 
     tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <shape key> [out.json]
 
@@ -32,7 +32,7 @@ def averages(d, counter):
 def main():
     fetch, write, key = averages(sys.argv[1], 'FETCH_SIZE'), averages(sys.argv[2], 'WRITE_SIZE'), sys.argv[3]
     out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                             'profiles', 'r02_pmc_traffic.json')
+                                                             'profiles', 'r03_pmc_traffic.json')
     table = json.load(open(out)) if os.path.exists(out) else {}
     rec = {}
     for k in sorted(set(fetch) & set(write)):
