@@ -21,8 +21,8 @@ One "step" = one pass of the hot path over one batch of synthetic objects:
   C4 (EPro-PnP-Det nuScenes shape): ONE batch of 600 objects x N=128, 4-DoF, RSLM(16,64,3) + LM 5 + AMIS S=128/K=4,
       normalize=True, split contiguously over the ranks (75/GPU at 8: `sharding.shard_objects`), fwd+bwd on the shard,
       with ONE RCCL `all_gather_into_tensor` per step (`sharding.ObjectExchange`: the pose outputs and the detection
-      loss's norm_factor scalar in the same payload) issued on a side stream right after the forward and consumed after
-      the backward -- INSIDE the timed region: strong scaling.  The line reports the collective's share of the step.
+      loss's norm_factor scalar in the same payload) issued in stream order right after the forward -- INSIDE the timed
+      region: strong scaling.  The line reports the collective's share of the step.
 fp32, inputs resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` is the Jacobian sweep: the fused LM kernel credited one 28 B/point read per
@@ -208,9 +208,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hipgraph', action='store_true', help='skip the informational hipGraph replay measurement')
     ap.add_argument('--cpu-sample', type=int, default=64)
-    ap.add_argument('--launch', choices=['eager', 'graph'], default='eager',
+    ap.add_argument('--launch', choices=['auto', 'eager', 'graph'], default='auto',
                     help="'graph': the rank's whole step (RCCL exchange included) captured once into a hipGraph; the timed "
-                         "region replays it (fresh samples per replay).  Default: eager launches")
+                         "region replays it (fresh samples per replay).  'auto' (default): graph for the launch-bound Det "
+                         "step (C4: 0.2 ms of kernels behind ~25 launches), eager for the GPU-bound C2 / C5")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ('objects', 'points', 'samples', 'amis_iters', 'lm_iters'):
@@ -276,7 +277,7 @@ def main():
     # (epropnp_profile_*): the forward is one host call (epropnp_monte_carlo_forward), its stages are not visible from here
     coll_events = []
     gathered, layer_last_pose = {}, {}
-    # C4: the step's ONE collective (pose outputs + the loss's norm_factor scalar), on a side stream (sharding.ObjectExchange)
+    # C4: the step's ONE collective (pose outputs + the loss's norm_factor scalar in one payload, sharding.ObjectExchange)
     exchange = sharding.ObjectExchange(total, force_collective=dist is not None) if strong else None
     nf_scale = 1.0 / max(2 * B, 1)
 
@@ -290,16 +291,16 @@ def main():
             loss = monte_carlo_pose_loss(logw, cost_init).mean()       # Monte-Carlo pose (KL) loss, NaN -> 0
             loss.backward()
             return loss
-        # Det step.  pose_opt is final here: its all-gather (with the rank's norm_factor input in the same payload) starts
-        # now on a side stream and runs under the loss and the backward; the loss takes the world mean out of the exchange
-        # (a device-side event wait), the gathered poses are picked up after backward().
+        # Det step.  pose_opt is final here: its all-gather (with the rank's norm_factor input in the same payload) is issued
+        # now, in stream order (sharding.ObjectExchange: why not a side stream); the loss takes the world mean out of the
+        # exchange, the gathered poses are picked up after backward().
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         exchange.start(pose_opt, w2d.detach().sum() * nf_scale)
         layer_last_pose['pose_opt'] = pose_opt.detach()
         if timed:
-            e1.record()                 # main-stream time of issuing the exchange (packing + RCCL enqueue run on the side stream)
+            e1.record()                 # GPU time of the pack kernel + the RCCL kernel in stream order
             coll_events.append((e0, e1))
         # detection loss: per-object weights, avg_factor = the whole batch, world-mean EMA of norm_factor
         loss = loss_mod(logw, cost_init, exchange, weight=obj_weight, avg_factor=float(total))
@@ -323,48 +324,59 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
-    prof_steps = args.steps
-    if args.launch == 'graph':
-        # The whole rank step -- set_param, forward, the exchange on its side stream, loss, backward -- captured once and
-        # replayed.  Per-kernel HIP events cannot sit inside a graph: the stage times come from `prof_steps` eager steps
-        # just before the capture (outside the timed region).  The Philox call counter lives in device memory and is
-        # advanced in-stream, so every replay draws fresh samples.
-        prof_steps = 10
+    launch = args.launch if args.launch != 'auto' else ('graph' if args.config == 'C4' else 'eager')
+    launch_note = None
+    # Per-kernel stage times: HIP events around every kernel stage inside the library.  In the GPU-bound configurations
+    # they sit in the timed region itself (they cost nothing there: 1.76 ms per C2 step with or without); in the
+    # launch-bound Det step their ~20 event records per step would slow the host-bound eager step by 40 % and cannot sit in a
+    # graph at all, so there the stage times come from `prof_steps` eager steps just before the timed region.
+    prof_in_region = launch == 'eager' and args.config != 'C4'
+    prof_steps = args.steps if prof_in_region else 10
+    if not prof_in_region:
         fence()
         _hip.profile(enable=True, reset=True)
         for _ in range(prof_steps):
             step(timed=True)
         fence()
         _hip.profile(enable=False)
-        layer.enable_graph_safe_rng(dev)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        fence()
-        graph, held = torch.cuda.CUDAGraph(), {}
-        with torch.cuda.graph(graph):
-            held['loss'] = step()
-        for _ in range(max(args.warmup, 3)):
-            graph.replay()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            graph.replay()
-        fence()
-        elapsed = time.perf_counter() - t0
-        loss = held['loss']
-    else:
-        fence()
+    graph, held = None, {}
+    if launch == 'graph':
+        # The whole rank step -- set_param, forward, the exchange, loss, backward -- captured once and replayed.  The Philox
+        # call counter lives in device memory and is advanced in-stream, so every replay draws fresh samples.
+        try:
+            layer.enable_graph_safe_rng(dev)
+            # The leaves' AccumulateGrad nodes were created by the eager steps above on the default stream and are kept alive
+            # by the autograd graph behind cost_fun.delta (set_param builds the new graph before the old one is released): a
+            # backward under capture would have to synchronise with the default stream, which a capture cannot.  Drop that
+            # graph so that the warm-up below creates fresh nodes on a side stream.
+            cost_fun.delta = None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            fence()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                held['loss'] = step()
+        except Exception as e:          # a capture that is refused falls back to eager launches, and the line says so
+            graph, launch = None, 'eager'
+            launch_note = 'hipGraph capture failed, eager launches timed instead: ' + repr(e)[:200]
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else (lambda: held.__setitem__('loss', step(timed=prof_in_region)))
+    for _ in range(3 if graph is not None else 0):
+        run()
+    fence()
+    if prof_in_region:
         _hip.profile(enable=True, reset=True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step(timed=True)
-        fence()
-        elapsed = time.perf_counter() - t0
-        _hip.profile(enable=False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    fence()
+    elapsed = time.perf_counter() - t0
+    _hip.profile(enable=False)
+    loss = held['loss']
     loss_val = float(loss.detach())
     my_ms = elapsed / args.steps * 1e3
     ranks = {'launcher': 'torch.distributed.run' if 'RANK' in os.environ else 'single process', 'process_group': None}
@@ -396,7 +408,7 @@ def main():
     if strong:          # the collective's cost on the critical path, measured: the same steps without the exchange
         exchange.disabled = True
         run = step
-        if args.launch == 'graph':
+        if graph is not None:
             graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph2):
                 step()
@@ -437,14 +449,16 @@ def main():
         ne_gbs = ne_bytes / (ne_mean_ms * 1e-3) / 1e9
         ne_traffic, ne_src = measured_traffic('normal_equations_kernel', shape_key) if shape_key else (None, None)
         names = {'C2': 'C2 batched synthetic', 'C5': 'C5 stress (one shard per GPU)', 'C4': 'C4 EPro-PnP-Det nuScenes shape'}
-        par = (f'one batch of {total} objects split x{world} ({B} on rank 0), all_gather_into_tensor of pose outputs + '
-               f'world-mean of norm_factor inside the step') if strong else f'objects sharded x{world}, no data-path collective'
+        par = (f'one batch of {total} objects split x{world} ({B} on rank 0), ONE all_gather_into_tensor (pose outputs + '
+               f'norm_factor) inside the step') if strong else f'objects sharded x{world}, no data-path collective'
         out = {
             'metric': f'PnP instances/sec (fwd+bwd, N={N} pts, {S} samples)',
             'value': round(value, 1), 'unit': 'instances/s', 'n_gpus': world, 'ranks': ranks, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': cfg['scaling'],
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'device_spinup_steps': SPINUP_STEPS,
-            'launch': 'eager' if args.launch == 'eager' else 'hipGraph replay of the whole rank step (captured once; fresh samples per replay)',
+            'launch': 'eager' if launch == 'eager' else 'hipGraph replay of the whole rank step, RCCL exchange included (captured once; fresh samples per replay)',
+            'launch_note': launch_note,
+            'kernel_ms_source': 'HIP events inside the library over the timed region' if prof_in_region else f'HIP events inside the library over {prof_steps} eager steps before the timed region',
             'config': {'workload': f'{names[args.config]}: {B} objects/GPU x N={N} points, S={S} MC samples, '
                                    f'K={K} AMIS iters, L={L} LM iters, EProPnP{dof}DoF fwd+bwd'
                                    + (', RSLM(16,64,3) init, normalize=True, Det loss' if args.config == 'C4' else ''),
@@ -484,10 +498,10 @@ def main():
         if strong:
             c_ms = sum(a.elapsed_time(b) for a, b in coll_events) / max(len(coll_events), 1)
             out['collective'] = {'op': 'ONE all_gather_into_tensor per step: pose_opt chunk + the norm_factor scalar of the '
-                                       'detection loss in the same payload, issued on a side stream after the forward, '
-                                       'consumed after backward (sharding.ObjectExchange)',
-                                 'backend': 'nccl (RCCL)' if dist is not None else 'none (single process)',
-                                 'issue_ms_on_main_stream': round(c_ms, 4),
+                                       'detection loss in the same payload, issued in stream order right after the forward '
+                                       '(sharding.ObjectExchange)',
+                                 'backend': 'nccl (RCCL)' if dist is not None else 'none (single process)', 'route': exchange.route,
+                                 'gpu_ms_in_stream_order': round(c_ms, 4),
                                  # A/B in this run: the same K steps with the exchange switched off (every rank, below)
                                  'ms_per_step_without_exchange': round(ms_without, 4),
                                  'share_of_step': round(max(0.0, ms - ms_without) / ms, 4),

@@ -204,6 +204,9 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   const int g4 = (lane >> 4) * 4, col = lane & 15, kk = lane >> 4;
   PNP_PHASE(0);
   for (int it = 0; it < K; ++it) {
+#ifdef PNP_TUNING
+    if (!(a.ablate & 32) || it == 0)      // bit5: the sweep re-uses the first iteration's pose table (what the sweep alone costs)
+#endif
     amis_draw<DOF>(cx, p, a, it, Kc, noise, pose_samples);
     __syncthreads();
     PNP_PHASE(1);

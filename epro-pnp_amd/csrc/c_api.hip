@@ -83,6 +83,12 @@ int epropnp_evaluate_cost(const epropnp_problem* prob, const float* poses, int32
   return pnp::launch_evaluate_cost(prob, poses, num_poses, cost, (hipStream_t)stream);
 }
 
+int epropnp_cost_pose_cam_grad(const epropnp_problem* prob, const float* poses, const float* weights, int32_t num_poses,
+                               int32_t m_pose, float* grad_h_outer, float* grad_cam, void* stream) {
+  pnp::StageScope prof_("cost_pose_cam_grad", (hipStream_t)stream);
+  return pnp::launch_cost_pose_cam_grad(prob, poses, weights, num_poses, m_pose, grad_h_outer, grad_cam, (hipStream_t)stream);
+}
+
 int epropnp_normal_equations(const epropnp_problem* prob, const float* pose, int32_t clip_jac, float* jtj, float* jtr,
                              float* cost, void* stream) {
   pnp::StageScope prof_("normal_equations", (hipStream_t)stream);

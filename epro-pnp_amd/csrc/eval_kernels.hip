@@ -133,6 +133,90 @@ __global__ __launch_bounds__(MAXW * 64) void evaluate_cost_kernel(Problem p, con
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// Gradients of  sum_j a_j cost(pose_j)  w.r.t. the camera intrinsics and (for one of the poses) w.r.t. the pose -- what the
+// reference's autograd records for cost_init = evaluate_pnp(pose=pose_init) and for the AMIS log-weights w.r.t.
+// camera.cam_mats and pose_init (epropnp/epropnp.py:121-124,139-169; common.py:90-99; camera.py:21-30,81-93: project_b,
+// depth clamp, projection clamp with torch.clamp's masks; cost_fun.py:8-12,45-61: Huber).  With h = K y, y = R X + t and
+// g_h = d cost / d h per point-pose:
+//     d/dK = sum_j a_j sum_n g_h y^T                                   -> out_gk (B,3,3)
+//     M    = a_m sum_n g_h (X,Y,Z,1)^T  for the pose m = m_pose        -> out_m  (B,3,4)
+// from which d/dt_m = K^T M[:,3] and d/dR_m = K^T M[:,:3] (host side, epropnp/functional.py:cost_pose_grad).  A rarely
+// taken path (nothing in the reference's training loops differentiates w.r.t. these): a plain VALU sweep, lane = point,
+// IEEE divide / sqrt as on the cost_init path; poses with zero weight are skipped.
+template <int DOF, bool BOUNDS>
+__global__ __launch_bounds__(256) void cost_pose_cam_grad_kernel(Problem p, const float* __restrict__ poses,
+                                                                 const float* __restrict__ weights, int P, int m_pose,
+                                                                 float* __restrict__ out_m, float* __restrict__ out_gk) {
+  constexpr int PL = PoseLen<DOF>::value;
+  __shared__ float scratch[21 * 4];
+  const int b = object_of_block(p.B);
+  if (b >= p.B) return;
+  float K[9], delta;
+  Bounds bd;
+  load_camera<BOUNDS>(p, b, K, bd, delta);
+  float acc[21];          // [0..11] M, [12..20] d/dK
+#pragma unroll
+  for (int i = 0; i < 21; ++i) acc[i] = 0.f;
+  for (int j = 0; j < P; ++j) {
+    const float a = (weights != nullptr) ? weights[(size_t)j * p.B + b] : 1.0f;
+    if (a == 0.f) continue;                                  // wave-uniform
+    float R[9], ps[PL];
+#pragma unroll
+    for (int i = 0; i < PL; ++i) ps[i] = poses[((size_t)j * p.B + b) * PL + i];
+    pose_to_rot<DOF>(ps, R);
+    float KR[9], Kt[3];
+    compose_kr_kt(K, R, ps, KR, Kt);
+    const bool want_m = (j == m_pose);
+    for (int n = (int)threadIdx.x; n < p.N; n += (int)blockDim.x) {
+      const Point q = load_point(p, b, n);
+      const float hx = KR[0] * q.X + KR[1] * q.Y + KR[2] * q.Z + Kt[0];
+      const float hy = KR[3] * q.X + KR[4] * q.Y + KR[5] * q.Z + Kt[1];
+      const float hz = KR[6] * q.X + KR[7] * q.Y + KR[8] * q.Z + Kt[2];
+      const bool front = hz >= p.z_min;                    // torch.clamp(min=) passes the gradient where x >= min
+      const float z = front ? hz : p.z_min;
+      const float ppx = hx / z, ppy = hy / z;
+      float px = ppx, py = ppy;
+      if (BOUNDS) {
+        px = fminf(fmaxf(px, bd.lbx), bd.ubx);
+        py = fminf(fmaxf(py, bd.lby), bd.uby);
+      }
+      const float rx = (px - q.u) * q.wu, ry = (py - q.v) * q.wv;
+      const float rho = sqrtf(rx * rx + ry * ry);
+      const float coef = a * ((rho <= delta) ? 1.0f : delta / rho);       // a * d huber / d r = a r min(1, delta / rho)
+      float gpx = coef * rx * q.wu, gpy = coef * ry * q.wv;
+      if (BOUNDS) {                                                       // the clamp passes no gradient where it is active
+        gpx = (ppx < bd.lbx || ppx > bd.ubx) ? 0.f : gpx;
+        gpy = (ppy < bd.lby || ppy > bd.uby) ? 0.f : gpy;
+      }
+      const float ghx = gpx / z, ghy = gpy / z;
+      const float ghz = front ? -(ghx * ppx + ghy * ppy) : 0.f;
+      if (want_m) {
+        acc[0] = fmaf(ghx, q.X, acc[0]); acc[1] = fmaf(ghx, q.Y, acc[1]); acc[2] = fmaf(ghx, q.Z, acc[2]); acc[3] += ghx;
+        acc[4] = fmaf(ghy, q.X, acc[4]); acc[5] = fmaf(ghy, q.Y, acc[5]); acc[6] = fmaf(ghy, q.Z, acc[6]); acc[7] += ghy;
+        acc[8] = fmaf(ghz, q.X, acc[8]); acc[9] = fmaf(ghz, q.Y, acc[9]); acc[10] = fmaf(ghz, q.Z, acc[10]); acc[11] += ghz;
+      }
+      const float y0 = R[0] * q.X + R[1] * q.Y + R[2] * q.Z + ps[0];
+      const float y1 = R[3] * q.X + R[4] * q.Y + R[5] * q.Z + ps[1];
+      const float y2 = R[6] * q.X + R[7] * q.Y + R[8] * q.Z + ps[2];
+      acc[12] = fmaf(ghx, y0, acc[12]); acc[13] = fmaf(ghx, y1, acc[13]); acc[14] = fmaf(ghx, y2, acc[14]);
+      acc[15] = fmaf(ghy, y0, acc[15]); acc[16] = fmaf(ghy, y1, acc[16]); acc[17] = fmaf(ghy, y2, acc[17]);
+      acc[18] = fmaf(ghz, y0, acc[18]); acc[19] = fmaf(ghz, y1, acc[19]); acc[20] = fmaf(ghz, y2, acc[20]);
+    }
+  }
+  block_sum<21>(acc, scratch);
+  if (threadIdx.x < 21) {
+    float v = acc[0];
+#pragma unroll
+    for (int i = 1; i < 21; ++i) v = ((int)threadIdx.x == i) ? acc[i] : v;
+    if (threadIdx.x < 12) {
+      if (out_m != nullptr) out_m[(size_t)b * 12 + threadIdx.x] = v;
+    } else if (out_gk != nullptr) {
+      out_gk[(size_t)b * 9 + (threadIdx.x - 12)] = v;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
 // Glue of the training step that the reference leaves to ~25 small ATen launches: adaptive Huber threshold and the
 // Monte-Carlo pose loss.  Both are single HBM-bound passes.
 __global__ __launch_bounds__(256) void adaptive_delta_kernel(const float* __restrict__ x2d, const float* __restrict__ w2d,
@@ -754,6 +838,22 @@ int launch_evaluate_cost(const epropnp_problem* prob, const float* poses, int nu
     return 0;
   });
   return check_launch("evaluate_cost_kernel");
+}
+
+int launch_cost_pose_cam_grad(const epropnp_problem* prob, const float* poses, const float* weights, int num_poses,
+                              int m_pose, float* out_m, float* out_gk, hipStream_t st) {
+  if (int rc = check_problem(prob)) return rc;
+  if (prob->num_obj == 0) return EPROPNP_OK;
+  if (!poses || (!out_m && !out_gk) || num_poses < 1 || m_pose >= num_poses)
+    return fail(EPROPNP_EINVAL, "cost_pose_cam_grad: NULL pointer / bad pose index");
+  const Problem d = to_device_problem(prob);
+  const dim3 grid(padded_object_grid(d.B)), block(d.N > 128 ? 256 : (d.N > 64 ? 128 : 64));
+  dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+    PNP_LAUNCH((cost_pose_cam_grad_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, 0, st, d, poses, weights,
+               num_poses, m_pose, out_m, out_gk);
+    return 0;
+  });
+  return check_launch("cost_pose_cam_grad_kernel");
 }
 
 }  // namespace pnp

@@ -122,6 +122,8 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
                                float* pose_samples_n, float* logweights, float* cost_init, float* pose_opt,
                                float* pose_samples, hipStream_t st);
 int launch_evaluate_cost(const epropnp_problem* prob, const float* poses, int num_poses, float* cost, hipStream_t st);
+int launch_cost_pose_cam_grad(const epropnp_problem* prob, const float* poses, const float* weights, int num_poses,
+                              int m_pose, float* out_m, float* out_gk, hipStream_t st);
 int launch_normal_equations(const epropnp_problem* prob, const float* pose, int clip_jac, float* jtj, float* jtr,
                             float* cost, hipStream_t st);
 int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,

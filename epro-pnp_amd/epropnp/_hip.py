@@ -60,6 +60,7 @@ def _declare(lib):
     lib.epropnp_monte_carlo_forward.argtypes = [C.POINTER(Problem), C.POINTER(McParams)] + [vp] * 16
     lib.epropnp_evaluate_cost.argtypes = [C.POINTER(Problem), vp, i32, vp, vp]
     lib.epropnp_normal_equations.argtypes = [C.POINTER(Problem), vp, i32, vp, vp, vp, vp]
+    lib.epropnp_cost_pose_cam_grad.argtypes = [C.POINTER(Problem), vp, vp, i32, i32, vp, vp, vp]
     lib.epropnp_lm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), vp, vp, vp, vp, vp, vp]
     lib.epropnp_amis_forward.argtypes = [C.POINTER(Problem), C.POINTER(AmisParams), vp, vp, vp, vp, vp, vp, vp]
     lib.epropnp_amis_backward.argtypes = [C.POINTER(Problem), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -83,7 +84,7 @@ def _declare(lib):
     lib.epropnp_mc_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     for name in ('evaluate_cost', 'normal_equations', 'lm_solve', 'amis_forward', 'amis_backward', 'adaptive_delta',
                  'mc_loss_forward', 'mc_loss_backward', 'rslm_draw', 'gn_step_forward', 'gn_step_backward', 'rslm_solve', 'center_points', 'shift_poses', 'prepare_forward', 'prepare_backward', 'pose_opt_plus_forward', 'pose_opt_plus_backward', 'shift_poses_backward', 'prepare_dense_forward',
-                 'prepare_dense_backward', 'amis_backward_split', 'monte_carlo_forward'):
+                 'prepare_dense_backward', 'amis_backward_split', 'monte_carlo_forward', 'cost_pose_cam_grad'):
         getattr(lib, 'epropnp_' + name).restype = C.c_int
     return lib
 
@@ -96,7 +97,7 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_center_points', 'epropnp_shift_poses', 'epropnp_prepare_forward', 'epropnp_prepare_backward',
            'epropnp_pose_opt_plus_forward', 'epropnp_pose_opt_plus_backward', 'epropnp_shift_poses_backward',
            'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split',
-           'epropnp_monte_carlo_forward')
+           'epropnp_monte_carlo_forward', 'epropnp_cost_pose_cam_grad')
 
 
 def lib():

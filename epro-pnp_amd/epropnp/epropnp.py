@@ -17,6 +17,15 @@ from . import proposals
 from .common import pnp_denormalize, pnp_normalize
 
 
+def _DetachedCamera(camera):
+    """Shallow copy of a camera object whose intrinsics do not require grad (same tensors otherwise)."""
+    import copy
+    cam = camera.shallow_copy() if hasattr(camera, 'shallow_copy') else copy.copy(camera)
+    if isinstance(cam.cam_mats, torch.Tensor):
+        cam.cam_mats = cam.cam_mats.detach()
+    return cam
+
+
 def cholesky_wrapper(mat, default_diag=None, force_cpu=True):
     """Batched Cholesky; matrices that are not positive definite yield diag(default_diag) (or I).
     Kept for API compatibility (reference: epropnp/epropnp.py:16-33); the AMIS kernel has its own in-register
@@ -109,8 +118,9 @@ class EProPnPBase(torch.nn.Module):
         """Weighted pose samples from the pose distribution defined by the correspondences.
 
         x3d (B,N,3), x2d (B,N,2), w2d (B,N,2); pose_init (B,4|7) optional (the target pose for the MC loss).
-        fp32 tensors on a HIP device only (no CPU / fp64 path); differentiable w.r.t. x3d, x2d, w2d and a tensor-valued
-        cost_fun.delta -- not w.r.t. pose_init or camera.cam_mats (a warning is issued if those require grad).
+        fp32 tensors on a HIP device only (no CPU / fp64 path); differentiable w.r.t. x3d, x2d, w2d, a tensor-valued
+        cost_fun.delta, and -- as in the reference -- w.r.t. pose_init (through cost_init) and camera.cam_mats (through
+        cost_init and the log-weights).
         Limits: the samples of ONE iteration (mc_samples / num_iter) must fit the LDS pose table (<~ 1500); the total
         mc_samples is unbounded (the sampler state moves from LDS to a global scratch buffer beyond ~2500).  The
         RSLM initialiser's one-launch kernel takes <= 16 points per proposal and <= 512 points per object (beyond that
@@ -119,12 +129,21 @@ class EProPnPBase(torch.nn.Module):
                  pose_sample_logweights (S,B) [differentiable], cost_init (B,)|None [differentiable].
         """
         assert x3d.dim() == x2d.dim() == w2d.dim() == 3
-        if torch.is_grad_enabled() and ((pose_init is not None and pose_init.requires_grad)
-                                        or (isinstance(camera.cam_mats, torch.Tensor) and camera.cam_mats.requires_grad)):
-            import warnings       # the reference's cost_init = evaluate_pnp(pose=pose_init) is differentiable w.r.t. these too
-            warnings.warn('EProPnP.monte_carlo_forward: gradients flow to x3d, x2d, w2d and cost_fun.delta only; pose_init / '
-                          'camera.cam_mats require grad but receive none from the HIP path (detach them, or use '
-                          'epropnp.common.evaluate_pnp for a differentiable cost of pose_init)', stacklevel=2)
+        cam_grad = isinstance(camera.cam_mats, torch.Tensor) and camera.cam_mats.requires_grad
+        if torch.is_grad_enabled() and x3d.size(0) > 0 and ((pose_init is not None and pose_init.requires_grad) or cam_grad):
+            # The reference's cost_init = evaluate_pnp(pose=pose_init) and its log-weights are recorded by autograd w.r.t.
+            # pose_init and camera.cam_mats as well (epropnp.py:121-124,139-169).  The kernel nodes differentiate w.r.t. the
+            # correspondences; these two inputs get their gradients from gradient-only terms (value 0) added to the outputs.
+            out = list(self.monte_carlo_forward(x3d, x2d, w2d, _DetachedCamera(camera), cost_fun,
+                                                pose_init=None if pose_init is None else pose_init.detach(),
+                                                force_init_solve=force_init_solve, noise=noise, **kwargs))
+            prob = hip.PnPProblem(x3d.detach(), x2d.detach(), w2d.detach(), _DetachedCamera(camera), cost_fun, self.dof)
+            if pose_init is not None:
+                out[5] = out[5] + hip.pose_cam_grad_term(prob, pose_init.detach().unsqueeze(0), pose_init, camera.cam_mats,
+                                                         1.0, 0)[0]
+            if cam_grad:        # logweights = -cost(samples) - log mixture: d/d cam_mats through the cost of every sample
+                out[4] = out[4] + hip.pose_cam_grad_term(prob, out[3].detach(), None, camera.cam_mats, -1.0, -1)
+            return tuple(out)
         if self._fusable(x3d, x2d, w2d, pose_init, force_init_solve, kwargs):
             return self._fused_forward(x3d, x2d, w2d, camera, cost_fun, pose_init, force_init_solve, noise, **kwargs)
         if self.normalize:

@@ -205,6 +205,77 @@ def evaluate_cost(prob, poses):
     return cost[0] if squeeze else cost
 
 
+def pose_cam_grad(prob, poses, weights, m_pose=-1, want_cam=True):
+    """Gradients of sum_j weights[j] * cost(poses[j]) w.r.t. pose number `m_pose` (or None for -1) and w.r.t. the camera
+    intrinsics (or None): what autograd records in the reference for `cost_init = evaluate_pnp(pose=pose_init,
+    out_cost=True)` and for the AMIS log-weights w.r.t. pose_init and camera.cam_mats (epropnp.py:121-124,139-169).
+
+    poses (P,B,pose_len), weights (P,B) -> (d/d poses[m_pose] (B,pose_len) | None, d/d cam_mats (B,3,3) | None).
+    One sweep kernel (`epropnp_cost_pose_cam_grad`) reduces d/dK and M = a_m sum_n (d cost / d h_n)(X_n, 1)^T per object;
+    with h = K (R X + t): d/dt = K^T M[:,3], d/dR = K^T M[:,:3], and d/dq (d/dyaw) through the derivative of the rotation
+    the reference builds when the pose requires grad (common.py:30-36: the `1 - 2 (j^2 + k^2)` form, quaternion not
+    normalised; :44-61 for yaw)."""
+    ps = _f32c(poses, 'poses')
+    P = ps.shape[0]
+    assert ps.shape[1:] == (prob.B, prob.pose_len)
+    wt = None if weights is None else _f32c(weights, 'weights')
+    M = prob.new(prob.B, 3, 4) if m_pose >= 0 else None
+    gk = prob.new(prob.B, 3, 3) if want_cam else None
+    _hip.call('epropnp_cost_pose_cam_grad', C.byref(prob.c), _hip.ptr(ps), _hip.ptr(wt), P, int(m_pose), _hip.ptr(M),
+              _hip.ptr(gk), prob.stream)
+    if M is None:
+        return None, gk
+    K, pm = prob.cam, ps[m_pose]
+    g_t = torch.einsum('bij,bi->bj', K, M[:, :, 3])                   # K^T M[:,3]
+    G_R = torch.einsum('bij,bik->bjk', K, M[:, :, :3]).reshape(-1, 9)     # K^T M[:,:3]
+    if prob.dof == 6:
+        w, i, j, k = pm[:, 3], pm[:, 4], pm[:, 5], pm[:, 6]
+        o = torch.zeros_like(w)
+        dR = torch.stack((                                        # d R / d (w, i, j, k), each row-major (B,9)
+            torch.stack((o, -k, j, k, o, -i, -j, i, o), -1),
+            torch.stack((o, j, k, j, -2 * i, -w, k, w, -2 * i), -1),
+            torch.stack((-2 * j, i, w, i, o, k, -w, k, -2 * j), -1),
+            torch.stack((-2 * k, -w, i, w, -2 * k, j, i, j, o), -1)), 1) * 2          # (B,4,9)
+        g_rot = torch.einsum('bqn,bn->bq', dR, G_R)
+    else:
+        yaw = pm[:, 3]
+        c, s_ = torch.cos(yaw), torch.sin(yaw)
+        o = torch.zeros_like(yaw)
+        dR = torch.stack((-s_, o, c, o, o, o, -c, o, -s_), -1)                        # (B,9)
+        g_rot = (dR * G_R).sum(-1, keepdim=True)
+    return torch.cat((g_t, g_rot), -1), gk
+
+
+class _PoseCamGrad(torch.autograd.Function):
+    """Gradient-only node: contributes 0 to its consumer in the forward and, in the backward, the gradient of
+    sum_j g[j] * sign * cost(poses[j]) w.r.t. the pose `m_pose` and the camera intrinsics -- the two inputs of the
+    reference's evaluate_pnp that the kernel nodes (which differentiate w.r.t. the correspondences) do not cover."""
+
+    @staticmethod
+    def forward(ctx, pose_m, cam_mats, poses, prob, sign, m_pose):
+        ctx.prob, ctx.poses, ctx.sign, ctx.m_pose = prob, poses.detach(), float(sign), int(m_pose)
+        ctx.cam_shape = None if cam_mats is None else cam_mats.shape
+        _guard_inputs(ctx, prob)
+        return prob.new(poses.shape[0], prob.B).zero_()
+
+    @staticmethod
+    def backward(ctx, g):
+        _check_inputs(ctx)
+        want_pose = ctx.needs_input_grad[0] and ctx.m_pose >= 0
+        want_cam = ctx.needs_input_grad[1]
+        gp, gk = pose_cam_grad(ctx.prob, ctx.poses, g.to(torch.float32) * ctx.sign, ctx.m_pose if want_pose else -1, want_cam)
+        if gk is not None and tuple(ctx.cam_shape) != tuple(gk.shape):     # cam_mats broadcast over objects: (3,3) / (1,3,3)
+            gk = gk.sum_to_size(ctx.cam_shape)
+        return gp, gk, None, None, None, None
+
+
+def pose_cam_grad_term(prob, poses, pose_m, cam_mats, sign, m_pose):
+    """(P,B) zeros whose backward feeds d/d pose_m and d/d cam_mats of sum_j g[j] * sign * cost(poses[j])."""
+    pm = pose_m if (pose_m is not None and pose_m.requires_grad) else None
+    cm = cam_mats if (isinstance(cam_mats, torch.Tensor) and cam_mats.requires_grad) else None
+    return _PoseCamGrad.apply(pm, cm, poses, prob, sign, m_pose if pm is not None else -1)
+
+
 def normal_equations(prob, pose, clip_jac=True):
     """pose (B,pose_len) -> JtJ (B,d,d), Jtr (B,d), cost (B,) of the Huber-rescaled residual/Jacobian."""
     ps = _f32c(pose, 'pose')

@@ -53,24 +53,100 @@ def gather_objects(local, num_obj, obj_dim=0, group=None, force_collective=False
     return torch.cat(pieces, 0).movedim(0, obj_dim)
 
 
-class ObjectExchange:
-    """The Det step's whole exchange as ONE collective that stays off the step's critical path.
+class RcclComm:
+    """An RCCL communicator of our own over the ranks of a torch.distributed group, driven through the library's C API
+    (the librccl.so that torch itself has loaded): `all_gather` enqueues ONE ncclAllGather on torch's CURRENT stream.
 
-    `start(local, scalars)` packs this rank's per-object outputs (object axis first, equally padded chunk) and a few
-    per-rank scalars (the detection loss's `norm_factor` input, `monte_carlo_pose_loss.py:53` of EPro-PnP-Det) into one
-    send buffer and issues ONE `all_gather_into_tensor` on a side stream: the caller's stream goes on with the loss
-    and the backward.  `world_mean()` (device tensor, mean over ranks of the scalars) and `objects()` (the full
-    `(num_obj, ...)` tensor) make the CURRENT stream wait for the side stream -- an event wait on the device, the host
-    never blocks.  Buffers are allocated once per shape and reused (nothing is allocated per step, so the exchange can
-    sit inside a hipGraph capture of the step).  A `MonteCarloPoseLoss` accepts the exchange in place of its
-    `norm_factor` argument and takes `world_mean()` instead of issuing its own all-reduce.
+    torch.distributed's nccl backend runs every collective on an internal stream and chains current -> internal -> current
+    with events; on this platform each cross-queue hop costs tens of microseconds of GPU time and the Python / c10d
+    wrapper ~50 us of host time -- more than the whole Det step's kernels (tools/exchange_probe.py).  Called directly, the
+    collective is one kernel in stream order between the step's own kernels: no hop, ~10 us of host time, and it is
+    recorded by a hipGraph capture of the step like any other launch.
+    The unique id is created on group rank 0 and broadcast through the torch group (which also proves the group works);
+    ncclCommInitRank is collective over the group."""
+
+    _FLOAT32 = 7            # ncclFloat32 (rccl.h)
+
+    def __init__(self, group=None):
+        import ctypes
+        import os
+        assert dist.is_initialized(), 'RcclComm needs an initialised torch.distributed group'
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        lib = None
+        for cand in (os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'), 'librccl.so', 'librccl.so.1'):
+            try:
+                lib = ctypes.CDLL(cand)
+                break
+            except OSError:
+                continue
+        if lib is None:
+            raise RuntimeError('librccl.so not found (looked next to torch and on the loader path)')
+        self._lib = lib
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [('internal', ctypes.c_ubyte * 128)]
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        uid = UniqueId()
+        if self.rank == 0:
+            self._check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+        dev = torch.device('cuda', torch.cuda.current_device())
+        box = torch.tensor(list(uid.internal), dtype=torch.uint8, device=dev)       # zeros on the other ranks
+        dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), bytes(box.cpu().tolist()), 128)
+        comm = ctypes.c_void_p()
+        self._check(lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        self._comm = comm
+        self.device = dev
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f'{what} failed: {self._lib.ncclGetErrorString(rc).decode()}')
+
+    def all_gather(self, recv, send):
+        """recv (world * n,) <- every rank's send (n,), fp32 contiguous device tensors; on the current stream."""
+        assert send.dtype == torch.float32 and recv.dtype == torch.float32 and send.is_contiguous() and recv.is_contiguous()
+        assert recv.numel() == self.world * send.numel()
+        stream = torch.cuda.current_stream(send.device).cuda_stream
+        self._check(self._lib.ncclAllGather(send.data_ptr(), recv.data_ptr(), send.numel(), self._FLOAT32, self._comm,
+                                            stream), 'ncclAllGather')
+
+    def close(self):
+        if getattr(self, '_comm', None) is not None:
+            self._lib.ncclCommDestroy(self._comm)
+            self._comm = None
+
+
+class ObjectExchange:
+    """The Det step's whole exchange as ONE collective in stream order.
+
+    `start(local, scalars)` packs a few per-rank scalars (the detection loss's `norm_factor` input,
+    `monte_carlo_pose_loss.py:53` of EPro-PnP-Det) and this rank's per-object outputs (object axis first, equally padded
+    chunk) into one send buffer with ONE kernel and issues ONE `all_gather_into_tensor` on the caller's stream, right after
+    the forward that produced the outputs.  `world_mean()` (device tensor: mean over ranks of the scalars) and `objects()`
+    (the full `(num_obj, ...)` tensor) read the receive buffer -- stream order is the only synchronisation, the host never
+    blocks.  Buffers are allocated once per shape and reused, so the exchange sits inside a hipGraph capture of the step
+    like any other launch (RCCL kernels are captured: `bench.py --launch graph`).  A `MonteCarloPoseLoss` accepts the
+    exchange in place of its `norm_factor` argument and takes `world_mean()` instead of issuing its own all-reduce.
+
+    Why not a side stream: measured on MI355X (tools/exchange_probe.py, profiles/r03_exchange_probe.txt) a collective on
+    the caller's stream adds ~14 us to an eager step and ~2 us to a replayed one; routed over a side stream (fork event,
+    c10d's internal stream, join event) it adds 33-48 us eager and 25 us replayed -- every cross-queue dependency is a
+    GPU-side bubble of ~10 us here, more than the 10 KB collective itself.
+    On device tensors the collective is RCCL's ncclAllGather called directly on the current stream (`RcclComm`: +4 us per
+    eager step against +11 us through c10d in the same probe, and no internal stream); `direct=False`, CPU tensors (gloo)
+    or a failed communicator set-up take `torch.distributed.all_gather_into_tensor` (`self.route` says which ran).
     Without a process group (or with one rank and `force_collective=False`) no collective is issued."""
 
-    def __init__(self, num_obj, group=None, force_collective=False):
+    def __init__(self, num_obj, group=None, force_collective=False, direct=True):
         self.num_obj, self.group, self.force = int(num_obj), group, bool(force_collective)
+        self.direct, self._comm, self.route = bool(direct), None, None
         self._key = None
-        self._side = None
-        self._done = None
         self._local = self._scal = None
         self.disabled = False       # timing A/B only (bench.py): the step without its exchange
 
@@ -92,59 +168,50 @@ class ObjectExchange:
         if not self._active():
             return self
         chunk = (self.num_obj + world - 1) // world
-        row = local[0].numel() if local.shape[0] else int(torch.Size(local.shape[1:]).numel())
+        row = int(torch.Size(local.shape[1:]).numel())
         key = (world, chunk, tuple(local.shape[1:]), self._n_scal, local.dtype, local.device)
         if key != self._key:
             self._key = key
-            self._send = local.new_zeros(chunk * row + self._n_scal)
-            self._recv = local.new_empty(world * (chunk * row + self._n_scal))
-            if local.is_cuda:
-                self._side = torch.cuda.Stream(device=local.device)
-                self._done = torch.cuda.Event()
+            self._send = local.new_zeros(self._n_scal + chunk * row)          # [scalars | rows | zero padding]
+            self._recv = local.new_empty(world * (self._n_scal + chunk * row))
         self._chunk, self._row = chunk, row
         n = local.shape[0] * row
-        if local.is_cuda:
-            cur = torch.cuda.current_stream(local.device)
-            self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
-                self._send[:n].copy_(local.reshape(-1))
-                if self._n_scal:
-                    self._send[chunk * row:].copy_(scal)
-                dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
-                self._done.record(self._side)
-            for t in (local, scal):         # consumed on the side stream: keep the allocator from recycling them early
-                if t is not None and not torch.cuda.is_current_stream_capturing():
-                    t.record_stream(self._side)
+        parts = ([scal] if scal is not None else []) + [local.reshape(-1)]
+        torch.cat(parts, out=self._send[:self._n_scal + n])                   # one kernel
+        if self.direct and local.is_cuda and self._comm is None:
+            try:
+                self._comm = RcclComm(self.group)
+            except Exception as e:         # no librccl / bootstrap refused: c10d's route still works, say so once
+                import warnings
+                warnings.warn(f'ObjectExchange: direct RCCL communicator unavailable ({e}); using torch.distributed')
+                self.direct = False
+        if self.direct and local.is_cuda:
+            self._comm.all_gather(self._recv, self._send)
+            self.route = 'rccl ncclAllGather on the current stream'
         else:
-            self._send[:n].copy_(local.reshape(-1))
-            if self._n_scal:
-                self._send[chunk * row:].copy_(scal)
             dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+            self.route = f'torch.distributed.all_gather_into_tensor ({dist.get_backend(self.group)})'
         return self
-
-    def _wait(self):
-        if self._done is not None and self._local.is_cuda:
-            torch.cuda.current_stream(self._local.device).wait_event(self._done)
 
     def world_mean(self):
         """Mean over ranks of the scalars handed to start(): shape (n_scalars,), or () for a single scalar."""
         assert self._scal is not None, 'start() was called without scalars'
         if not self._active():
             return self._scal.reshape(()) if self._n_scal == 1 else self._scal
-        self._wait()
-        world = self._world()         # mmdet's reduce_mean arithmetic: divide by the world size, then sum over ranks
-        m = self._recv.view(world, -1)[:, self._chunk * self._row:].div(world).sum(0)
+        m = self._recv.view(self._world(), -1)[:, :self._n_scal].mean(0)
         return m.reshape(()) if self._n_scal == 1 else m
 
     def objects(self):
         """The gathered (num_obj, ...) per-object outputs, ranks in order, padding trimmed."""
         if not self._active():
             return self._local
-        self._wait()
         world = self._world()
-        per = self._recv.view(world, -1)[:, :self._chunk * self._row]
+        per = self._recv.view(world, -1)[:, self._n_scal:]
+        shape = (self.num_obj,) + tuple(self._local.shape[1:])
+        if self.num_obj == world * self._chunk:          # even split: no padding to trim
+            return per.reshape(shape)
         pieces = []
         for r in range(world):
             lo, hi = shard_range(self.num_obj, r, world)
             pieces.append(per[r, :(hi - lo) * self._row])
-        return torch.cat(pieces, 0).view((self.num_obj,) + tuple(self._local.shape[1:]))
+        return torch.cat(pieces, 0).view(shape)

@@ -142,6 +142,17 @@ int epropnp_noise_stride(int dof);
 int epropnp_evaluate_cost(const epropnp_problem* prob, const float* poses, int32_t num_poses, float* cost,
                           void* stream);
 
+/* Gradients of sum_j a_j cost(pose_j) w.r.t. the camera intrinsics and, for one of the poses, the reduction behind the
+ * gradient w.r.t. that pose -- what autograd records in the reference for cost_init = evaluate_pnp(pose=pose_init,
+ * out_cost=True) and for the AMIS log-weights w.r.t. camera.cam_mats and pose_init (epropnp/epropnp.py:121-124,139-169 ->
+ * common.py:90-99 -> camera.py:21-30,81-93 -> cost_fun.py:8-12,45-61).  With h = K (R X + t), g_h = d cost / d h:
+ *   poses (P,B,pose_len), weights (P,B) | NULL (= 1), m_pose in [-1, P)
+ *   -> grad_cam (B,3,3) | NULL  = sum_j a_j sum_n g_h (R_j X_n + t_j)^T
+ *   -> grad_h_outer (B,3,4) | NULL = a_m sum_n g_h (X_n, Y_n, Z_n, 1)^T for pose m = m_pose (zeros for m_pose = -1):
+ *      d/dt_m = K^T M[:,3],  d/dR_m = K^T M[:,:3]  (per object, on the caller's side). */
+int epropnp_cost_pose_cam_grad(const epropnp_problem* prob, const float* poses, const float* weights, int32_t num_poses,
+                               int32_t m_pose, float* grad_h_outer, float* grad_cam, void* stream);
+
 /* evaluate_pnp(..., out_jacobian, out_residual, out_cost) fused with the normal equations the LM solver forms
  * from them: common.py:67-100 -> camera.py:10-18,81-143 (project_a, Jacobian, clip_jac) -> cost_fun.py:63-84
  * (robust rescaling) -> levenberg_marquardt.py:205-214 (JtJ, Jtr).  The (B,2N,dof) Jacobian is never written.

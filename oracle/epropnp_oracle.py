@@ -34,13 +34,20 @@ import torch
 
 
 def quat_to_rotmat(q):
-    """epropnp/common.py:21-42, the no-grad branch (:37-41): R = 2(w[v]x + v v^T) + (w^2 - v.v) I.
+    """epropnp/common.py:21-42.  Two algebraically equal forms, selected as in the reference by `q.requires_grad`
+    (:30): the `1 - 2 (j^2 + k^2)` form (:31-36) when the quaternion is differentiated -- its derivative w.r.t. q differs
+    from the other form's even on the unit sphere -- and R = 2(w[v]x + v v^T) + (w^2 - v.v) I (:37-41) otherwise.
     The quaternion is NOT normalised."""
     w, x, y, z = q.unbind(-1)
-    dd = w * w - (x * x + y * y + z * z)
-    r00 = 2 * (x * x) + dd
-    r11 = 2 * (y * y) + dd
-    r22 = 2 * (z * z) + dd
+    if q.requires_grad:
+        r00 = 1 - 2 * (y * y + z * z)
+        r11 = 1 - 2 * (x * x + z * z)
+        r22 = 1 - 2 * (x * x + y * y)
+    else:
+        dd = w * w - (x * x + y * y + z * z)
+        r00 = 2 * (x * x) + dd
+        r11 = 2 * (y * y) + dd
+        r22 = 2 * (z * z) + dd
     r01 = 2 * (x * y - w * z)
     r02 = 2 * (x * z + w * y)
     r10 = 2 * (x * y + w * z)

@@ -146,7 +146,7 @@ def test_bench_multi_gpu_harness(config, form):
     `python bench.py --gpus N`, which spawns its N ranks itself (the launch model of
     EPro-PnP-Det/tools/train.py:123 replaced) -- on the nccl backend: 2 ranks when the box has two GPUs, one rank (through
     the same launcher route, BENCH_SELF_LAUNCH=1) otherwise.  C4 = 600 objects split over the ranks + ONE
-    all_gather_into_tensor per step on a side stream inside the timed region, C2 / C5 = disjoint shards."""
+    all_gather_into_tensor per step inside the timed region, C2 / C5 = disjoint shards."""
     import json
     import subprocess
     import sys

@@ -215,6 +215,11 @@ def test_inplace_edit_between_forward_and_backward_is_detected(backend):
     x2d.add_(1.0)
     with pytest.raises(RuntimeError, match='modified by an inplace operation'):
         (out[5] + torch.logsumexp(out[4], 0)).sum().backward()
+    # a pose_init that requires grad receives its gradient (tests/test_pose_cam_grad.py), no warning any more
+    import warnings
     pi = p['pose_init'].clone().requires_grad_(True)
-    with pytest.warns(UserWarning, match='pose_init'):
-        layer.monte_carlo_forward(x3d, p['x2d'], p['w2d'], cam, cf, pose_init=pi, force_init_solve=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        out = layer.monte_carlo_forward(x3d, p['x2d'], p['w2d'], cam, cf, pose_init=pi, force_init_solve=False)
+    out[5].sum().backward()
+    assert pi.grad is not None and bool(torch.isfinite(pi.grad).all()) and pi.grad.abs().max() > 0
