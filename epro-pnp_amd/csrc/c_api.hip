@@ -60,7 +60,68 @@ void profile_end(hipStream_t) {}
 #endif
 }  // namespace pnp
 
+namespace pnp {
+// The default status word: when a caller passes no `epropnp_problem.status`, kernels report numerical events (a singular
+// damped system, a non-finite pose: what torch.linalg.solve / torch.inverse raise on in the reference,
+// levenberg_marquardt.py:15-19,178-181) into a per-device int32[2] in HOST memory mapped into the device.  It costs nothing
+// on the normal path (no event -> no memory operation) and lets the host side notice a failure with a plain load -- no
+// synchronisation, no copy: the Python layer polls it on entry to every call and raises what the reference would have
+// raised, one call late at most (`epropnp_async_status`).  EPROPNP_ASYNC_STATUS=0 switches it off.
+static int32_t* g_status_words[64] = {nullptr};
+static int g_status_mode = -1;
+
+int32_t* default_status_word() {
+  if (g_status_mode < 0) {
+    const char* e = getenv("EPROPNP_ASYNC_STATUS");
+    g_status_mode = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+  if (g_status_mode == 0) return nullptr;
+  int dev = 0;
+#ifndef EPROPNP_EMU
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+#endif
+  int32_t* w = __atomic_load_n(&g_status_words[dev], __ATOMIC_ACQUIRE);
+  if (w != nullptr) return w;
+#ifndef EPROPNP_EMU
+  // may be the first call of a process that is already capturing a graph: a host allocation is not a stream operation,
+  // relax the thread's capture mode around it
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  void* mem = nullptr;
+  const hipError_t rc = hipHostMalloc(&mem, 2 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent);
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (rc != hipSuccess) { (void)hipGetLastError(); g_status_mode = 0; return nullptr; }
+  w = (int32_t*)mem;
+#else
+  w = (int32_t*)malloc(2 * sizeof(int32_t));
+#endif
+  w[0] = 0;
+  w[1] = INT32_MAX;
+  int32_t* expected = nullptr;
+  if (!__atomic_compare_exchange_n(&g_status_words[dev], &expected, w, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+#ifndef EPROPNP_EMU
+    (void)hipHostFree(w);
+#else
+    free(w);
+#endif
+    w = expected;
+  }
+  return w;
+}
+}  // namespace pnp
+
 extern "C" {
+
+int32_t* epropnp_async_status_word(void) { return pnp::default_status_word(); }
+
+int epropnp_async_status(int32_t* flags_and_first, int clear) {
+  int32_t* w = pnp::default_status_word();
+  const int32_t f = w ? __atomic_load_n(&w[0], __ATOMIC_RELAXED) : 0;
+  const int32_t o = w ? __atomic_load_n(&w[1], __ATOMIC_RELAXED) : INT32_MAX;
+  if (flags_and_first) { flags_and_first[0] = f; flags_and_first[1] = o; }
+  if (w && clear) { __atomic_store_n(&w[0], 0, __ATOMIC_RELAXED); __atomic_store_n(&w[1], INT32_MAX, __ATOMIC_RELAXED); }
+  return f;
+}
 
 int epropnp_abi_version(void) { return EPROPNP_ABI_VERSION; }
 

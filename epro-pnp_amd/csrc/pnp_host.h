@@ -11,6 +11,7 @@
 namespace pnp {
 
 char* last_error_buffer();   // thread-local, defined in c_api.hip
+int32_t* default_status_word();   // per-device host-mapped int32[2] the kernels report into when the caller gives none (c_api.hip)
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -44,7 +45,7 @@ inline Problem to_device_problem(const epropnp_problem* p) {
   d.z_min = p->z_min; d.B = p->num_obj; d.N = p->num_pts;
   d.huber_eps = (p->huber_eps > 0.f) ? p->huber_eps : 1e-10f;
   d.inv_huber_eps = 1.0f / d.huber_eps;
-  d.status = p->status;
+  d.status = p->status ? p->status : default_status_word();
   return d;
 }
 

@@ -21,11 +21,17 @@ struct Problem {
   int* status;                      // optional int32[2]: [0] |= flags, [1] = min(object index); see epropnp_hip.h
 };
 
-// record a numerical event for the caller (no-op without a status buffer); rare by construction, so plain atomics
+// record a numerical event for the caller (no-op without a status word); rare by construction, so plain atomics.  System
+// scope: the word may live in host memory (the library's default status word, pnp_host.h:default_status_word).
 __device__ __forceinline__ void raise_status(const Problem& p, int flags, int b) {
   if (p.status != nullptr && flags != 0) {
+#ifndef EPROPNP_EMU
+    __hip_atomic_fetch_or(p.status, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_min(p.status + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
     atomicOr(p.status, flags);
     atomicMin(p.status + 1, b);
+#endif
   }
 }
 

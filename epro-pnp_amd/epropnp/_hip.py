@@ -46,7 +46,7 @@ class McParams(C.Structure):
                 ('rslm_inds', C.c_void_p), ('rslm_rot', C.c_void_p)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 
@@ -56,6 +56,9 @@ def _declare(lib):
     lib.epropnp_last_error.restype = C.c_char_p
     lib.epropnp_noise_stride.argtypes = [C.c_int]
     lib.epropnp_profile_enable.argtypes = [C.c_int]
+    lib.epropnp_async_status.argtypes = [C.POINTER(C.c_int32), C.c_int]
+    lib.epropnp_async_status.restype = C.c_int
+    lib.epropnp_async_status_word.restype = C.POINTER(C.c_int32)
     lib.epropnp_profile_read.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     lib.epropnp_monte_carlo_forward.argtypes = [C.POINTER(Problem), C.POINTER(McParams)] + [vp] * 16
     lib.epropnp_evaluate_cost.argtypes = [C.POINTER(Problem), vp, i32, vp, vp]
@@ -97,7 +100,8 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_center_points', 'epropnp_shift_poses', 'epropnp_prepare_forward', 'epropnp_prepare_backward',
            'epropnp_pose_opt_plus_forward', 'epropnp_pose_opt_plus_backward', 'epropnp_shift_poses_backward',
            'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split',
-           'epropnp_monte_carlo_forward', 'epropnp_cost_pose_cam_grad')
+           'epropnp_monte_carlo_forward', 'epropnp_cost_pose_cam_grad', 'epropnp_async_status',
+           'epropnp_async_status_word')
 
 
 def lib():
@@ -183,6 +187,56 @@ def profile_read(stage):
     ms, n = C.c_float(0), C.c_int32(0)
     lib().epropnp_profile_read(stage.encode(), C.byref(ms), C.byref(n))
     return (ms.value if n.value else float('nan')), n.value
+
+
+ST_LM_NOT_SPD, ST_NONFINITE_POSE = 1, 2          # include/epropnp_hip.h: the two events the reference raises on
+_status_words = {}
+
+
+STATUS_MODE = os.environ.get('EPROPNP_ASYNC_STATUS', 'warn')     # 'warn' (default) | 'raise' | '0' (no status word at all)
+
+
+def poll_status():
+    """The asynchronous half of the error convention.  Kernels report a damped normal-equation system without a Cholesky
+    factor / a non-finite pose into the library's host-mapped status word of the current device; reading it is a plain
+    host load, so every entry into the package polls it -- at the first call after the failing kernel has run, without
+    ever synchronising (`flush_status()` synchronises and polls).
+    What happens then follows the reference's behaviour rather than its letter: `torch.linalg.solve` / `torch.inverse`
+    (levenberg_marquardt.py:15-19,178-181) raise only on an exactly zero LU pivot, which the LM damping rules out, and
+    otherwise hand NaN poses on silently -- the callers' losses zero NaN objects (monte_carlo_pose_loss.py:31).  So the
+    default is a RuntimeWarning naming the object; EPROPNP_ASYNC_STATUS=raise (or `_hip.STATUS_MODE = 'raise'`) turns it
+    into the RuntimeError, `with numerics_check():` does so for a block, synchronously.  Events the reference takes in its
+    stride (Cholesky fallback of a proposal, non-finite log-weight) are dropped here."""
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    w = _status_words.get((id(_lib), dev))
+    if w is None:
+        w = lib().epropnp_async_status_word()
+        _status_words[(id(_lib), dev)] = w if w else False
+    if not w:
+        return
+    flags = w[0]
+    if flags:
+        first = w[1]
+        w[0], w[1] = 0, 2 ** 31 - 1
+        msg = None
+        if flags & ST_LM_NOT_SPD:
+            msg = (f'linalg.solve: the damped normal equations of object {first} are singular or not finite '
+                   f'(reported asynchronously by an earlier EPro-PnP launch on device {dev})')
+        elif flags & ST_NONFINITE_POSE:
+            msg = (f'the solver produced a non-finite pose for object {first} (reported asynchronously by an earlier '
+                   f'EPro-PnP launch on device {dev})')
+        if msg is not None:
+            if STATUS_MODE == 'raise':
+                raise RuntimeError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def flush_status():
+    """Synchronise the current device and raise any pending numerical event now."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    poll_status()
 
 
 def call(fn_name, *args):

@@ -34,13 +34,21 @@ def status_buffer(device):
     return bufs[key]
 
 
+def flush_status():
+    """Synchronise the current device and raise a pending numerical event (singular normal equations, non-finite pose) now."""
+    _hip.flush_status()
+
+
 class numerics_check:
     """Context manager: kernels launched inside record numerical events in a device-side status word (no host sync on
     the way); leaving the block -- or calling .check() -- synchronises once and raises what the reference would have
     raised where the event happened:
 
-        with hip.numerics_check():                 # or EProPnP*/LMSolver(...).check_numerics = True
+        with hip.numerics_check():
             pose_opt, *_ = solver(x3d, x2d, w2d, camera, cost_fun, pose_init=p0)
+
+    Outside such a block the same two RuntimeErrors are still raised, asynchronously: kernels report into the library's
+    host-mapped status word and every entry into the package polls it (`_hip.poll_status`, `flush_status()`).
 
     * a damped normal-equation system without a Cholesky factor (singular or NaN input) or a non-finite pose
       -> RuntimeError, as `torch.linalg.solve` / `torch.inverse` raise in levenberg_marquardt.py:15-19,178-181;
@@ -126,6 +134,8 @@ class PnPProblem:
             delta = torch.full((B,), float(delta), dtype=torch.float32, device=dev)
         self.delta = _f32c(delta.to(dev).expand(B) if delta.dim() <= 1 else delta.reshape(B), 'delta')
         self.status = status_buffer(dev)          # None unless numerics checking is on (epropnp.status)
+        if self.status is None:
+            _hip.poll_status()                    # default: the library's host-mapped word, polled on entry (no sync)
         self.c = _hip.Problem(_hip.ptr(self.x3d), _hip.ptr(self.x2d), _hip.ptr(self.w2d), _hip.ptr(self.cam),
                               _hip.ptr(self.lb), _hip.ptr(self.ub), _hip.ptr(self.delta), self.z_min, B, N, dof,
                               self.huber_eps, _hip.ptr(self.status))

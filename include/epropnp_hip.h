@@ -28,7 +28,7 @@ extern "C" {
 #define EPROPNP_ELAUNCH (-2)  /* HIP launch/runtime error                                         */
 #define EPROPNP_ENODEV (-3)   /* no HIP device / not a gfx950 code object                         */
 
-#define EPROPNP_ABI_VERSION 3
+#define EPROPNP_ABI_VERSION 4
 
 /* Correspondences + camera + robust-cost parameters of one batch of objects.
  * Mirrors the state of PerspectiveCamera (epropnp/camera.py:35-62) and HuberPnPCost.delta
@@ -51,7 +51,8 @@ typedef struct epropnp_problem {
                             atomicMin the first offending object index into status[1] (initialise to {0, INT32_MAX}).
                             Lets a caller reproduce, after a synchronisation of its choosing, the RuntimeError that
                             torch.linalg.solve / torch.inverse raise in the reference (levenberg_marquardt.py:15-19,
-                            :178-181) instead of receiving NaN poses silently.                                        */
+                            :178-181) instead of receiving NaN poses silently.  NULL selects the library's default
+                            status word (epropnp_async_status below).                                                 */
 } epropnp_problem;
 
 /* status[0] flags */
@@ -131,6 +132,18 @@ const char* epropnp_last_error(void);
 int epropnp_profile_enable(int on);
 int epropnp_profile_reset(void);
 int epropnp_profile_read(const char* stage, float* mean_ms, int32_t* count);
+
+/* The default status word.  With `epropnp_problem.status == NULL` kernels report the events above into a per-device
+ * int32[2] in host memory mapped into the device: no cost without an event, and the host notices a failure with a plain
+ * load -- no synchronisation.  `epropnp_async_status` returns the flags seen so far on the current device (and the first
+ * offending object in flags_and_first[1]), optionally clearing them; `epropnp_async_status_word` returns the word itself
+ * for callers that poll it directly (NULL when switched off with EPROPNP_ASYNC_STATUS=0).  The Python layer polls on entry
+ * to every call and reports EPROPNP_ST_LM_NOT_SPD / _NONFINITE_POSE -- asynchronously: at the first call after the failing
+ * kernel has run, as HIP reports its own faults -- as a RuntimeWarning, or as the RuntimeError of
+ * levenberg_marquardt.py:15-19,178-181 with EPROPNP_ASYNC_STATUS=raise (the reference's LU raises only on an exactly zero
+ * pivot and otherwise hands NaN poses on, which its losses zero: monte_carlo_pose_loss.py:31). */
+int epropnp_async_status(int32_t* flags_and_first, int clear);
+int32_t* epropnp_async_status_word(void);
 
 /* Floats per (iteration, sample, object) of an injected-noise buffer for the given dof (8 for 6-DoF:
  * [z0,z1,z2, chi2, g0..g3]; 4 + 3*16 for 4-DoF: [z0,z1,z2, chi2, u | 16x(u1,u2,u3)]). */

@@ -130,10 +130,29 @@ def test_numerics_check_reports_what_the_reference_raises(backend):
     with pytest.raises(RuntimeError, match='object 4'):
         with F.numerics_check():
             solver.solve(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])
-    # unchecked, the failure is silent: every trust-region step of that object is rejected (NaN comparisons are false),
-    # so it comes back at its starting pose while the other objects are solved
+    # outside such a block the call itself returns (nothing synchronises): every trust-region step of that object is
+    # rejected (NaN comparisons are false), so it comes back at its starting pose while the other objects are solved ...
     pose_opt = solver.solve(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])[0]
     assert torch.equal(pose_opt[4], p['pose_init'][4]) and not torch.equal(pose_opt[3], p['pose_init'][3])
+    # ... and the event arrives asynchronously: the kernels reported into the library's host-mapped status word, which the
+    # next entry into the package (or flush_status) reads with a plain host load -- a RuntimeWarning by default (the
+    # reference hands NaN poses on silently and its losses zero them), the RuntimeError on request
+    from epropnp import _hip
+    with pytest.warns(RuntimeWarning, match='object 4'):
+        F.flush_status()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        F.flush_status()                              # reported once
+    solver.solve(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])
+    if p['x3d'].is_cuda:
+        torch.cuda.synchronize()
+    _hip.STATUS_MODE = 'raise'
+    try:
+        with pytest.raises(RuntimeError, match='singular or not finite'):
+            solver.solve(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])  # on entry to the NEXT call
+    finally:
+        _hip.STATUS_MODE = 'warn'
     hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6)
     po, cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
     cov = cov.clone()
