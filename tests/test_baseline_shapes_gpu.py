@@ -9,7 +9,7 @@ Bars: north-star pose <= 1e-4 and KL loss <= 1e-3 (batch mean: strictly), per ob
 rounding spread (orc.rounding_spread: max change of the fp32 oracle under <= 3 ulp input perturbations + its fp32-vs-fp64
 drift), matched by rank over the slice (helpers.assert_within_spread).  No literal waivers.
 
-Set EPROPNP_PARITY_REPORT=<file> to append the measured errors / spreads as JSON lines (profiles/r02_parity_*.jsonl).
+Set EPROPNP_PARITY_REPORT=<file> to append the measured errors / spreads as JSON lines (profiles/r03_parity_*.jsonl).
 """
 import json
 import os
@@ -78,8 +78,19 @@ def compare_with_oracle(name, got, base, spread, nslice):
     e_loss = (got['loss_obj'] - base['loss_obj']).abs()
     e_mean = abs(got['loss_obj'].mean().item() - base['loss_obj'].mean().item())
     grads = {k: rel_per_object(got[k], base[k]) for k in ('gx3d', 'gx2d', 'gw2d')}
+    # how much of the pass is owed to the yardstick: per quantity, the objects whose error exceeds the BARE north-star bar
+    # (`flips`: trust-region / proposal-fit decisions that fell the other way), the objects whose bar the oracle's own
+    # rounding spread widens, and the rank slack assert_within_spread grants for them
+    import math
+    counts = {}
+    for key, err, spr, bar in (('pose', e_pose, spread['pose_opt'], POSE_TOL), ('cost', e_cost, spread['cost'], 1e-5),
+                               ('loss', e_loss, spread['loss_obj'], KL_TOL)) + tuple(
+                                   (k, grads[k], spread[k], GRAD_TOL) for k in grads):
+        n_trip = int((spr.flatten() > bar).sum())
+        counts[key] = {'bar': bar, 'errors_above_bare_bar': int((err.flatten() > bar).sum()), 'bars_widened_by_spread': n_trip,
+                       'rank_slack': 0 if n_trip == 0 else 1 + math.ceil(math.sqrt(2 * n_trip))}
     report(name, objects=nslice, pose_err=e_pose, pose_spread=spread['pose_opt'], cost_err=e_cost, cost_spread=spread['cost'],
-           loss_err=e_loss, loss_spread=spread['loss_obj'], kl_mean_err=e_mean,
+           loss_err=e_loss, loss_spread=spread['loss_obj'], kl_mean_err=e_mean, counts=counts,
            **{k + '_err': v for k, v in grads.items()}, **{k + '_spread': spread[k] for k in grads})
     assert_within_spread(e_pose, spread['pose_opt'], POSE_TOL, what=name + ' pose_opt')
     assert_within_spread(e_cost, spread['cost'], 1e-5, what=name + ' cost')
@@ -141,6 +152,12 @@ def test_c5_shard_slice_matches_oracle(dev):
     """BASELINE configs[4], one GPU's shard: 8192 objects x 2048 points x 1024 samples.  16 objects against the oracle
     (one oracle run of 16 such objects costs what 128 C2 objects cost)."""
     check_6dof_slice(dev, 'C5', 8192, 2048, 1024, 4, 3, nslice=16, seed=4048, trials=8)
+
+
+def test_many_samples_layer_matches_oracle(dev):
+    """EProPnP6DoF(mc_samples=4096): sampler state in the global scratch buffer (beyond the 160 KiB of LDS) and the all-VALU
+    backward -- the whole layer, forward and backward, against the oracle on the same injected noise (every object)."""
+    check_6dof_slice(dev, 'S4096', 16, 128, 4096, 4, 3, nslice=16, seed=808, trials=4)
 
 
 def c3_training_problem(B, N, seed):
