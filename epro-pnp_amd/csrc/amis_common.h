@@ -548,7 +548,7 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
       smp[i * S + m] = ps[i];
-      pose_samples[((size_t)m * p.B + b) * PL + i] = ps[i];
+      if (pose_samples != nullptr) pose_samples[((size_t)m * p.B + b) * PL + i] = ps[i];
     }
     {   // project_b operands of this sample -> LDS row (read back as broadcast by every lane of the sweep)
       float R[9], KR[9], Kt[3];

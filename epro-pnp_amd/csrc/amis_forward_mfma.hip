@@ -123,10 +123,23 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
                                                                   float* __restrict__ pose_samples,
                                                                   float* __restrict__ logweights,
                                                                   float* __restrict__ proposals,
-                                                                  float* __restrict__ spill) {
+                                                                  float* __restrict__ spill, int nsplit,
+                                                                  float* __restrict__ xch) {
   static_assert(!SPILL || NPT == 0, "the spill variant streams the points");
   constexpr int PL = PoseLen<DOF>::value;
-  const int b = object_of_block(p.B);
+  // nsplit = G > 1 (few objects, register mode): G workgroups share one object.  Each runs the whole sampler -- draws, weights
+  // and proposal fits are deterministic, so the G copies stay identical -- but sweeps only every G-th group of point tiles;
+  // the partial costs of an iteration meet in global memory behind a per-object arrival counter (below).  All parts of an
+  // object sit on the same XCD (workgroup g -> XCD g % 8), so the exchange stays in one L2.
+  const int G = nsplit;
+  int b, part = 0;
+  if (G > 1) {
+    const int g = (int)blockIdx.x, per = (p.B + 7) >> 3, idx = g >> 3;
+    part = idx % G;
+    b = (g & 7) * per + idx / G;
+  } else {
+    b = object_of_block(p.B);
+  }
   if (b >= p.B) return;
   AmisParams a = a_in;
   if (a.offset_dev != nullptr) a.offset += *a.offset_dev;
@@ -140,7 +153,8 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   PNP_DYN_SMEM(float, smem);
   constexpr bool kRegs = NPT > 0;
   constexpr bool kFold = kRegs && !BOUNDS;
-  const int WPs = kRegs ? W : 1;      // point slices whose partial costs are summed in amis_weights
+  const int WPs = kRegs ? (G > 1 ? G : W) : 1;      // point slices whose partial costs are summed in amis_weights
+  const int cpart_rows = (kRegs && G > W) ? G : (kRegs ? W : 1);
   float* ptab = smem;                 // [s16][12]   x | y | z rows of (K R | K t)          (16-B aligned)
   float* pB = ptab + 12 * s16;        // [NC][4]     (X, Y, Z, 1)        (NC = 0 in register mode)
   float* pW = pB + 4 * NC;            // [NC][4]     (wu, wv, -u wu, -v wv)
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   float* mixl = cst + S;              // [S]
   float* lgw = mixl + S;              // [S]
   float* cpart = SPILL ? pW + 4 * NC : lgw + S;                              // [WPs][s16]
-  float* prop = cpart + WPs * s16;    // [K][kPropStride]
+  float* prop = cpart + cpart_rows * s16;    // [K][kPropStride]
   float* red = prop + K * kPropStride;   // [256]
   float* nzb = (s <= T) ? ptab : red + 256;   // [s][8] base noise drawn ahead; shares the pose table's LDS when one
                                               // sample per lane suffices (amis_draw separates the two uses)
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   if (kRegs) {
 #pragma unroll
     for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
-      const Point q = load_point(p, b, (wv + W * i) * 16 + (lane & 15));      // zero weight beyond N
+      const Point q = load_point(p, b, ((part * W + wv) + G * W * i) * 16 + (lane & 15));      // zero weight beyond N
       const int k4 = lane >> 4;
       rB[i] = (k4 == 0) ? q.X : (k4 == 1) ? q.Y : (k4 == 2) ? q.Z : 1.0f;
       // without a projection clamp the weights are folded into the B operands of the x and y rows (same 5 VGPRs)
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
 #ifdef PNP_TUNING
     if (!(a.ablate & 32) || it == 0)      // bit5: the sweep re-uses the first iteration's pose table (what the sweep alone costs)
 #endif
-    amis_draw<DOF>(cx, p, a, it, Kc, noise, pose_samples);
+    amis_draw<DOF>(cx, p, a, it, Kc, noise, part == 0 ? pose_samples : nullptr);
     __syncthreads();
     PNP_PHASE(1);
 
@@ -282,6 +296,47 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
       }
     }
     __syncthreads();
+    if (kRegs && G > 1) {
+      // ---- exchange of the partial costs between the G parts of this object ----
+      // own row = sum over this workgroup's waves (fixed order) -> global slot [b][it][part][s16]; every thread then polls the
+      // words it gathers from the other parts until they are no longer the fill pattern the launcher wrote into the (per-launch,
+      // per-iteration) slots: the data is its own arrival flag -- one store and one load round trip, no counter, one barrier.
+      // Every access to the exchanged words is a relaxed AGENT-scope atomic (sc1 stores / loads: they bypass the per-CU L1
+      // and the non-coherent L2 lines of other XCDs); no release / acquire fences -- at agent scope those write back and
+      // invalidate the whole L2, 20 us per exchange (profiles/r03_fwd_split_timing.txt).  A cost can never BE the fill
+      // pattern: it is a negative NaN with a full payload, and NaN costs are stored as the canonical quiet NaN.
+      float* slot = xch + (((size_t)b * K + it) * G) * s16;
+      for (int m = tid; m < s; m += T) {
+        float c = cpart[m];
+        for (int w = 1; w < W; ++w) c += cpart[w * s16 + m];
+#ifndef EPROPNP_EMU
+        unsigned bits = __float_as_uint(c);
+        bits = (c != c) ? 0x7fc00000u : bits;
+        __hip_atomic_store(reinterpret_cast<unsigned*>(slot) + part * s16 + m, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        slot[part * s16 + m] = c;
+#endif
+      }
+#ifndef EPROPNP_EMU
+      __syncthreads();             // every wave has read the per-wave rows of cpart: they may be overwritten now
+      bool timed_out = false;
+      for (int i = tid; i < G * s; i += T) {
+        const int q = i / s, m = i - q * s;
+        const unsigned* src = reinterpret_cast<const unsigned*>(slot) + q * s16 + m;
+        unsigned v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every part of every object is resident (the launcher sizes the grid for one workgroup per CU), so this wait is
+        // short; the bound turns a scheduling accident into a reported event instead of a hang
+        for (int spins = 0; v == 0xffffffffu && spins < (1 << 22); ++spins) {
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        timed_out |= (v == 0xffffffffu);
+        cpart[q * s16 + m] = __uint_as_float(v);
+      }
+      if (timed_out) raise_status(p, EPROPNP_ST_SPLIT_TIMEOUT, b);
+      __syncthreads();
+#endif
+    }
     PNP_PHASE(2);
 
     amis_weights<DOF>(cx, a, it, WPs);
@@ -292,7 +347,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
     PNP_PHASE(4);
   }
 
-  {   // numerical events for the caller's status word (include/epropnp_hip.h); no-op without one
+  if (part == 0) {   // numerical events for the caller's status word (include/epropnp_hip.h); no-op without one
     int st_bits = 0;
     for (int m = tid; m < S; m += T) {
       const float lw = lgw[m];
@@ -303,7 +358,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
       st_bits |= (prop[i * kPropStride + 37] != 0.f || prop[i * kPropStride + 38] != 0.f) ? EPROPNP_ST_CHOL_FALLBACK : 0;
     raise_status(p, st_bits, b);
   }
-  if (proposals != nullptr)
+  if (proposals != nullptr && part == 0)
     for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
   PNP_PHASE(5);
 #ifdef PNP_TUNING
@@ -348,6 +403,33 @@ static int dispatch_npt(int npt, F&& f) {
   }
 }
 
+// Parts per object for the split over workgroups: the most parts (<= 8) that leave every wave two point tiles and keep the
+// whole grid resident at ONE workgroup per CU -- the parts of an object wait for each other, so they must all be running
+// (256 CUs; each CU holds at least two of these workgroups, which leaves room for a second such launch on another stream).
+// Two parts do not pay for the exchange.  EPROPNP_FWD_SPLIT=<G> overrides (1: off).
+static int forward_split_parts(int B, int ptiles) {
+  const long wgs = padded_object_grid(B);
+  int g = 8;
+  while (g > 1 && (wgs * g > 256 || 8 * g > ptiles)) g >>= 1;
+  if (g < 4) g = 1;
+  { int ov[1]; if (env_ints("EPROPNP_FWD_SPLIT", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && wgs * ov[0] <= 512 && 4 * ov[0] <= ptiles) g = ov[0]; }
+  return g;
+}
+
+unsigned long long amis_forward_split_bytes(const epropnp_problem* prob, int mc_samples, int num_iter) {
+#ifdef EPROPNP_EMU
+  return 0;
+#else
+  if (prob == nullptr || prob->num_obj <= 0 || num_iter <= 0 || mc_samples % num_iter != 0) return 0;
+  const int ptiles = (prob->num_pts + 15) / 16;
+  if (ptiles > 8 * 16 || (prob->dof == 4 && ptiles > 8 * 12)) return 0;      // register mode only (launcher below)
+  const int g = forward_split_parts(prob->num_obj, ptiles);
+  if (g <= 1) return 0;
+  const int s16 = ((mc_samples / num_iter + 15) / 16) * 16;
+  return sizeof(float) * (unsigned long long)prob->num_obj * num_iter * g * s16;
+#endif
+}
+
 int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_params* am, const float* pose_opt,
                              const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
                              float* proposals, hipStream_t st) {
@@ -380,13 +462,28 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   } else {
     sh.chunk = 0;
   }
+  // Few objects (register mode): G workgroups per object, each sweeping every G-th group of point tiles (kernel comment).
+  int G = 1;
+#ifndef EPROPNP_EMU
+  if (npt > 0) {
+    const int g = forward_split_parts(d.B, ptiles);
+    const size_t need = sizeof(float) * (size_t)d.B * K * g * sh.s16;
+    int ovf[1];
+    const bool forced = env_ints("EPROPNP_FWD_SPLIT", ovf, 1);           // experiments: scratch from hipMallocAsync
+    if (g > 1 && (forced || (am->split_scratch != nullptr && am->split_scratch_bytes >= need))) {
+      int per_wave = (ptiles + 4 * g - 1) / (4 * g), o = 1;      // tiles per wave, rounded up to an instantiated NPT
+      while (o < per_wave) o *= 2;
+      if (o <= 8) { G = g; waves = 4; npt = o; }
+    }
+  }
+#endif
   AmisParams k;
   k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
   auto lds_bytes = [&](bool spilled) {
     return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (size_t)(PL + 3) * S) +
-                            (size_t)(npt ? waves : 1) * sh.s16 + (size_t)K * kPropStride + 256 +
+                            (size_t)(npt ? (G > waves ? G : waves) : 1) * sh.s16 + (size_t)K * kPropStride + 256 +
                             (s <= 64 * waves ? 0 : 8 * (size_t)s));
   };
   size_t smem = lds_bytes(false);
@@ -420,7 +517,8 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-      PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals, spill);
+      PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals, spill, 1,
+                 (float*)nullptr);
       return 0;
     });
     const int rc = check_launch("amis_forward_mfma_kernel (sampler state in global scratch)");
@@ -431,6 +529,31 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
 #endif
     return rc;
   }
+  float* xch = nullptr;
+  char* owned = nullptr;
+  dim3 grid_split = grid;
+  if (G > 1) {
+#ifndef EPROPNP_EMU
+    // exchange buffer [B][K][G][s16], filled with the "not yet written" pattern on the stream: the caller's scratch (no
+    // allocation: in a hipGraph an alloc / free node pair costs more than the split saves), or for EPROPNP_FWD_SPLIT
+    // experiments a stream-ordered allocation
+    const size_t xbytes = sizeof(float) * (size_t)d.B * K * G * sh.s16;
+    char* mem = (am->split_scratch != nullptr && am->split_scratch_bytes >= xbytes) ? (char*)am->split_scratch : nullptr;
+    if (mem == nullptr) {
+      if (hipMallocAsync((void**)&mem, xbytes, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(EPROPNP_ELAUNCH, "amis_forward: scratch for the %d-way split (%zu B) could not be allocated", G, xbytes);
+      }
+      owned = mem;
+    }
+    if (hipMemsetAsync(mem, 0xff, xbytes, st) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(EPROPNP_ELAUNCH, "amis_forward: could not fill the split scratch");
+    }
+    xch = (float*)mem;
+    grid_split = dim3(padded_object_grid(d.B) * G);
+#endif
+  }
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     return dispatch_npt(npt, [&](auto NPT) -> int {
       auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
@@ -438,11 +561,14 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-      PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
-                 (float*)nullptr);
+      PNP_LAUNCH(kern, grid_split, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
+                 (float*)nullptr, G, xch);
       return 0;
     });
   });
+#ifndef EPROPNP_EMU
+  if (owned != nullptr) (void)hipFreeAsync(owned, st);
+#endif
   return check_launch("amis_forward_mfma_kernel");
 }
 

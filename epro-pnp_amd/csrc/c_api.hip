@@ -127,6 +127,10 @@ int epropnp_abi_version(void) { return EPROPNP_ABI_VERSION; }
 
 const char* epropnp_last_error(void) { return pnp::last_error_buffer(); }
 
+uint64_t epropnp_amis_forward_split_bytes(const epropnp_problem* prob, int32_t mc_samples, int32_t num_iter) {
+  return pnp::amis_forward_split_bytes(prob, mc_samples, num_iter);
+}
+
 int epropnp_noise_stride(int dof) { return dof == 6 ? 8 : (dof == 4 ? 4 + 3 * 16 : -1); }
 
 int epropnp_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_params* par, const float* pose_init,

@@ -122,6 +122,7 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
                                float* start_pose, float* start_cost, float* pose_opt_n, float* pose_cov, float* cost,
                                float* pose_samples_n, float* logweights, float* cost_init, float* pose_opt,
                                float* pose_samples, hipStream_t st);
+unsigned long long amis_forward_split_bytes(const epropnp_problem* prob, int mc_samples, int num_iter);
 int launch_evaluate_cost(const epropnp_problem* prob, const float* poses, int num_poses, float* cost, hipStream_t st);
 int launch_cost_pose_cam_grad(const epropnp_problem* prob, const float* poses, const float* weights, int num_poses,
                               int m_pose, float* out_m, float* out_gk, hipStream_t st);

@@ -36,7 +36,8 @@ class LmParams(C.Structure):
 class AmisParams(C.Structure):
     _fields_ = [('mc_samples', C.c_int32), ('num_iter', C.c_int32), ('eps', C.c_float),
                 ('acg_mle_iter', C.c_int32), ('acg_dispersion', C.c_float), ('seed', C.c_uint64),
-                ('offset', C.c_uint64), ('offset_dev', C.c_void_p)]
+                ('offset', C.c_uint64), ('offset_dev', C.c_void_p), ('split_scratch', C.c_void_p),
+                ('split_scratch_bytes', C.c_uint64)]
 
 
 class McParams(C.Structure):
@@ -56,6 +57,8 @@ def _declare(lib):
     lib.epropnp_last_error.restype = C.c_char_p
     lib.epropnp_noise_stride.argtypes = [C.c_int]
     lib.epropnp_profile_enable.argtypes = [C.c_int]
+    lib.epropnp_amis_forward_split_bytes.argtypes = [C.POINTER(Problem), C.c_int32, C.c_int32]
+    lib.epropnp_amis_forward_split_bytes.restype = C.c_uint64
     lib.epropnp_async_status.argtypes = [C.POINTER(C.c_int32), C.c_int]
     lib.epropnp_async_status.restype = C.c_int
     lib.epropnp_async_status_word.restype = C.POINTER(C.c_int32)
@@ -101,7 +104,7 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_pose_opt_plus_forward', 'epropnp_pose_opt_plus_backward', 'epropnp_shift_poses_backward',
            'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split',
            'epropnp_monte_carlo_forward', 'epropnp_cost_pose_cam_grad', 'epropnp_async_status',
-           'epropnp_async_status_word')
+           'epropnp_async_status_word', 'epropnp_amis_forward_split_bytes')
 
 
 def lib():
@@ -190,6 +193,7 @@ def profile_read(stage):
 
 
 ST_LM_NOT_SPD, ST_NONFINITE_POSE = 1, 2          # include/epropnp_hip.h: the two events the reference raises on
+ST_SPLIT_TIMEOUT = 16                            # a workgroup of a split forward gave up waiting: outputs invalid
 _status_words = {}
 
 
@@ -218,6 +222,9 @@ def poll_status():
     if flags:
         first = w[1]
         w[0], w[1] = 0, 2 ** 31 - 1
+        if flags & ST_SPLIT_TIMEOUT:
+            raise RuntimeError(f'amis_forward: a workgroup of object {first} timed out waiting for its siblings (split over '
+                               f'workgroups, device {dev}): the outputs of that launch are invalid; set EPROPNP_FWD_SPLIT=1')
         msg = None
         if flags & ST_LM_NOT_SPD:
             msg = (f'linalg.solve: the damped normal equations of object {first} are singular or not finite '

@@ -214,12 +214,11 @@ class EProPnPBase(torch.nn.Module):
         cfg = self._amis_config(noise)
         par = _hip.McParams()
         par.lm = hip._lm_struct(sv, fast_mode)
-        par.amis = _hip.AmisParams(cfg['mc_samples'], cfg['num_iter'], cfg['eps'], int(cfg['acg_mle_iter']),
-                                   cfg['acg_dispersion'], int(cfg['seed']), int(cfg['offset']),
-                                   _hip.ptr(cfg.get('offset_dev')))
+        par.amis, split_scratch = hip._amis_struct(prob, cfg['mc_samples'], cfg['num_iter'], cfg['eps'], cfg['acg_mle_iter'],
+                                                   cfg['acg_dispersion'], cfg['seed'], cfg['offset'], cfg.get('offset_dev'))
         par.normalize = int(bool(self.normalize))
         par.init_mode = 1 if pose_init is None else (2 if force_init_solve else 0)
-        keep = None
+        keep = split_scratch
         if par.init_mode:
             init = sv.init_solver
             par.rslm_lm = hip._lm_struct(init, fast_mode)
@@ -238,7 +237,7 @@ class EProPnPBase(torch.nn.Module):
             par.rslm_seed = init._draw_seed
             par.rslm_offset = 0 if counter is not None else init._draw_calls - 1
             par.rslm_offset_dev, par.rslm_inds, par.rslm_rot = _hip.ptr(counter), _hip.ptr(inds), _hip.ptr(rot)
-            keep = (inds, rot, counter)
+            keep = (inds, rot, counter, split_scratch)
         delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
         pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
             x3d, x2d, w2d, delta, prob, pose_init, par, noise, bool(with_cost))

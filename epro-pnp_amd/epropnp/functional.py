@@ -319,6 +319,23 @@ def noise_stride(dof):
     return _hip.lib().epropnp_noise_stride(dof)
 
 
+def split_scratch(prob, mc_samples, num_iter):
+    """Scratch for the AMIS forward's split over workgroups (few objects: csrc/amis_forward_mfma.hip), or None when the
+    library would not split this problem.  From torch's caching allocator: no HIP allocation on the step's path, and inside
+    a hipGraph capture no alloc / free nodes (which cost more than the split saves)."""
+    if prob.B > 64:
+        return None
+    nbytes = int(_hip.lib().epropnp_amis_forward_split_bytes(C.byref(prob.c), int(mc_samples), int(num_iter)))
+    return prob.new((nbytes + 3) // 4) if nbytes > 0 else None
+
+
+def _amis_struct(prob, S, K, eps, acg_mle_iter, acg_dispersion, seed, offset, offset_dev):
+    """-> (epropnp_amis_params, the scratch tensor to keep alive until the launch is enqueued)"""
+    scratch = split_scratch(prob, S, K)
+    return _hip.AmisParams(int(S), int(K), eps, int(acg_mle_iter), acg_dispersion, int(seed), int(offset), _hip.ptr(offset_dev),
+                           _hip.ptr(scratch), 0 if scratch is None else scratch.numel() * 4), scratch
+
+
 def amis_forward(prob, pose_opt, pose_cov, mc_samples, num_iter, eps=1e-5, acg_mle_iter=3, acg_dispersion=0.001,
                  noise=None, seed=0, offset=0, with_proposals=False, offset_dev=None):
     """-> pose_samples (S,B,pose_len), logweights (S,B) [, proposals (B,K,40)]."""
@@ -330,10 +347,10 @@ def amis_forward(prob, pose_opt, pose_cov, mc_samples, num_iter, eps=1e-5, acg_m
     if noise is not None:
         nz = _f32c(noise, 'noise')
         assert nz.shape == (B, num_iter, S // num_iter, noise_stride(prob.dof)), f'noise shape {tuple(nz.shape)}'
-    par = _hip.AmisParams(S, int(num_iter), eps, int(acg_mle_iter), acg_dispersion, int(seed), int(offset),
-                          _hip.ptr(offset_dev))
+    par, scratch = _amis_struct(prob, S, num_iter, eps, acg_mle_iter, acg_dispersion, seed, offset, offset_dev)
     _hip.call('epropnp_amis_forward', C.byref(prob.c), C.byref(par), _hip.ptr(po), _hip.ptr(pc), _hip.ptr(nz),
               _hip.ptr(samples), _hip.ptr(logw), _hip.ptr(props), prob.stream)
+    del scratch          # stream-ordered reuse by the caching allocator: the launch is enqueued
     return (samples, logw, props) if with_proposals else (samples, logw)
 
 

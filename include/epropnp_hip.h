@@ -61,6 +61,8 @@ typedef struct epropnp_problem {
 #define EPROPNP_ST_CHOL_FALLBACK 4     /* a proposal covariance was replaced by its default (cholesky_wrapper,
                                           epropnp.py:16-33: what the reference does silently as well)                  */
 #define EPROPNP_ST_NONFINITE_WEIGHT 8  /* an AMIS log-weight is NaN / +inf                                              */
+#define EPROPNP_ST_SPLIT_TIMEOUT 16    /* amis_forward split over workgroups (few objects): a part gave up waiting for its
+                                          siblings' partial costs -- the object's outputs are invalid                   */
 
 /* Trust-region parameters of LMSolver.__init__ (epropnp/levenberg_marquardt.py:31-53). */
 typedef struct epropnp_lm_params {
@@ -85,7 +87,17 @@ typedef struct epropnp_amis_params {
   uint64_t offset;        /* Philox counter offset (advance by 1 per call for fresh draws) */
   const uint64_t* offset_dev; /* optional DEVICE counter added to `offset` when the kernel runs: lets a captured hipGraph
                                  draw fresh samples on every replay (the caller increments it inside the graph) */
+  void* split_scratch;        /* optional DEVICE scratch of `split_scratch_bytes` bytes (or NULL / 0).  With few objects
+                                 (one workgroup per object would leave most CUs idle) epropnp_amis_forward deals an object's
+                                 point tiles to several workgroups, which exchange partial costs through this buffer; it
+                                 takes the split only if the buffer holds epropnp_amis_forward_split_bytes() bytes.  The
+                                 library fills it on the stream before the launch; contents are undefined afterwards.     */
+  uint64_t split_scratch_bytes;
 } epropnp_amis_params;
+
+/* Bytes of `split_scratch` with which epropnp_amis_forward would split the objects of this problem over workgroups
+ * (0: it would not -- enough objects to fill the device, too few point tiles, or a shape the split does not serve). */
+uint64_t epropnp_amis_forward_split_bytes(const epropnp_problem* prob, int32_t mc_samples, int32_t num_iter);
 
 /* Everything EProPnPBase.monte_carlo_forward does between its arguments and its return tuple
  * (epropnp/epropnp.py:87-196): one host call that enqueues, in order,

@@ -333,6 +333,50 @@ def test_forward_kernel_variants_agree(backend, monkeypatch):
     assert (torch.logsumexp(w1, 0) - torch.logsumexp(w3, 0)).abs().max().item() < 1e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('dof,bounds,B,N,S,K', [(6, None, 32, 512, 512, 4), (6, 'tight', 20, 300, 96, 3), (4, 'tensor', 64, 128, 128, 4),
+                                               (6, None, 3, 1000, 64, 2)])
+def test_forward_split_over_workgroups(monkeypatch, dof, bounds, B, N, S, K):
+    """Few objects: G workgroups share an object's point tiles and exchange partial costs through global memory behind a
+    per-object arrival counter (csrc/amis_forward_mfma.hip).  Same samples as the one-workgroup kernel (the sampler runs
+    redundantly in every part), log-weights equal up to the summation order of the partial costs, the oracle's log-weights
+    at the kernel's own samples, bit-reproducible, and usable twice at once on two streams."""
+    import install as emu
+    emu.uninstall()
+    from epropnp import functional as F
+    dev = torch.device('cuda:0')
+    prob = orc.make_problem(B, N, dof, seed=19, bounds=bounds)
+    noise = pack_noise(orc.make_noise(B, S, K, dof, seed=20), dof).to(dev)
+    p, cam, cf = make_layer_objects(prob, dev)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
+    monkeypatch.setenv('EPROPNP_FWD_SPLIT', '1')
+    s1, w1, pr1 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise, with_proposals=True)
+    monkeypatch.delenv('EPROPNP_FWD_SPLIT')
+    outs = [F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise, with_proposals=True) for _ in range(2)]
+    s2, w2, pr2 = outs[0]
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))                       # bit-reproducible
+    assert (s1 - s2).abs().max().item() <= 1e-4 * max(1.0, s1.abs().max().item())
+    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3
+    samples, logw, props = s2.cpu(), w2.cpu(), pr2.cpu()
+    ocam = orc.Cam(prob['cam_mats'].double(), 0.1, None if bounds is None else prob['lb'].double(),
+                   None if bounds is None else prob['ub'].double())
+    cost = orc.evaluate(prob['x3d'].double(), prob['x2d'].double(), prob['w2d'].double(), samples.double(), ocam,
+                        prob['delta'].double(), want_cost=True)[1]
+    expect = -cost.float() - _mixture_logq(samples, props, dof, K)
+    assert (logw - expect).abs().max().item() <= 2e-4 * max(1.0, expect.abs().max().item())
+    # two split launches in flight at once (their parts wait for each other: both grids must fit the device together)
+    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    both = []
+    for q in st:
+        q.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(q):
+            both.append(F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise))
+    torch.cuda.synchronize()
+    F.flush_status()
+    assert all(torch.equal(o[1], w2) for o in both)
+
+
 def test_von_mises_draws_match_oracle_over_kappa_range(backend):
     """The device's bounded Best-Fisher sampler (fp32, cancellation-free form, fp64 only for borderline decisions) makes
     the same accept/reject decisions and returns the same angles as the oracle's fp64 procedure, from nearly uniform
