@@ -115,7 +115,7 @@ struct MfmaShape {
 // floats per object -- lives in a global scratch buffer instead of LDS, for mc_samples beyond what 160 KiB hold
 // (the reference has no such limit).  Same code: the arrays are reached through pointers either way, every hand-over
 // between threads goes through a workgroup barrier, and a workgroup's global accesses share one L1.
-template <int DOF, bool BOUNDS, int NPT, bool SPILL = false>
+template <int DOF, bool BOUNDS, int NPT, bool SPILL = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
@@ -126,14 +126,17 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
                                                                   float* __restrict__ spill, int nsplit,
                                                                   float* __restrict__ xch) {
   static_assert(!SPILL || NPT == 0, "the spill variant streams the points");
+  static_assert(!SPLIT || NPT > 0, "the split over workgroups is a register-mode variant");
   constexpr int PL = PoseLen<DOF>::value;
   // nsplit = G > 1 (few objects, register mode): G workgroups share one object.  Each runs the whole sampler -- draws, weights
   // and proposal fits are deterministic, so the G copies stay identical -- but sweeps only every G-th group of point tiles;
   // the partial costs of an iteration meet in global memory behind a per-object arrival counter (below).  All parts of an
   // object sit on the same XCD (workgroup g -> XCD g % 8), so the exchange stays in one L2.
-  const int G = nsplit;
+  // (a template parameter: the one-workgroup-per-object instantiations carry none of this -- the scalar registers it keeps
+  // live spilled two VGPRs of the C2 kernel otherwise)
+  const int G = SPLIT ? nsplit : 1;
   int b, part = 0;
-  if (G > 1) {
+  if (SPLIT) {
     const int g = (int)blockIdx.x, per = (p.B + 7) >> 3, idx = g >> 3;
     part = idx % G;
     b = (g & 7) * per + idx / G;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
       }
     }
     __syncthreads();
-    if (kRegs && G > 1) {
+    if (kRegs && SPLIT) {
       // ---- exchange of the partial costs between the G parts of this object ----
       // own row = sum over this workgroup's waves (fixed order) -> global slot [b][it][part][s16]; every thread then polls the
       // words it gathers from the other parts until they are no longer the fill pattern the launcher wrote into the (per-launch,
@@ -554,18 +557,39 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
     grid_split = dim3(padded_object_grid(d.B) * G);
 #endif
   }
-  dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
-    return dispatch_npt(npt, [&](auto NPT) -> int {
-      auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
+  if (G > 1) {
+    dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+      auto go = [&](auto NPT) -> int {
+        auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value, false, true>;
 #ifndef EPROPNP_EMU
-      if (smem > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (smem > 64 * 1024)
+          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-      PNP_LAUNCH(kern, grid_split, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
-                 (float*)nullptr, G, xch);
-      return 0;
+        PNP_LAUNCH(kern, grid_split, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
+                   (float*)nullptr, G, xch);
+        return 0;
+      };
+      switch (npt) {
+        case 1: return go(ic<1>{});
+        case 2: return go(ic<2>{});
+        case 4: return go(ic<4>{});
+        default: return go(ic<8>{});
+      }
     });
-  });
+  } else {
+    dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+      return dispatch_npt(npt, [&](auto NPT) -> int {
+        auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
+#ifndef EPROPNP_EMU
+        if (smem > 64 * 1024)
+          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+        PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
+                   (float*)nullptr, 1, (float*)nullptr);
+        return 0;
+      });
+    });
+  }
 #ifndef EPROPNP_EMU
   if (owned != nullptr) (void)hipFreeAsync(owned, st);
 #endif
