@@ -190,8 +190,8 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
           const float ppx = hx[r] * rz, ppy = hy[r] * rz;          // un-clamped projection
           float px = ppx, py = ppy;
           if (BOUNDS) {
-            px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-            py = fminf(fmaxf(py, bd.lby), bd.uby);
+            px = clamp_lu(px, bd.lbx, bd.ubx);
+            py = clamp_lu(py, bd.lby, bd.uby);
           }
           const float rx = fmaf(px, w4.x, w4.z), ry = fmaf(py, w4.y, w4.w);
 #ifndef PNP_BWD_NO_FOLD
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
           A1x[i] += crx;
           A1y[i] += cry;
           float gpx = crx * w4.x, gpy = cry * w4.y;
-          if (BOUNDS) {                                        // the clamp passes no gradient where it is active
-            gpx = (ppx < bd.lbx || ppx > bd.ubx) ? 0.f : gpx;
-            gpy = (ppy < bd.lby || ppy > bd.uby) ? 0.f : gpy;
+          if (BOUNDS) {                  // the clamp passes no gradient where it is active: inside [lb, ub] <=> clamp(x) == x
+            gpx = (px == ppx) ? gpx : 0.f;
+            gpy = (py == ppy) ? gpy : 0.f;
           }
           const float ghx = gpx * rz, ghy = gpy * rz;
 #ifdef PNP_BWD_SELECT_FRONT

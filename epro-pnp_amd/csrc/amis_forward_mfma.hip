@@ -85,8 +85,8 @@ __device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& h
     } else {
       f32x2 px2 = hx2 * rz2, py2 = hy2 * rz2;
       if (BOUNDS) {
-        px2 = f32x2{fminf(fmaxf(px2[0], bd.lbx), bd.ubx), fminf(fmaxf(px2[1], bd.lbx), bd.ubx)};
-        py2 = f32x2{fminf(fmaxf(py2[0], bd.lby), bd.uby), fminf(fmaxf(py2[1], bd.lby), bd.uby)};
+        px2 = f32x2{clamp_lu(px2[0], bd.lbx, bd.ubx), clamp_lu(px2[1], bd.lbx, bd.ubx)};
+        py2 = f32x2{clamp_lu(py2[0], bd.lby, bd.uby), clamp_lu(py2[1], bd.lby, bd.uby)};
       }
       rx2 = fma2(px2, wu2, cu2);
       ry2 = fma2(py2, wv2, cv2);

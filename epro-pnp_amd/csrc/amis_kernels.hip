@@ -278,8 +278,8 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
         const float ppx = hx * rz, ppy = hy * rz;          // un-clamped projection
         float px = ppx, py = ppy;
         if (BOUNDS) {
-          px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-          py = fminf(fmaxf(py, bd.lby), bd.uby);
+          px = clamp_lu(px, bd.lbx, bd.ubx);
+          py = clamp_lu(py, bd.lby, bd.uby);
         }
         const float dx = px - q.u, dy = py - q.v;
         const float rx = dx * q.wu, ry = dy * q.wv;

@@ -115,8 +115,8 @@ __global__ __launch_bounds__(MAXW * 64) void evaluate_cost_kernel(Problem p, con
           const float z = fmaxf(hz, p.z_min);
           float px = hx / z, py = hy / z;
           if (BOUNDS) {
-            px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-            py = fminf(fmaxf(py, bd.lby), bd.uby);
+            px = clamp_lu(px, bd.lbx, bd.ubx);
+            py = clamp_lu(py, bd.lby, bd.uby);
           }
           const float rx = (px - q.u) * q.wu, ry = (py - q.v) * q.wv;
           c[jj] += huber_exact(sqrtf(rx * rx + ry * ry), delta);
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void cost_pose_cam_grad_kernel(Problem p, cons
       const float ppx = hx / z, ppy = hy / z;
       float px = ppx, py = ppy;
       if (BOUNDS) {
-        px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-        py = fminf(fmaxf(py, bd.lby), bd.uby);
+        px = clamp_lu(px, bd.lbx, bd.ubx);
+        py = clamp_lu(py, bd.lby, bd.uby);
       }
       const float rx = (px - q.u) * q.wu, ry = (py - q.v) * q.wv;
       const float rho = sqrtf(rx * rx + ry * ry);

@@ -43,8 +43,8 @@ PNP_FN void point_forward(const Point& p, const float (&K)[9], const float (&R)[
   f.px = f.ppx;
   f.py = f.ppy;
   if (BOUNDS) {
-    f.px = fminf(fmaxf(f.px, bd.lbx), bd.ubx);
-    f.py = fminf(fmaxf(f.py, bd.lby), bd.uby);
+    f.px = clamp_lu(f.px, bd.lbx, bd.ubx);
+    f.py = clamp_lu(f.py, bd.lby, bd.uby);
   }
   f.d0[0] = K[0] * f.rz; f.d0[1] = K[1] * f.rz; f.d0[2] = (K[2] - f.px) * f.rz;
   f.d1[0] = K[3] * f.rz; f.d1[1] = K[4] * f.rz; f.d1[2] = (K[5] - f.py) * f.rz;

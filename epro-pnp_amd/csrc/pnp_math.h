@@ -157,6 +157,18 @@ struct Bounds {   // projection clamp; only used when the kernel is instantiated
   float lbx, lby, ubx, uby;
 };
 
+// clamp(x, lo, hi) of camera.py:81-93 as ONE instruction: the median of three (v_med3_f32) is the clamp whenever lo <= hi,
+// a NaN x comes out as lo exactly as fminf(fmaxf(x, lo), hi) gives it, and x < lo / x > hi return lo / hi themselves, so
+// the equality tests of clip_jac still see the bound.  min + max are two half-rate instructions per coordinate: 8 of them per
+// two point-poses were a fifth of the AMIS sweeps' VALU time under a projection clamp (profiles/r03_tune_clamp_med3.txt).
+PNP_FN float clamp_lu(float x, float lo, float hi) {
+#ifndef EPROPNP_EMU
+  return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+  return fminf(fmaxf(x, lo), hi);
+#endif
+}
+
 // Huber cost of one point under pose (KR, Kt): cost-only path (project_b).  FAST selects the 1-ulp
 // hardware rcp/sqrt (AMIS sweeps); otherwise IEEE division / sqrt (cost_init, evaluate_cost).
 template <bool BOUNDS, bool FAST>
@@ -176,8 +188,8 @@ PNP_FN float point_cost(const Point& p, const float (&KR)[9], const float (&Kt)[
     py = hy / z;
   }
   if (BOUNDS) {
-    px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-    py = fminf(fmaxf(py, bd.lby), bd.uby);
+    px = clamp_lu(px, bd.lbx, bd.ubx);
+    py = clamp_lu(py, bd.lby, bd.uby);
   }
   const float rx = (px - p.u) * p.wu;
   const float ry = (py - p.v) * p.wv;
@@ -219,8 +231,8 @@ PNP_FN float sweep_cost(const SweepPoint& p, const float (&KR)[9], const float (
   const float rz = fast_rcp(fmaxf(hz, z_min));
   float px = hx * rz, py = hy * rz;
   if (BOUNDS) {
-    px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-    py = fminf(fmaxf(py, bd.lby), bd.uby);
+    px = clamp_lu(px, bd.lbx, bd.ubx);
+    py = clamp_lu(py, bd.lby, bd.uby);
   }
   const float rx = fmaf(px, p.wu, p.cu);
   const float ry = fmaf(py, p.wv, p.cv);

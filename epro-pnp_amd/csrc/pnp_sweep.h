@@ -101,8 +101,8 @@ PNP_FN void point_normal_eq(const Point& p, const float (&K)[9], const float (&R
   rz = rz * fmaf(-z, rz, 2.0f);
   float px = hx * rz, py = hy * rz;
   if (BOUNDS) {
-    px = fminf(fmaxf(px, bd.lbx), bd.ubx);
-    py = fminf(fmaxf(py, bd.lby), bd.uby);
+    px = clamp_lu(px, bd.lbx, bd.ubx);
+    py = clamp_lu(py, bd.lby, bd.uby);
   }
   float J0[DOF], J1[DOF];
   J0[0] = K[0] * rz; J0[1] = K[1] * rz; J0[2] = (K[2] - px) * rz;
