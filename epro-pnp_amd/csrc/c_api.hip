@@ -250,10 +250,15 @@ int epropnp_pose_opt_plus_backward(const epropnp_problem* prob, float eps, const
 
 int epropnp_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int32_t num_proposals,
                        int32_t num_points, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                       const int64_t* inds, const float* rot, float* pose, float* cost, void* stream) {
+                       const int64_t* inds, const float* rot, float* pose, float* cost, void* scratch,
+                       uint64_t scratch_bytes, void* stream) {
   pnp::StageScope prof_("rslm_solve", (hipStream_t)stream);
   return pnp::launch_rslm_solve(prob, lm, num_proposals, num_points, seed, offset, (const unsigned long long*)offset_dev,
-                                (const long long*)inds, rot, pose, cost, (hipStream_t)stream);
+                                (const long long*)inds, rot, pose, cost, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+uint64_t epropnp_rslm_solve_scratch_bytes(const epropnp_problem* prob, int32_t num_proposals) {
+  return pnp::rslm_scratch_bytes(prob, num_proposals);
 }
 
 int epropnp_center_points(const float* x3d, int32_t num_obj, int32_t num_pts, float* offset, float* x3d_centered,

@@ -64,7 +64,7 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
     StageScope ps("rslm_solve", st);
     if ((rc = launch_rslm_solve(&q, &par->rslm_lm, par->rslm_proposals, par->rslm_points, par->rslm_seed, par->rslm_offset,
                                 (const unsigned long long*)par->rslm_offset_dev, (const long long*)par->rslm_inds,
-                                par->rslm_rot, start_pose, start_cost, st)))
+                                par->rslm_rot, start_pose, start_cost, par->rslm_scratch, par->rslm_scratch_bytes, st)))
       return rc;
     if (par->init_mode == 2) {
       PNP_LAUNCH(select_start_kernel, dim3((B * PL + 255) / 256), dim3(256), 0, st, pinit, cost_init, start_pose, start_cost,

@@ -133,7 +133,9 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
                               float* grad_x2d, float* grad_w2d, float* grad_delta, int nsplit, hipStream_t st);
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
                       unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
-                      float* pose_out, float* cost_out, hipStream_t st);
+                      float* pose_out, float* cost_out, void* scratch, unsigned long long scratch_bytes,
+                      hipStream_t st);
+unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int num_proposals);
 int launch_center_points(const float* x3d, int B, int N, float* offset, float* out, hipStream_t st);
 int launch_shift_poses(const float* pose, const float* offset, int P, int B, int dof, float sign, float* out,
                        hipStream_t st);

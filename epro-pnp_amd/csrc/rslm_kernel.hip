@@ -51,11 +51,17 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
                                                           const unsigned long long* __restrict__ offset_dev,
                                                           const long long* __restrict__ inds,
                                                           const float* __restrict__ rot, float* __restrict__ pose_out,
-                                                          float* __restrict__ cost_out) {
+                                                          float* __restrict__ cost_out, int parts, float* __restrict__ cand_out) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NV = NormalEq<DOF>::NV;
-  const int b = object_of_block(p.B);
-  if (b >= p.B) return;
+  // parts > 1: the proposals of an object are dealt to `parts` workgroups (v = b * parts + part), each keeps the best of its
+  // share and writes it to cand_out[part][b][PL + 1]; rslm_reduce_kernel picks the winner.  An object's 64 proposals are
+  // four rounds of one workgroup: at 600 objects on 256 CUs a CU gets two or three such workgroups (as long as 768 objects
+  // take), and at <= 256 objects the rounds in sequence are the whole run time (profiles/r03_rslm_parts.txt).
+  const int v = object_of_block(p.B * parts);
+  if (v >= p.B * parts) return;
+  const int b = v / parts, part = v - b * parts;
+  const int P_lo = (int)(((long long)P * part) / parts), P_hi = (int)(((long long)P * (part + 1)) / parts);
   const int tid = (int)threadIdx.x, l16 = tid & 15, row = tid >> 4, N = p.N;
   const unsigned long long offset = offset_in + (offset_dev ? *offset_dev : 0ull);
 #ifdef PNP_TUNING
@@ -134,9 +140,9 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
 #pragma unroll
   for (int i = 0; i < PL; ++i) best_pose[i] = 0.f;
   float* mykey = key + row * Np;
-  for (int j0 = 0; j0 < P; j0 += kRslmRows) {
-    const bool active = (j0 + row) < P;
-    const int j = active ? j0 + row : P - 1;
+  for (int j0 = P_lo; j0 < P_hi; j0 += kRslmRows) {
+    const bool active = (j0 + row) < P_hi;
+    const int j = active ? j0 + row : P_hi - 1;
     const size_t prow = (size_t)j * p.B + b;                 // (proposal, object) row of the composite path
 
     // ---- sub-sample: n_pts distinct indices ~ mean weight (:305-308) ----
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
       c = row_sum16(c);
     }
     PNP_RSLM_PHASE(4);
-    if (active && (j0 == 0 || c < best_cost)) {
+    if (active && (j0 == P_lo || c < best_cost)) {
       best_cost = c;
 #pragma unroll
       for (int i = 0; i < PL; ++i) best_pose[i] = pose[i];
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
   __syncthreads();
   float* cand = red;      // [16][PL + 1]
   if (l16 == 0) {
-    cand[row * (PL + 1)] = (row < P) ? best_cost : INFINITY;
+    cand[row * (PL + 1)] = (row < P_hi - P_lo) ? best_cost : INFINITY;
 #pragma unroll
     for (int i = 0; i < PL; ++i) cand[row * (PL + 1) + 1 + i] = best_pose[i];
   }
@@ -280,19 +286,66 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
   if (tid == 0) {
     int w = 0;
     float wc = cand[0];
-    for (int r = 1; r < kRslmRows && r < P; ++r) {
+    for (int r = 1; r < kRslmRows && r < P_hi - P_lo; ++r) {
       const float cr = cand[r * (PL + 1)];
       if (cr < wc) { wc = cr; w = r; }
     }
+    if (parts > 1) {
+      float* dst = cand_out + ((size_t)part * p.B + b) * (PL + 1);
+      dst[0] = wc;
 #pragma unroll
-    for (int i = 0; i < PL; ++i) pose_out[(size_t)b * PL + i] = cand[w * (PL + 1) + 1 + i];
-    if (cost_out) cost_out[b] = wc;
+      for (int i = 0; i < PL; ++i) dst[1 + i] = cand[w * (PL + 1) + 1 + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < PL; ++i) pose_out[(size_t)b * PL + i] = cand[w * (PL + 1) + 1 + i];
+      if (cost_out) cost_out[b] = wc;
+    }
   }
+}
+
+// winner over the parts of an object (ties: the lowest part = the lowest proposal index, as the single-workgroup kernel)
+template <int PL>
+__global__ __launch_bounds__(256) void rslm_reduce_kernel(const float* __restrict__ cand, int B, int parts,
+                                                          float* __restrict__ pose_out, float* __restrict__ cost_out) {
+  const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (b >= B) return;
+  int w = 0;
+  float wc = cand[(size_t)b * (PL + 1)];
+  for (int q = 1; q < parts; ++q) {
+    const float c = cand[((size_t)q * B + b) * (PL + 1)];
+    if (c < wc) { wc = c; w = q; }
+  }
+  const float* src = cand + ((size_t)w * B + b) * (PL + 1) + 1;
+#pragma unroll
+  for (int i = 0; i < PL; ++i) pose_out[(size_t)b * PL + i] = src[i];
+  if (cost_out) cost_out[b] = wc;
+}
+
+// Parts per object (whole rounds of 16 proposals each), measured (profiles/r03_rslm_parts.txt): up to 256 objects the kernel
+// is pure latency -- rounds in sequence -- and quarters win (75 x 64 proposals: 40 -> 22 us); up to 768 objects halves even
+// out the two-or-three-workgroups-per-CU quantisation (600 x 64: 71 -> 63 us); beyond that the per-workgroup staging of the
+// points costs more than the balance gains.  EPROPNP_RSLM_PARTS=<n> overrides.
+static int rslm_parts(int B, int P) {
+  int best = (B <= 256) ? 4 : (B <= 768 ? 2 : 1);
+  while (best > 1 && P % (kRslmRows * best) != 0) best >>= 1;
+  { int ov[1]; if (env_ints("EPROPNP_RSLM_PARTS", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4) && P % (kRslmRows * ov[0]) == 0) best = ov[0]; }
+  return best;
+}
+
+unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int P) {
+#ifdef EPROPNP_EMU
+  return 0;
+#else
+  if (prob == nullptr || prob->num_obj <= 0 || P < 1) return 0;
+  const int q = rslm_parts(prob->num_obj, P);
+  const int PL = prob->dof == 6 ? 7 : 4;
+  return q > 1 ? sizeof(float) * (unsigned long long)q * prob->num_obj * (PL + 1) : 0;
+#endif
 }
 
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
                       unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
-                      float* pose_out, float* cost_out, hipStream_t st) {
+                      float* pose_out, float* cost_out, void* scratch, unsigned long long scratch_bytes, hipStream_t st) {
   if (int rc = check_problem(prob)) return rc;
   if (!lm) return fail(EPROPNP_EINVAL, "rslm_solve: params NULL");
   if (prob->num_obj == 0) return EPROPNP_OK;
@@ -310,12 +363,27 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
   k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps;
   const int Np = (d.N + 3) & ~3;
   const size_t smem = sizeof(float) * ((size_t)(7 + kRslmRows) * Np + 128);
-  const dim3 grid(padded_object_grid(d.B)), block(256);
+  int parts = 1;
+#ifndef EPROPNP_EMU
+  parts = rslm_parts(d.B, P);
+  const int PLh = prob->dof == 6 ? 7 : 4;
+  if (parts > 1 && (scratch == nullptr || scratch_bytes < sizeof(float) * (size_t)parts * d.B * (PLh + 1))) parts = 1;
+#endif
+  const dim3 grid(padded_object_grid(d.B * parts)), block(256);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     PNP_LAUNCH((rslm_solve_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, smem, st, d, k, P, n_pts, seed,
-               offset, offset_dev, inds, rot, pose_out, cost_out);
+               offset, offset_dev, inds, rot, pose_out, cost_out, parts, (float*)scratch);
     return 0;
   });
+  if (parts > 1) {
+    if (int rc = check_launch("rslm_solve_kernel")) return rc;
+    const dim3 rgrid((d.B + 255) / 256);
+    if (prob->dof == 6) {
+      PNP_LAUNCH((rslm_reduce_kernel<7>), rgrid, block, 0, st, (const float*)scratch, d.B, parts, pose_out, cost_out);
+    } else {
+      PNP_LAUNCH((rslm_reduce_kernel<4>), rgrid, block, 0, st, (const float*)scratch, d.B, parts, pose_out, cost_out);
+    }
+  }
   return check_launch("rslm_solve_kernel");
 }
 

@@ -44,7 +44,8 @@ class McParams(C.Structure):
     _fields_ = [('lm', LmParams), ('amis', AmisParams), ('normalize', C.c_int32), ('init_mode', C.c_int32),
                 ('rslm_lm', LmParams), ('rslm_points', C.c_int32), ('rslm_proposals', C.c_int32),
                 ('rslm_seed', C.c_uint64), ('rslm_offset', C.c_uint64), ('rslm_offset_dev', C.c_void_p),
-                ('rslm_inds', C.c_void_p), ('rslm_rot', C.c_void_p)]
+                ('rslm_inds', C.c_void_p), ('rslm_rot', C.c_void_p), ('rslm_scratch', C.c_void_p),
+                ('rslm_scratch_bytes', C.c_uint64)]
 
 
 ABI_VERSION = 4
@@ -84,7 +85,9 @@ def _declare(lib):
     lib.epropnp_prepare_dense_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.epropnp_prepare_dense_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.epropnp_rslm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), i32, i32, C.c_uint64, C.c_uint64, vp, vp, vp,
-                                       vp, vp, vp]
+                                       vp, vp, vp, C.c_uint64, vp]
+    lib.epropnp_rslm_solve_scratch_bytes.argtypes = [C.POINTER(Problem), i32]
+    lib.epropnp_rslm_solve_scratch_bytes.restype = C.c_uint64
     lib.epropnp_adaptive_delta.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp]
     lib.epropnp_mc_loss_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.epropnp_mc_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
@@ -104,7 +107,7 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_pose_opt_plus_forward', 'epropnp_pose_opt_plus_backward', 'epropnp_shift_poses_backward',
            'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split',
            'epropnp_monte_carlo_forward', 'epropnp_cost_pose_cam_grad', 'epropnp_async_status',
-           'epropnp_async_status_word', 'epropnp_amis_forward_split_bytes')
+           'epropnp_async_status_word', 'epropnp_amis_forward_split_bytes', 'epropnp_rslm_solve_scratch_bytes')
 
 
 def lib():

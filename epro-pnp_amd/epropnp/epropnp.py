@@ -237,7 +237,9 @@ class EProPnPBase(torch.nn.Module):
             par.rslm_seed = init._draw_seed
             par.rslm_offset = 0 if counter is not None else init._draw_calls - 1
             par.rslm_offset_dev, par.rslm_inds, par.rslm_rot = _hip.ptr(counter), _hip.ptr(inds), _hip.ptr(rot)
-            keep = (inds, rot, counter, split_scratch)
+            rs = hip.rslm_scratch(prob, par.rslm_proposals)
+            par.rslm_scratch, par.rslm_scratch_bytes = _hip.ptr(rs), 0 if rs is None else rs.numel() * 4
+            keep = (inds, rot, counter, split_scratch, rs)
         delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
         pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
             x3d, x2d, w2d, delta, prob, pose_init, par, noise, bool(with_cost))

@@ -702,9 +702,18 @@ def rslm_solve(prob, num_proposals, num_points, num_iter, seed=0, offset=0, inds
     pose, cost = prob.new(prob.B, prob.pose_len), prob.new(prob.B)
     par = _hip.LmParams(int(num_iter), int(bool(fast_mode)), min_lm_diagonal, max_lm_diagonal, min_relative_decrease,
                         initial_trust_region_radius, max_trust_region_radius, eps)
+    scratch = rslm_scratch(prob, P)
     _hip.call('epropnp_rslm_solve', C.byref(prob.c), C.byref(par), P, n, int(seed), int(offset), _hip.ptr(offset_dev),
-              _hip.ptr(inds), _hip.ptr(rot), _hip.ptr(pose), _hip.ptr(cost), prob.stream)
+              _hip.ptr(inds), _hip.ptr(rot), _hip.ptr(pose), _hip.ptr(cost), _hip.ptr(scratch),
+              0 if scratch is None else scratch.numel() * 4, prob.stream)
     return pose, cost
+
+
+def rslm_scratch(prob, num_proposals):
+    """Scratch with which the RSLM kernel deals an object's proposals to several workgroups (finer load balance), or None
+    when the library would not; from torch's caching allocator (no HIP allocation, no alloc / free graph nodes)."""
+    nbytes = int(_hip.lib().epropnp_rslm_solve_scratch_bytes(C.byref(prob.c), int(num_proposals)))
+    return prob.new((nbytes + 3) // 4) if nbytes > 0 else None
 
 
 class _GnStep(torch.autograd.Function):

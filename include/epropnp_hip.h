@@ -116,6 +116,8 @@ typedef struct epropnp_mc_params {
   const uint64_t* rslm_offset_dev;
   const int64_t* rslm_inds;      /* injected sub-sample indices (P,B,n) or NULL                                      */
   const float* rslm_rot;         /* injected initial rotations or NULL                                               */
+  void* rslm_scratch;            /* optional scratch of epropnp_rslm_solve (see there) or NULL                       */
+  uint64_t rslm_scratch_bytes;
 } epropnp_mc_params;
 
 /*   pose_init (B,pose_len) or NULL (init_mode 1); noise as in epropnp_amis_forward
@@ -324,10 +326,15 @@ int epropnp_shift_poses_backward(const float* pose, const float* offset, const f
  *   inds: NULL (drawn on the device, same stream as epropnp_rslm_draw) or (P,B,num_points) int64 injected indices
  *   rot:  NULL (drawn on the device) or (P,B,1) yaw / (P,B,4) unit quaternions, injected
  *   offset_dev: optional device counter added to `offset` at run time (hipGraph replay), or NULL
+ *   scratch: optional DEVICE buffer of scratch_bytes bytes (or NULL / 0): with epropnp_rslm_solve_scratch_bytes() bytes the
+ *            proposals of an object are dealt to 2 or 4 workgroups (finer load balance: 600 objects x 64 proposals 66 ->
+ *            51 us) whose candidates meet there; contents undefined afterwards.  Results do not depend on it.
  *   -> pose (B,pose_len) best proposal, cost (B,) its full-set Huber cost (may be NULL).   num_pts in [2, 512]. */
 int epropnp_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int32_t num_proposals,
                        int32_t num_points, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                       const int64_t* inds, const float* rot, float* pose, float* cost, void* stream);
+                       const int64_t* inds, const float* rot, float* pose, float* cost, void* scratch,
+                       uint64_t scratch_bytes, void* stream);
+uint64_t epropnp_rslm_solve_scratch_bytes(const epropnp_problem* prob, int32_t num_proposals);
 
 #ifdef __cplusplus
 }
