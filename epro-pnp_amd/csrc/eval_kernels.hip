@@ -420,6 +420,33 @@ __global__ __launch_bounds__(256) void shift_poses_kernel(const float* __restric
   }
 }
 
+// the two shifts of pnp_denormalize (pose_opt and the S x B samples, common.py:127-136) in ONE launch: at the detection shape
+// each is a ~5 us launch around ~1 us of work
+template <int DOF>
+__global__ __launch_bounds__(256) void shift_poses_pair_kernel(const float* __restrict__ pose_a, float* __restrict__ out_a, int Pa,
+                                                                const float* __restrict__ pose_b, float* __restrict__ out_b, int Pb,
+                                                                const float* __restrict__ offset, int B, float sign) {
+  constexpr int PL = PoseLen<DOF>::value;
+  const size_t na = (size_t)Pa * B, total = na + (size_t)Pb * B;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const bool first = g < na;
+    const size_t i = first ? g : g - na;
+    const float* __restrict__ pose = first ? pose_a : pose_b;
+    float* __restrict__ out = first ? out_a : out_b;
+    const int b = (int)(i % (size_t)B);
+    float ps[PL], R[9];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) ps[k] = pose[i * PL + k];
+    pose_to_rot<DOF>(ps, R);
+    const float ox = offset[(size_t)b * 3], oy = offset[(size_t)b * 3 + 1], oz = offset[(size_t)b * 3 + 2];
+    ps[0] += sign * (R[0] * ox + R[1] * oy + R[2] * oz);
+    ps[1] += sign * (R[3] * ox + R[4] * oy + R[5] * oz);
+    ps[2] += sign * (R[6] * ox + R[7] * oy + R[8] * oz);
+#pragma unroll
+    for (int k = 0; k < PL; ++k) out[i * PL + k] = ps[k];
+  }
+}
+
 // backward of shift_poses w.r.t. the pose (the offset is a detached constant, as in pnp_normalize):
 //   out_t = t + sign * R(rot) o   =>   g_t passes through;  g_rot += sign * d(R o)/d(rot)^T g_t
 //   6-DoF, R o = (w^2 - v.v) o + 2 v (v.o) + 2 w (v x o)  (common.py:21-42, q not normalised):
@@ -490,6 +517,18 @@ int launch_shift_poses(const float* pose, const float* offset, int P, int B, int
   if (dof == 6) PNP_LAUNCH(shift_poses_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, pose, offset, P, B, sign, out);
   else PNP_LAUNCH(shift_poses_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, pose, offset, P, B, sign, out);
   return check_launch("shift_poses_kernel");
+}
+
+int launch_shift_poses_pair(const float* pose_a, float* out_a, int Pa, const float* pose_b, float* out_b, int Pb,
+                            const float* offset, int B, int dof, float sign, hipStream_t st) {
+  if (B <= 0 || Pa + Pb <= 0) return EPROPNP_OK;
+  if (!pose_a || !out_a || !pose_b || !out_b || !offset) return fail(EPROPNP_EINVAL, "shift_poses_pair: NULL pointer");
+  const size_t total = (size_t)(Pa + Pb) * B;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dof == 6) PNP_LAUNCH(shift_poses_pair_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, pose_a, out_a, Pa, pose_b, out_b, Pb, offset, B, sign);
+  else PNP_LAUNCH(shift_poses_pair_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, pose_a, out_a, Pa, pose_b, out_b, Pb, offset, B, sign);
+  return check_launch("shift_poses_pair_kernel");
 }
 
 // Correspondence pre-processing of the reference's callers, fused (forward + backward):

@@ -60,13 +60,15 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
     if ((rc = launch_evaluate_cost(&q, pinit, 1, cost_init, st))) return rc;
   }
   const float* start = pinit;
+  bool selected = false;      // the cheaper-of-two selection was folded into the RSLM reduce launch
   if (par->init_mode != 0) {  // random-sample initialiser (levenberg_marquardt.py:115-130,283-353)
     StageScope ps("rslm_solve", st);
     if ((rc = launch_rslm_solve(&q, &par->rslm_lm, par->rslm_proposals, par->rslm_points, par->rslm_seed, par->rslm_offset,
                                 (const unsigned long long*)par->rslm_offset_dev, (const long long*)par->rslm_inds,
-                                par->rslm_rot, start_pose, start_cost, par->rslm_scratch, par->rslm_scratch_bytes, st)))
+                                par->rslm_rot, start_pose, start_cost, par->rslm_scratch, par->rslm_scratch_bytes, st,
+                                par->init_mode == 2 ? pinit : nullptr, par->init_mode == 2 ? cost_init : nullptr, &selected)))
       return rc;
-    if (par->init_mode == 2) {
+    if (par->init_mode == 2 && !selected) {
       PNP_LAUNCH(select_start_kernel, dim3((B * PL + 255) / 256), dim3(256), 0, st, pinit, cost_init, start_pose, start_cost,
                  B, PL);
       if ((rc = check_launch("select_start_kernel"))) return rc;
@@ -77,8 +79,8 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
   { StageScope ps("amis_forward", st); if ((rc = launch_amis_forward(&q, &par->amis, pose_opt_n, pose_cov, noise, pose_samples_n, logweights, nullptr, st))) return rc; }
   if (par->normalize) {       // pnp_denormalize (common.py:127-136)
     StageScope ps("shift_poses", st);
-    if ((rc = launch_shift_poses(pose_opt_n, offset, 1, B, prob->dof, -1.0f, pose_opt, st))) return rc;
-    if ((rc = launch_shift_poses(pose_samples_n, offset, S, B, prob->dof, -1.0f, pose_samples, st))) return rc;
+    if ((rc = launch_shift_poses_pair(pose_opt_n, pose_opt, 1, pose_samples_n, pose_samples, S, offset, B, prob->dof, -1.0f, st)))
+      return rc;
   }
   return EPROPNP_OK;
 }

@@ -134,8 +134,11 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
                       unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
                       float* pose_out, float* cost_out, void* scratch, unsigned long long scratch_bytes,
-                      hipStream_t st);
+                      hipStream_t st, const float* rival_pose = nullptr, const float* rival_cost = nullptr,
+                      bool* rival_taken = nullptr);
 unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int num_proposals);
+int launch_shift_poses_pair(const float* pose_a, float* out_a, int Pa, const float* pose_b, float* out_b, int Pb,
+                            const float* offset, int B, int dof, float sign, hipStream_t st);
 int launch_center_points(const float* x3d, int B, int N, float* offset, float* out, hipStream_t st);
 int launch_shift_poses(const float* pose, const float* offset, int P, int B, int dof, float sign, float* out,
                        hipStream_t st);

@@ -304,9 +304,14 @@ __global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm,
 }
 
 // winner over the parts of an object (ties: the lowest part = the lowest proposal index, as the single-workgroup kernel)
+// rival (optional): a given start pose and its cost -- force_init_solve=True with a pose_init takes, per object, the cheaper
+// of {pose_init, RSLM pose} (levenberg_marquardt.py:124-130: `use_init = cost_init < cost_init_solve`); folded in here it
+// saves the separate selection launch
 template <int PL>
 __global__ __launch_bounds__(256) void rslm_reduce_kernel(const float* __restrict__ cand, int B, int parts,
-                                                          float* __restrict__ pose_out, float* __restrict__ cost_out) {
+                                                          float* __restrict__ pose_out, float* __restrict__ cost_out,
+                                                          const float* __restrict__ rival_pose,
+                                                          const float* __restrict__ rival_cost) {
   const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (b >= B) return;
   int w = 0;
@@ -316,6 +321,7 @@ __global__ __launch_bounds__(256) void rslm_reduce_kernel(const float* __restric
     if (c < wc) { wc = c; w = q; }
   }
   const float* src = cand + ((size_t)w * B + b) * (PL + 1) + 1;
+  if (rival_pose != nullptr && rival_cost[b] < wc) src = rival_pose + (size_t)b * PL;     // (cost_out keeps the RSLM cost)
 #pragma unroll
   for (int i = 0; i < PL; ++i) pose_out[(size_t)b * PL + i] = src[i];
   if (cost_out) cost_out[b] = wc;
@@ -345,7 +351,9 @@ unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int P) {
 
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
                       unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
-                      float* pose_out, float* cost_out, void* scratch, unsigned long long scratch_bytes, hipStream_t st) {
+                      float* pose_out, float* cost_out, void* scratch, unsigned long long scratch_bytes, hipStream_t st,
+                      const float* rival_pose, const float* rival_cost, bool* rival_taken) {
+  if (rival_taken) *rival_taken = false;
   if (int rc = check_problem(prob)) return rc;
   if (!lm) return fail(EPROPNP_EINVAL, "rslm_solve: params NULL");
   if (prob->num_obj == 0) return EPROPNP_OK;
@@ -379,10 +387,13 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
     if (int rc = check_launch("rslm_solve_kernel")) return rc;
     const dim3 rgrid((d.B + 255) / 256);
     if (prob->dof == 6) {
-      PNP_LAUNCH((rslm_reduce_kernel<7>), rgrid, block, 0, st, (const float*)scratch, d.B, parts, pose_out, cost_out);
+      PNP_LAUNCH((rslm_reduce_kernel<7>), rgrid, block, 0, st, (const float*)scratch, d.B, parts, pose_out, cost_out, rival_pose,
+                 rival_cost);
     } else {
-      PNP_LAUNCH((rslm_reduce_kernel<4>), rgrid, block, 0, st, (const float*)scratch, d.B, parts, pose_out, cost_out);
+      PNP_LAUNCH((rslm_reduce_kernel<4>), rgrid, block, 0, st, (const float*)scratch, d.B, parts, pose_out, cost_out, rival_pose,
+                 rival_cost);
     }
+    if (rival_taken) *rival_taken = rival_pose != nullptr && rival_cost != nullptr;
   }
   return check_launch("rslm_solve_kernel");
 }
