@@ -96,3 +96,29 @@ def test_cpp_nodes_guard_and_status(dev):
     with pytest.raises(RuntimeError, match='object 2'):
         with F.numerics_check():
             layer.monte_carlo_forward(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], force_init_solve=False)
+
+
+@pytest.mark.gpu
+def test_mc_loss_node_without_cost_target(dev):
+    """functional.mc_pose_loss(logweights, None): the C++ node has a single tensor input then; its backward must not ask
+    needs_input_grad for an edge that does not exist (it raised 'Index out of range'), and agrees with the ctypes node."""
+    from epropnp import _hip
+    from epropnp import functional as F
+    g = torch.Generator().manual_seed(3)
+    logw0 = torch.randn(40, 6, generator=g).to(dev)
+    grads = []
+    for use_ext in (True, False):
+        if not use_ext:
+            os.environ['EPROPNP_NO_TORCH_EXT'] = '1'
+        _hip._torch_ext = False
+        try:
+            assert (_hip.torch_ext() is not None) == use_ext
+            logw = logw0.clone().requires_grad_(True)
+            loss = F.mc_pose_loss(logw, None)
+            assert torch.allclose(loss, torch.logsumexp(logw0, 0), atol=1e-5)
+            loss.sum().backward()
+            grads.append(logw.grad.clone())
+        finally:
+            os.environ.pop('EPROPNP_NO_TORCH_EXT', None)
+    assert torch.equal(grads[0], grads[1])
+    assert torch.allclose(grads[0], torch.softmax(logw0, 0), atol=1e-6)
