@@ -425,9 +425,8 @@ unsigned long long amis_forward_split_bytes(const epropnp_problem* prob, int mc_
 #else
   if (prob == nullptr || prob->num_obj <= 0 || num_iter <= 0 || mc_samples % num_iter != 0) return 0;
   const int ptiles = (prob->num_pts + 15) / 16;
-  if (ptiles > 8 * 16 || (prob->dof == 4 && ptiles > 8 * 12)) return 0;      // register mode only (launcher below)
   const int g = forward_split_parts(prob->num_obj, ptiles);
-  if (g <= 1) return 0;
+  if (g <= 1 || (ptiles + 4 * g - 1) / (4 * g) > 8) return 0;      // a part must fit 4 waves x 8 register-resident tiles
   const int s16 = ((mc_samples / num_iter + 15) / 16) * 16;
   return sizeof(float) * (unsigned long long)prob->num_obj * num_iter * g * s16;
 #endif
@@ -466,9 +465,11 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
     sh.chunk = 0;
   }
   // Few objects (register mode): G workgroups per object, each sweeping every G-th group of point tiles (kernel comment).
+  // (Decided on the tiles of a PART: 32 objects x 4096 points do not fit one workgroup's registers -- 0.415 ms streaming the
+  // points through LDS on 32 CUs -- but an eighth of them does.)
   int G = 1;
 #ifndef EPROPNP_EMU
-  if (npt > 0) {
+  {
     const int g = forward_split_parts(d.B, ptiles);
     const size_t need = sizeof(float) * (size_t)d.B * K * g * sh.s16;
     int ovf[1];
@@ -476,7 +477,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
     if (g > 1 && (forced || (am->split_scratch != nullptr && am->split_scratch_bytes >= need))) {
       int per_wave = (ptiles + 4 * g - 1) / (4 * g), o = 1;      // tiles per wave, rounded up to an instantiated NPT
       while (o < per_wave) o *= 2;
-      if (o <= 8) { G = g; waves = 4; npt = o; }
+      if (o <= 8) { G = g; waves = 4; npt = o; sh.chunk = 0; }
     }
   }
 #endif
@@ -494,7 +495,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   if (smem > 160 * 1024) {
     // the sampler state does not fit LDS: stream the points (NPT = 0, 8 waves) and keep the per-sample arrays in a global
     // scratch buffer, allocated and released in stream order
-    waves = 8; npt = 0;
+    waves = 8; npt = 0; G = 1;
     sh.chunk = ((d.N + 15) / 16) * 16;
     if (sh.chunk > kChunk) sh.chunk = kChunk;
     const int tiles = sh.s16 / 16;

@@ -336,7 +336,7 @@ def test_forward_kernel_variants_agree(backend, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dof,bounds,B,N,S,K', [(6, None, 32, 512, 512, 4), (6, 'tight', 20, 300, 96, 3), (4, 'tensor', 64, 128, 128, 4),
                                                (6, None, 3, 1000, 64, 2), (4, 'tensor', 16, 512, 64, 2), (6, None, 8, 600, 1024, 2),
-                                               (6, 'tensor', 5, 2048, 60, 1)])
+                                               (6, 'tensor', 5, 2048, 60, 1), (6, None, 32, 4096, 128, 4), (4, 'tensor', 9, 3000, 64, 2)])
 def test_forward_split_over_workgroups(monkeypatch, dof, bounds, B, N, S, K):
     """Few objects: G workgroups share an object's point tiles and exchange partial costs through global memory behind a
     per-object arrival counter (csrc/amis_forward_mfma.hip).  Same samples as the one-workgroup kernel (the sampler runs

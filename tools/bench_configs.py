@@ -71,6 +71,15 @@ def main():
     t = timed(lambda: train_step(layer, x3d, x2d, w2d, cam, cf, p['pose_init'], False))
     out.append(dict(config='C3 LineMOD training: 32 obj x 512 pts, LM 5 + AMIS S=512 K=4, fwd+bwd', ms=round(t * 1e3, 4),
                     instances_per_s=round(B / t, 1)))
+    # ---- C3 dense (BASELINE.json configs[2] as worded): 32 objects x ALL 4096 correspondences of the 64 x 64 crop through
+    # 6-DoF LM + AMIS, fwd+bwd, tensor bounds (the reference trains on a 512-point subset and solves the dense set at test time)
+    B, N = 32, 4096
+    pd = bench.synth_problem(B, N, dev, seed=6)
+    xd = [pd[k].requires_grad_(True) for k in ('x3d', 'x2d', 'w2d')]
+    camd = PerspectiveCamera(cam_mats=pd['cam_mats'], lb=lb, ub=ub)
+    t = timed(lambda: train_step(layer, *xd, camd, cf, pd['pose_init'], False))
+    out.append(dict(config='C3 LineMOD dense: 32 obj x 4096 pts, LM 5 + AMIS S=512 K=4, fwd+bwd', ms=round(t * 1e3, 4),
+                    instances_per_s=round(B / t, 1)))
     # ---- C4 nuScenes: 600 objects x 128 points, 4-DoF, S=128, K=4, normalize, RSLM(16,64,3) + LM 5, image bounds
     B, N = 600, 128
     p = bench.synth_problem(B, N, dev, seed=5, dof=4)
