@@ -161,9 +161,15 @@ int epropnp_normal_equations(const epropnp_problem* prob, const float* pose, int
 }
 
 int epropnp_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
-                     float* pose_cov, float* cost, int32_t* accept_mask, void* stream) {
+                     float* pose_cov, float* cost, int32_t* accept_mask, void* split_scratch, uint64_t split_scratch_bytes,
+                     void* stream) {
   pnp::StageScope prof_("lm_solve", (hipStream_t)stream);
-  return pnp::launch_lm_solve(prob, lm, pose_init, pose_opt, pose_cov, cost, accept_mask, (hipStream_t)stream);
+  return pnp::launch_lm_solve(prob, lm, pose_init, pose_opt, pose_cov, cost, accept_mask, split_scratch, split_scratch_bytes,
+                              (hipStream_t)stream);
+}
+
+uint64_t epropnp_lm_solve_split_bytes(const epropnp_problem* prob, const epropnp_lm_params* lm) {
+  return pnp::lm_split_bytes(prob, lm);
 }
 
 int epropnp_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,

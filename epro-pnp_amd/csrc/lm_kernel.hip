@@ -16,20 +16,38 @@ namespace pnp {
 // reductions are row_ror adds only) -- the shape of the RSLM initialiser's 10^4..10^5 sub-problems.
 // PPL == 0 selects the streaming variant for N beyond the register-resident limit (8192): every sweep re-reads the
 // object's points from HBM / L2 (the reference accepts any N).
-template <int DOF, int PPL, bool BOUNDS, int MAXW>
+// SPLIT (few objects with many points: LineMOD's 32 crops x 4096 dense correspondences keep 32 of 256 CUs busy otherwise): G
+// workgroups share an object's points.  Every part runs the whole iteration -- damping, solve, trust region are deterministic
+// functions of the reduced normal equations, so the G copies stay identical -- but sweeps only its own points; after each
+// sweep the parts' partial normal equations (NV floats each) meet in caller-provided scratch: relaxed agent-scope atomics,
+// the data is its own arrival flag (the same exchange as the AMIS forward's split, csrc/amis_forward_mfma.hip).
+template <int DOF, int PPL, bool BOUNDS, int MAXW, bool SPLIT = false>
 __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(Problem p, LmParams lm, const float* __restrict__ pose_init,
                                                                float* __restrict__ pose_opt, float* __restrict__ pose_cov,
-                                                               float* __restrict__ cost_out, int* __restrict__ accept_out) {
+                                                               float* __restrict__ cost_out, int* __restrict__ accept_out,
+                                                               int nsplit, float* __restrict__ xch) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
+  static_assert(!SPLIT || (MAXW > 0 && MAXW <= 4 && PPL > 0), "the split serves the register-resident <= 4-wave variants");
   // dynamic LDS: transposed reduction scratch (waves * kSumTStride<NV>) for <= 4 waves, NV * 16 for the DPP fallback
+  // (+ NV floats for the split's exchange)
   PNP_DYN_SMEM(float, scratch);
   constexpr bool kRow = (MAXW == 0);
-  const int b_raw = kRow ? (int)(blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4)) : object_of_block(p.B);
+  const int G = SPLIT ? nsplit : 1;
+  int b_raw, part = 0;
+  if (SPLIT) {           // all parts of an object on one XCD (workgroup g -> XCD g % 8)
+    const int g = (int)blockIdx.x, per = (p.B + 7) >> 3, idx = g >> 3;
+    part = idx % G;
+    b_raw = (g & 7) * per + idx / G;
+  } else {
+    b_raw = kRow ? (int)(blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4)) : object_of_block(p.B);
+  }
   if (!kRow && b_raw >= p.B) return;
   const bool live = b_raw < p.B;          // row variant: padded rows compute on object B-1 and write nothing
   const int b = live ? b_raw : p.B - 1;
-  const bool writer = kRow ? (live && (threadIdx.x & 15u) == 0) : (threadIdx.x == 0);
+  const bool writer = kRow ? (live && (threadIdx.x & 15u) == 0) : (threadIdx.x == 0 && part == 0);
+  const int NS = lm.fast_mode ? (lm.num_iter > 0 ? lm.num_iter : 1) : lm.num_iter + 1;      // sweeps per solve
+  int sweep_idx = 0;
 
   float K[9], delta;
   Bounds bd;
@@ -42,7 +60,7 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
   Point pts[PPL > 0 ? PPL : 1];
 #pragma unroll
   for (int k = 0; k < PPL; ++k)
-    pts[k] = load_point(p, b, kRow ? (int)(threadIdx.x & 15u) : (int)threadIdx.x + k * (int)blockDim.x);
+    pts[k] = load_point(p, b, kRow ? (int)(threadIdx.x & 15u) : (SPLIT ? part * PPL * (int)blockDim.x : 0) + (int)threadIdx.x + k * (int)blockDim.x);
 
   float pose[PL];
 #pragma unroll
@@ -72,6 +90,44 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
     } else {
       block_sum<NV>(acc, scratch);
     }
+#ifndef EPROPNP_EMU
+    if (SPLIT) {
+      // this part's NV sums -> slot [b][sweep][part][NV]; lanes 0..NV-1 then add the G rows in part order (their own from
+      // the register, the siblings' polled until no longer the fill pattern) and hand the totals to everyone through LDS
+      const int tid = (int)threadIdx.x;
+      float* xl = scratch + (int)(blockDim.x >> 6) * kSumTStride<NV>;
+      unsigned* slot = reinterpret_cast<unsigned*>(xch) + (((size_t)b * NS + sweep_idx) * G) * NV;
+      float mine = acc[0];
+#pragma unroll
+      for (int i = 1; i < NV; ++i) mine = (tid == i) ? acc[i] : mine;
+      if (tid < NV) {
+        const unsigned bits = (mine != mine) ? 0x7fc00000u : __float_as_uint(mine);
+        __hip_atomic_store(slot + part * NV + tid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float tot = 0.f;
+        bool timed_out = false;
+        for (int q = 0; q < G; ++q) {
+          float v = mine;
+          if (q != part) {
+            unsigned u = __hip_atomic_load(slot + q * NV + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spins = 0; u == 0xffffffffu && spins < (1 << 22); ++spins) {
+              __builtin_amdgcn_s_sleep(1);
+              u = __hip_atomic_load(slot + q * NV + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            timed_out |= (u == 0xffffffffu);
+            v = __uint_as_float(u);
+          }
+          tot += v;
+        }
+        if (timed_out) raise_status(p, EPROPNP_ST_SPLIT_TIMEOUT, b);
+        xl[tid] = tot;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] = xl[i];
+      __syncthreads();
+      ++sweep_idx;
+    }
+#endif
   };
 
   float cur[NV];
@@ -104,8 +160,37 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
   }
 }
 
+// Parts per object for the split, measured (profiles/r03_lm_split.txt): an exchange costs ~3.5 us per sweep, which only pays
+// when an object's sweep keeps a whole CU busy for longer -- beyond 2048 points (32 x 4096, LM 5: 97.8 -> 59.6 us; 64 x 2048:
+// 51.5 -> 55.6, 32 x 512: 28.9 -> 50).  Then: the most parts (<= 8) with at least 256 points each that keep the grid at one
+// workgroup per CU (the parts of an object wait for each other).  EPROPNP_LM_SPLIT=<G> overrides (1: off).
+static int lm_split_parts(int B, int N) {
+  const long wgs = padded_object_grid(B);
+  int g = (N > 2048) ? 8 : 1;
+  while (g > 1 && (wgs * g > 256 || (long)N < 256L * g)) g >>= 1;
+  { int ov[1]; if (env_ints("EPROPNP_LM_SPLIT", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && wgs * ov[0] <= 512 && (long)N >= 64L * ov[0]) g = ov[0]; }
+  return g;
+}
+
+static int lm_sweeps(const epropnp_lm_params* lm) {
+  return lm->fast_mode ? (lm->num_iter > 0 ? lm->num_iter : 1) : lm->num_iter + 1;
+}
+
+unsigned long long lm_split_bytes(const epropnp_problem* prob, const epropnp_lm_params* lm) {
+#ifdef EPROPNP_EMU
+  return 0;
+#else
+  if (prob == nullptr || lm == nullptr || prob->num_obj <= 0 || prob->num_pts <= 16 || prob->num_pts > kMaxResidentPoints) return 0;
+  const int g = lm_split_parts(prob->num_obj, prob->num_pts);
+  const int NV = prob->dof == 6 ? NormalEq<6>::NV : NormalEq<4>::NV;
+  if (g <= 1 || (prob->num_pts + g - 1) / g > 1024) return 0;       // a part: 4 waves x <= 4 points per lane
+  return sizeof(float) * (unsigned long long)prob->num_obj * lm_sweeps(lm) * g * NV;
+#endif
+}
+
 int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
-                    float* pose_cov, float* cost, int32_t* accept_mask, hipStream_t st) {
+                    float* pose_cov, float* cost, int32_t* accept_mask, void* split_scratch,
+                    unsigned long long split_scratch_bytes, hipStream_t st) {
   if (int rc = check_problem(prob)) return rc;
   if (!lm) return fail(EPROPNP_EINVAL, "lm_solve: params NULL");
   if (prob->num_obj == 0) return EPROPNP_OK;
@@ -121,7 +206,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
     const dim3 grid((d.B + 15) / 16), block(256);
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 1, decltype(BND)::value, 0>), grid, block, 0, st, d, k, pose_init,
-                 pose_opt, pose_cov, cost, accept_mask);
+                 pose_opt, pose_cov, cost, accept_mask, 1, (float*)nullptr);
       return 0;
     });
     return check_launch("lm_solve_kernel (row variant)");
@@ -131,11 +216,43 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 0, decltype(BND)::value, 8>), grid, block,
                  sizeof(float) * NormalEq<decltype(DOF)::value>::NV * 16, st, d, k, pose_init, pose_opt, pose_cov, cost,
-                 accept_mask);
+                 accept_mask, 1, (float*)nullptr);
       return 0;
     });
     return check_launch("lm_solve_kernel (streaming)");
   }
+#ifndef EPROPNP_EMU
+  {   // few objects with many points: G workgroups per object (kernel comment); 4 waves per part, <= 2 points per lane
+    const int G = lm_split_parts(d.B, d.N);
+    const int NVh = prob->dof == 6 ? NormalEq<6>::NV : NormalEq<4>::NV;
+    const size_t need = sizeof(float) * (size_t)d.B * lm_sweeps(lm) * G * NVh;
+    const int per_part = (d.N + G - 1) / G;
+    if (G > 1 && split_scratch != nullptr && split_scratch_bytes >= need && per_part <= 1024) {
+      const int ppl = per_part > 512 ? 4 : (per_part > 256 ? 2 : 1);
+      if (hipMemsetAsync(split_scratch, 0xff, need, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(EPROPNP_ELAUNCH, "lm_solve: could not fill the split scratch");
+      }
+      const dim3 grid(padded_object_grid(d.B) * G), block(256);
+      dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
+        constexpr int NVc = NormalEq<decltype(DOF)::value>::NV;
+        const size_t smem = sizeof(float) * (4 * kSumTStride<NVc> + 32);
+        if (ppl == 4) {
+          PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 4, decltype(BND)::value, 4, true>), grid, block, smem, st, d, k,
+                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch);
+        } else if (ppl == 2) {
+          PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 2, decltype(BND)::value, 4, true>), grid, block, smem, st, d, k,
+                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch);
+        } else {
+          PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 1, decltype(BND)::value, 4, true>), grid, block, smem, st, d, k,
+                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch);
+        }
+        return 0;
+      });
+      return check_launch("lm_solve_kernel (split over workgroups)");
+    }
+  }
+#endif
   // fewest waves per object at every batch size: more waves only add cross-wave reduction + barrier latency to each of
   // the 1+L dependent sweeps (measured on MI355X at B = 32 / 256 / 600: 1 wave 38 / 30 / 30 us vs 86 / 62 / 41 us)
   Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/0);
@@ -147,7 +264,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
                grid, block,
                sizeof(float) * (decltype(MAXW)::value <= 4 ? s.waves * kSumTStride<NormalEq<decltype(DOF)::value>::NV>
                                                            : NormalEq<decltype(DOF)::value>::NV * 16),
-               st, d, k, pose_init, pose_opt, pose_cov, cost, accept_mask);
+               st, d, k, pose_init, pose_opt, pose_cov, cost, accept_mask, 1, (float*)nullptr);
     return 0;
   });
   return check_launch("lm_solve_kernel");

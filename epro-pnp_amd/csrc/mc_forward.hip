@@ -75,7 +75,7 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
     }
     start = start_pose;
   }
-  { StageScope ps("lm_solve", st); if ((rc = launch_lm_solve(&q, &par->lm, start, pose_opt_n, pose_cov, cost, nullptr, st))) return rc; }
+  { StageScope ps("lm_solve", st); if ((rc = launch_lm_solve(&q, &par->lm, start, pose_opt_n, pose_cov, cost, nullptr, par->lm_scratch, par->lm_scratch_bytes, st))) return rc; }
   { StageScope ps("amis_forward", st); if ((rc = launch_amis_forward(&q, &par->amis, pose_opt_n, pose_cov, noise, pose_samples_n, logweights, nullptr, st))) return rc; }
   if (par->normalize) {       // pnp_denormalize (common.py:127-136)
     StageScope ps("shift_poses", st);

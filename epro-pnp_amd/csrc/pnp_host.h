@@ -168,7 +168,9 @@ int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, flo
 int launch_mc_loss_backward(const float* logw, const float* lse, const float* loss, const float* g, int S, int B,
                             float* glogw, float* gct, hipStream_t st);
 int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
-                    float* pose_cov, float* cost, int32_t* accept_mask, hipStream_t st);
+                    float* pose_cov, float* cost, int32_t* accept_mask, void* split_scratch,
+                    unsigned long long split_scratch_bytes, hipStream_t st);
+unsigned long long lm_split_bytes(const epropnp_problem* prob, const epropnp_lm_params* lm);
 int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
                         const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
                         float* proposals, hipStream_t st);

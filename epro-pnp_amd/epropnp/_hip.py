@@ -45,7 +45,7 @@ class McParams(C.Structure):
                 ('rslm_lm', LmParams), ('rslm_points', C.c_int32), ('rslm_proposals', C.c_int32),
                 ('rslm_seed', C.c_uint64), ('rslm_offset', C.c_uint64), ('rslm_offset_dev', C.c_void_p),
                 ('rslm_inds', C.c_void_p), ('rslm_rot', C.c_void_p), ('rslm_scratch', C.c_void_p),
-                ('rslm_scratch_bytes', C.c_uint64)]
+                ('rslm_scratch_bytes', C.c_uint64), ('lm_scratch', C.c_void_p), ('lm_scratch_bytes', C.c_uint64)]
 
 
 ABI_VERSION = 4
@@ -68,7 +68,9 @@ def _declare(lib):
     lib.epropnp_evaluate_cost.argtypes = [C.POINTER(Problem), vp, i32, vp, vp]
     lib.epropnp_normal_equations.argtypes = [C.POINTER(Problem), vp, i32, vp, vp, vp, vp]
     lib.epropnp_cost_pose_cam_grad.argtypes = [C.POINTER(Problem), vp, vp, i32, i32, vp, vp, vp]
-    lib.epropnp_lm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), vp, vp, vp, vp, vp, vp]
+    lib.epropnp_lm_solve.argtypes = [C.POINTER(Problem), C.POINTER(LmParams), vp, vp, vp, vp, vp, vp, C.c_uint64, vp]
+    lib.epropnp_lm_solve_split_bytes.argtypes = [C.POINTER(Problem), C.POINTER(LmParams)]
+    lib.epropnp_lm_solve_split_bytes.restype = C.c_uint64
     lib.epropnp_amis_forward.argtypes = [C.POINTER(Problem), C.POINTER(AmisParams), vp, vp, vp, vp, vp, vp, vp]
     lib.epropnp_amis_backward.argtypes = [C.POINTER(Problem), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.epropnp_amis_backward_split.argtypes = [C.POINTER(Problem), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
@@ -107,7 +109,8 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_pose_opt_plus_forward', 'epropnp_pose_opt_plus_backward', 'epropnp_shift_poses_backward',
            'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split',
            'epropnp_monte_carlo_forward', 'epropnp_cost_pose_cam_grad', 'epropnp_async_status',
-           'epropnp_async_status_word', 'epropnp_amis_forward_split_bytes', 'epropnp_rslm_solve_scratch_bytes')
+           'epropnp_async_status_word', 'epropnp_amis_forward_split_bytes', 'epropnp_rslm_solve_scratch_bytes',
+           'epropnp_lm_solve_split_bytes')
 
 
 def lib():

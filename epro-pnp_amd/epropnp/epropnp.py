@@ -214,11 +214,13 @@ class EProPnPBase(torch.nn.Module):
         cfg = self._amis_config(noise)
         par = _hip.McParams()
         par.lm = hip._lm_struct(sv, fast_mode)
+        lm_scratch = hip.lm_split_scratch(prob, par.lm)
+        par.lm_scratch, par.lm_scratch_bytes = _hip.ptr(lm_scratch), 0 if lm_scratch is None else lm_scratch.numel() * 4
         par.amis, split_scratch = hip._amis_struct(prob, cfg['mc_samples'], cfg['num_iter'], cfg['eps'], cfg['acg_mle_iter'],
                                                    cfg['acg_dispersion'], cfg['seed'], cfg['offset'], cfg.get('offset_dev'))
         par.normalize = int(bool(self.normalize))
         par.init_mode = 1 if pose_init is None else (2 if force_init_solve else 0)
-        keep = split_scratch
+        keep = (split_scratch, lm_scratch)
         if par.init_mode:
             init = sv.init_solver
             par.rslm_lm = hip._lm_struct(init, fast_mode)
@@ -239,7 +241,7 @@ class EProPnPBase(torch.nn.Module):
             par.rslm_offset_dev, par.rslm_inds, par.rslm_rot = _hip.ptr(counter), _hip.ptr(inds), _hip.ptr(rot)
             rs = hip.rslm_scratch(prob, par.rslm_proposals)
             par.rslm_scratch, par.rslm_scratch_bytes = _hip.ptr(rs), 0 if rs is None else rs.numel() * 4
-            keep = (inds, rot, counter, split_scratch, rs)
+            keep = (inds, rot, counter, split_scratch, rs, lm_scratch)
         delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
         pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
             x3d, x2d, w2d, delta, prob, pose_init, par, noise, bool(with_cost))

@@ -308,11 +308,21 @@ def lm_solve(prob, pose_init, num_iter, fast_mode=False, with_pose_cov=False, wi
     acc = prob.new(prob.B, dtype=torch.int32) if with_accepts else None
     par = _hip.LmParams(int(num_iter), int(bool(fast_mode)), min_lm_diagonal, max_lm_diagonal, min_relative_decrease,
                         initial_trust_region_radius, max_trust_region_radius, eps)
+    scratch = lm_split_scratch(prob, par)
     _hip.call('epropnp_lm_solve', C.byref(prob.c), C.byref(par), _hip.ptr(ps), _hip.ptr(pose_opt), _hip.ptr(cov),
-              _hip.ptr(cost), _hip.ptr(acc), prob.stream)
+              _hip.ptr(cost), _hip.ptr(acc), _hip.ptr(scratch), 0 if scratch is None else scratch.numel() * 4, prob.stream)
     if with_accepts:
         return pose_opt, cov, cost, acc
     return pose_opt, cov, cost
+
+
+def lm_split_scratch(prob, lm_par):
+    """Scratch with which lm_solve deals the points of an object to several workgroups (few objects x many points), or None
+    when the library would not; from torch's caching allocator."""
+    if prob.B > 128:
+        return None
+    nbytes = int(_hip.lib().epropnp_lm_solve_split_bytes(C.byref(prob.c), C.byref(lm_par)))
+    return prob.new((nbytes + 3) // 4) if nbytes > 0 else None
 
 
 def noise_stride(dof):

@@ -91,7 +91,7 @@ int main() {
   epropnp_lm_params lm = {L, 0, 1e-6f, 1e32f, 1e-3f, 30.0f, 1e16f, 1e-5f};
   PNP_OK(epropnp_evaluate_cost(&prob, d_init, 1, d_cinit, st));
   PNP_OK(epropnp_evaluate_cost(&prob, d_gt, 1, d_cgt, st));       // cost_target of the Monte-Carlo pose loss
-  PNP_OK(epropnp_lm_solve(&prob, &lm, d_init, d_opt, d_cov, d_cost, nullptr, st));
+  PNP_OK(epropnp_lm_solve(&prob, &lm, d_init, d_opt, d_cov, d_cost, nullptr, nullptr, 0, st));
   epropnp_amis_params amis = {S, K, 1e-5f, 3, 0.001f, 1234u, 0u, nullptr};
   PNP_OK(epropnp_amis_forward(&prob, &amis, d_opt, d_cov, nullptr, d_smp, d_logw, nullptr, st));
   PNP_OK(epropnp_mc_loss_forward(d_logw, d_cgt, S, B, d_loss, d_lse, st));

@@ -118,6 +118,8 @@ typedef struct epropnp_mc_params {
   const float* rslm_rot;         /* injected initial rotations or NULL                                               */
   void* rslm_scratch;            /* optional scratch of epropnp_rslm_solve (see there) or NULL                       */
   uint64_t rslm_scratch_bytes;
+  void* lm_scratch;              /* optional split scratch of the main epropnp_lm_solve (see there) or NULL          */
+  uint64_t lm_scratch_bytes;
 } epropnp_mc_params;
 
 /*   pose_init (B,pose_len) or NULL (init_mode 1); noise as in epropnp_amis_forward
@@ -191,8 +193,14 @@ int epropnp_normal_equations(const epropnp_problem* prob, const float* pose, int
  * pose_add :255-265): the whole iteration runs inside one kernel, points stay in registers.
  *   pose_init (B,pose_len) -> pose_opt (B,pose_len); pose_cov (B,dof,dof) or NULL; cost (B,) or NULL;
  *   accept_mask (B,) int32 or NULL: bit i = step i accepted (diagnostics for the trust-region flip rate). */
-int epropnp_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init,
-                     float* pose_opt, float* pose_cov, float* cost, int32_t* accept_mask, void* stream);
+int epropnp_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
+                     float* pose_cov, float* cost, int32_t* accept_mask, void* split_scratch, uint64_t split_scratch_bytes,
+                     void* stream);
+/* split_scratch: optional DEVICE buffer (or NULL / 0).  With few objects of many points (LineMOD: 32 crops x 4096 dense
+ * correspondences on 256 CUs) and epropnp_lm_solve_split_bytes() bytes of scratch, the points of an object are dealt to up to
+ * 8 workgroups that exchange their partial normal equations through it after every sweep; the library fills it on the stream
+ * before the launch, contents are undefined afterwards.  0: the library would not split this problem. */
+uint64_t epropnp_lm_solve_split_bytes(const epropnp_problem* prob, const epropnp_lm_params* lm);
 
 /* The AMIS loop of EProPnPBase.monte_carlo_forward (epropnp/epropnp.py:132-182) including initial_fit,
  * gen_new_distr/gen_old_distr, estimate_params (:199-342), the proposal densities (epropnp/distributions.py,

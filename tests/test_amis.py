@@ -358,7 +358,8 @@ def test_forward_split_over_workgroups(monkeypatch, dof, bounds, B, N, S, K):
     s2, w2, pr2 = outs[0]
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))                       # bit-reproducible
     assert (s1 - s2).abs().max().item() <= 1e-4 * max(1.0, s1.abs().max().item())
-    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3
+    # (the costs behind the log-weights are sums over N points of magnitude |logw|: the two kernels add them in another order)
+    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3 + 2e-6 * w1[torch.isfinite(w1)].abs().max().item()
     samples, logw, props = s2.cpu(), w2.cpu(), pr2.cpu()
     ocam = orc.Cam(prob['cam_mats'].double(), 0.1, None if bounds is None else prob['lb'].double(),
                    None if bounds is None else prob['ub'].double())

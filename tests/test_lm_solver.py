@@ -82,3 +82,49 @@ def test_lm_empty_batch(backend):
                                                         PerspectiveCamera(cam_mats=z(0, 3, 3)), HuberPnPCost(),
                                                         pose_init=z(0, 7), with_pose_cov=True, with_cost=True)
     assert pose.shape == (0, 7) and cov.shape == (0, 6, 6) and cost.shape == (0,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dof,bounds,B,N,lm_iter,fast', [(6, None, 32, 4096, 5, False), (6, 'tensor', 32, 4096, 3, True),
+                                                         (4, 'tensor', 16, 2500, 5, False), (6, 'tight', 5, 3000, 4, False),
+                                                         (6, None, 8, 8192, 10, False), (4, None, 7, 6000, 1, True)])
+def test_lm_split_over_workgroups(monkeypatch, dof, bounds, B, N, lm_iter, fast):
+    """Few objects x many points: the points of an object are dealt to up to 8 workgroups that exchange their partial normal
+    equations after every sweep (csrc/lm_kernel.hip, SPLIT).  Against the one-workgroup kernel (same decisions, sums in
+    another order), against the oracle, bit-reproducible, and twice at once on two streams."""
+    import install as emu
+    emu.uninstall()
+    from epropnp import functional as F
+    dev = torch.device('cuda:0')
+    prob = orc.make_problem(B, N, dof, seed=300 + N, bounds=bounds)
+    p, cam, cf = make_layer_objects(prob, dev)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    kw = dict(fast_mode=fast, with_pose_cov=True, with_cost=True)
+    par = F._hip.LmParams(lm_iter, int(fast), 1e-6, 1e32, 1e-3, 30.0, 1e16, 1e-5)
+    assert F.lm_split_scratch(hp, par) is not None, 'this shape is meant to take the split'
+    monkeypatch.setenv('EPROPNP_LM_SPLIT', '1')
+    one = F.lm_solve(hp, p['pose_init'], lm_iter, **kw)
+    monkeypatch.delenv('EPROPNP_LM_SPLIT')
+    outs = [F.lm_solve(hp, p['pose_init'], lm_iter, **kw) for _ in range(2)]
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    pose, cov, cost = (t.cpu() for t in outs[0])
+
+    def run(q, dt=torch.float32):
+        q = {k: (v.to(dt) if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in q.items()}
+        out = orc.lm_solve(q['x3d'], q['x2d'], q['w2d'], orc.Cam(q['cam_mats'], 0.1, q.get('lb'), q.get('ub')), q['delta'],
+                           q['pose_init'], fast_mode=fast, with_pose_cov=True, with_cost=True, num_iter=lm_iter)
+        return dict(pose_opt=out[0].float(), cost=out[2].float())
+    base = run(prob)
+    sp = orc.rounding_spread(run, prob, base, extra=[run(prob, torch.float64), dict(pose_opt=one[0].cpu(), cost=one[2].cpu())])
+    assert_within_spread((pose - base['pose_opt']).abs().max(-1).values, sp['pose_opt'], POSE_TOL, what='pose_opt')
+    assert_within_spread((cost - base['cost']).abs() / base['cost'].abs().clamp(min=1e-30), sp['cost'], 1e-5, what='cost')
+    assert bool(torch.isfinite(cov).all())
+    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    both = []
+    for q in st:
+        q.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(q):
+            both.append(F.lm_solve(hp, p['pose_init'], lm_iter, **kw))
+    torch.cuda.synchronize()
+    F.flush_status()
+    assert all(torch.equal(o[0], outs[0][0]) for o in both)
