@@ -357,7 +357,8 @@ def test_forward_split_over_workgroups(monkeypatch, dof, bounds, B, N, S, K):
     outs = [F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise, with_proposals=True) for _ in range(2)]
     s2, w2, pr2 = outs[0]
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))                       # bit-reproducible
-    assert (s1 - s2).abs().max().item() <= 1e-4 * max(1.0, s1.abs().max().item())
+    # later iterations' samples come from proposals refitted to weights whose costs were summed in another order
+    assert (s1 - s2).abs().max().item() <= 5e-4 * max(1.0, s1.abs().max().item())
     # (the costs behind the log-weights are sums over N points of magnitude |logw|: the two kernels add them in another order)
     assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3 + 2e-6 * w1[torch.isfinite(w1)].abs().max().item()
     samples, logw, props = s2.cpu(), w2.cpu(), pr2.cpu()
