@@ -379,6 +379,8 @@ def backward_split(B, N, S):
     n = 1
     while n < 8 and 2 * n * B <= 512 and 2 * n * 64 <= N:
         n *= 2
+    if n == 8 and N >= 2048 and 16 * B <= 512:      # dense crops (32 x 4096): two workgroups per CU, 108.6 -> 93.4 us
+        n = 16
     return n
 
 
