@@ -51,7 +51,9 @@ __global__ __launch_bounds__(MAXW * 64) void normal_equations_kernel(Problem p, 
   if (PPL > 0) {
     Point pts[PPL > 0 ? PPL : 1];
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) pts[k] = load_point(p, b, (int)threadIdx.x + k * (int)blockDim.x);
+    // non-temporal: the sweep reads every correspondence exactly once (IC-cold at C2: 17.0-17.8 -> 16.0-16.2 us, 0.43 -> 0.46 of
+    // the HBM peak; no change at the C5 size, where nothing fits a cache anyway: profiles/r03_tune_ne_nt_loads.txt)
+    for (int k = 0; k < PPL; ++k) pts[k] = load_point<true>(p, b, (int)threadIdx.x + k * (int)blockDim.x);
     load_camera<BOUNDS>(p, b, K, bd, delta);
 #pragma unroll
     for (int i = 0; i < PL; ++i) ps[i] = pose[(size_t)b * PL + i];

@@ -46,11 +46,27 @@ __device__ __forceinline__ int object_of_block(int B) {
 }
 __host__ __device__ __forceinline__ int padded_object_grid(int B) { return ((B + 7) >> 3) << 3; }
 
+#ifndef EPROPNP_EMU
+typedef float pnp_f32x2 __attribute__((ext_vector_type(2)));
+#endif
+
+// NT: non-temporal loads for kernels that stream an object's correspondences exactly once (the Jacobian sweep, the LM
+// solve): the lines are not kept in L2 / the Infinity Cache on their way through (MI355X_MICROARCH.md "nt-weights").
+template <bool NT = false>
 __device__ __forceinline__ Point load_point(const Problem& p, int b, int n) {
   Point q;
   if (n < p.N) {
     const size_t i = (size_t)b * (size_t)p.N + (size_t)n;
     const float* a = p.x3d + i * 3;
+#ifndef EPROPNP_EMU
+    if (NT) {
+      q.X = __builtin_nontemporal_load(a); q.Y = __builtin_nontemporal_load(a + 1); q.Z = __builtin_nontemporal_load(a + 2);
+      const pnp_f32x2 u = __builtin_nontemporal_load(reinterpret_cast<const pnp_f32x2*>(p.x2d + i * 2));
+      const pnp_f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const pnp_f32x2*>(p.w2d + i * 2));
+      q.u = u[0]; q.v = u[1]; q.wu = w[0]; q.wv = w[1];
+      return q;
+    }
+#endif
     q.X = a[0]; q.Y = a[1]; q.Z = a[2];
     const float2 u = *reinterpret_cast<const float2*>(p.x2d + i * 2);
     const float2 w = *reinterpret_cast<const float2*>(p.w2d + i * 2);
