@@ -53,7 +53,7 @@ __global__ __launch_bounds__(MAXW * 64) void normal_equations_kernel(Problem p, 
 #pragma unroll
     // non-temporal: the sweep reads every correspondence exactly once (IC-cold at C2: 17.0-17.8 -> 16.0-16.2 us, 0.43 -> 0.46 of
     // the HBM peak; no change at the C5 size, where nothing fits a cache anyway: profiles/r03_tune_ne_nt_loads.txt)
-    for (int k = 0; k < PPL; ++k) pts[k] = load_point<true>(p, b, (int)threadIdx.x + k * (int)blockDim.x);
+    for (int k = 0; k < PPL; ++k) pts[k] = load_point_streamed(p, b, (int)threadIdx.x + k * (int)blockDim.x);
     load_camera<BOUNDS>(p, b, K, bd, delta);
 #pragma unroll
     for (int i = 0; i < PL; ++i) ps[i] = pose[(size_t)b * PL + i];
@@ -65,7 +65,11 @@ __global__ __launch_bounds__(MAXW * 64) void normal_equations_kernel(Problem p, 
     const float zm = to_vgpr(p.z_min), dl = to_vgpr(delta);
     const float ie = to_vgpr(p.inv_huber_eps);
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, zm, dl, ie, bd, clip != 0, acc);
+    for (int k = 0; k < PPL; ++k) {
+      mask_point_beyond(pts[k], (int)threadIdx.x + k * (int)blockDim.x, p.N);
+      point_normal_eq<DOF, BOUNDS>(pts[k], K, R, t, zm, dl, ie, bd, clip != 0, acc);
+      sched_fence();      // point k's arithmetic under the loads of points k+1.. (wave_ops.h)
+    }
   } else {
     load_camera<BOUNDS>(p, b, K, bd, delta);
 #pragma unroll
@@ -837,7 +841,7 @@ int launch_normal_equations(const epropnp_problem* prob, const float* pose, int 
   if (!pose || !jtj || !jtr || !cost) return fail(EPROPNP_EINVAL, "normal_equations: NULL pointer");
   const Problem d = to_device_problem(prob);
   const dim3 grid(padded_object_grid(d.B));
-  if (d.N > kMaxResidentPoints) {     // streaming loop, 8 waves per object
+  if (d.N > kMaxResidentPoints || d.N == 0) {     // streaming loop, 8 waves per object (no points: it writes zeros)
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       PNP_LAUNCH((normal_equations_kernel<decltype(DOF)::value, 0, decltype(BND)::value, 8>), grid, dim3(512),
                  sizeof(float) * NormalEq<decltype(DOF)::value>::NV * 16, st, d, pose, clip_jac, jtj, jtr, cost);

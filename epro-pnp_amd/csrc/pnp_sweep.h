@@ -77,6 +77,32 @@ __device__ __forceinline__ Point load_point(const Problem& p, int b, int n) {
   return q;
 }
 
+// The same point, loaded UNCONDITIONALLY (index clamped to N - 1, the weights of a lane beyond N zeroed afterwards: zero cost,
+// zero Jacobian), non-temporal.  For sweeps that issue all of a lane's loads up front and then work through the points in
+// order: with the loads under per-point `n < N` branches the compiler cannot know how many of the later loads were issued,
+// so the s_waitcnt in front of the FIRST point's arithmetic waits for all of them; unconditional loads get exact counts and
+// point k's arithmetic runs underneath the loads of points k+1.. (together with sched_fence, wave_ops.h).  Requires N >= 1.
+__device__ __forceinline__ Point load_point_streamed(const Problem& p, int b, int n) {
+  Point q;
+  const int nc = min(n, p.N - 1);
+  const size_t i = (size_t)b * (size_t)p.N + (size_t)nc;
+  const float* a = p.x3d + i * 3;
+#ifndef EPROPNP_EMU
+  q.X = __builtin_nontemporal_load(a); q.Y = __builtin_nontemporal_load(a + 1); q.Z = __builtin_nontemporal_load(a + 2);
+  const pnp_f32x2 u = __builtin_nontemporal_load(reinterpret_cast<const pnp_f32x2*>(p.x2d + i * 2));
+  const pnp_f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const pnp_f32x2*>(p.w2d + i * 2));
+  q.u = u[0]; q.v = u[1]; q.wu = w[0]; q.wv = w[1];
+#else
+  q.X = a[0]; q.Y = a[1]; q.Z = a[2];
+  q.u = p.x2d[i * 2]; q.v = p.x2d[i * 2 + 1]; q.wu = p.w2d[i * 2]; q.wv = p.w2d[i * 2 + 1];
+#endif
+  return q;
+}
+// ... and the masking of a lane beyond N, applied where the point is consumed (not at the load: that would wait for it)
+__device__ __forceinline__ void mask_point_beyond(Point& q, int n, int N) {
+  if (n >= N) q.wu = q.wv = 0.f;
+}
+
 template <bool BOUNDS>
 __device__ __forceinline__ void load_camera(const Problem& p, int b, float (&K)[9], Bounds& bd, float& delta) {
 #pragma unroll

@@ -19,6 +19,15 @@ namespace pnp {
 constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// The instruction scheduler may not move anything across this point.  Between the per-point bodies of a sweep over
+// register-resident points it keeps point k's arithmetic ahead of point k+1's, so that the s_waitcnt in front of it waits for
+// point k's loads only and the arithmetic runs underneath the loads still in flight (otherwise the scheduler interleaves the
+// independent per-point chains and every wave waits for ALL of its loads before its first FMA).
+__device__ __forceinline__ void sched_fence() {
+#ifndef EPROPNP_EMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 // wave index as a wave-uniform (scalar-register) value: lets the compiler keep everything derived from it in SGPRs
 __device__ __forceinline__ int wave_id() {
 #ifndef EPROPNP_EMU

@@ -78,7 +78,8 @@ def test_shift_poses_is_differentiable_in_the_pose(backend, dof):
     torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('dof,bounds,B,N', [(6, None, 11, 300), (4, 'tight', 7, 64), (6, 'tight', 9, 512)])
+@pytest.mark.parametrize('dof,bounds,B,N', [(6, None, 11, 300), (4, 'tight', 7, 64), (6, 'tight', 9, 512), (6, None, 5, 2),
+                                            (4, None, 3, 3), (6, 'tight', 4, 449)])
 def test_normal_equations_launch_shapes_agree(backend, monkeypatch, dof, bounds, B, N):
     """normal_equations_kernel launch shapes (one wave per object = what bench.py's single-sweep roofline runs at C2,
     two waves, eight waves with the DPP reduction) against the oracle's J^T J / J^T r / cost."""
@@ -109,3 +110,20 @@ def test_normal_equations_launch_shapes_agree(backend, monkeypatch, dof, bounds,
         assert ((a - jtj).abs() / scale).max() < 2e-5, shape
         assert ((b - jtr).abs() / jtr.abs().amax(-1, keepdim=True).clamp(min=1e-3)).max() < 1e-4, shape
         torch.testing.assert_close(c, cost, rtol=1e-5, atol=1e-6)
+
+
+def test_normal_equations_without_points(backend):
+    """num_pts = 0: the sweep has nothing to load (the register-resident variants load unconditionally with the index clamped
+    to N - 1, so this shape takes the streaming kernel) and writes zeros."""
+    from epropnp import functional as F
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.cost_fun import HuberPnPCost
+    B = 5
+    z = lambda *s: torch.zeros(*s, device=backend)
+    cam = PerspectiveCamera(cam_mats=torch.eye(3, device=backend).expand(B, 3, 3).contiguous())
+    cf = HuberPnPCost(delta=1.0)
+    hp = F.PnPProblem(z(B, 0, 3), z(B, 0, 2), z(B, 0, 2), cam, cf, 6)
+    pose = torch.tensor([0., 0., 5., 1., 0., 0., 0.], device=backend).expand(B, 7).contiguous()
+    jtj, jtr, cost = F.normal_equations(hp, pose)
+    assert jtj.shape == (B, 6, 6) and jtr.shape == (B, 6) and cost.shape == (B,)
+    assert float(jtj.abs().max()) == 0.0 and float(jtr.abs().max()) == 0.0 and float(cost.abs().max()) == 0.0
