@@ -282,6 +282,13 @@ def main():
     exchange = sharding.ObjectExchange(total, force_collective=dist is not None) if strong else None
     nf_scale = 1.0 / max(2 * B, 1)
 
+    def norm_factor_input():
+        # the Det head's norm_factor input (mean weight scale).  Summed per object first: a (600 x 256) -> () torch.sum is a
+        # multi-block reduction whose semaphores are reset by a hipMemsetAsync, and a captured memset NODE of this ROCm stack
+        # writes garbage once eager launches have run between two replays (tools/ubench/graph_memset_node.py; the r03 C4
+        # line's loss of 17.7 against 1.79 eager was this).  Row sums + one single-block sum need no memset.
+        return w2d.detach().sum(dim=(1, 2)).sum() * nf_scale
+
     def step(timed=False):
         for t in (x3d, x2d, w2d):
             t.grad = None
@@ -298,7 +305,7 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        exchange.start(pose_opt, w2d.detach().sum() * nf_scale)
+        exchange.start(pose_opt, norm_factor_input())
         layer_last_pose['pose_opt'] = pose_opt.detach()
         if timed:
             e1.record()                 # GPU time of the pack kernel + the RCCL kernel in stream order
@@ -379,6 +386,11 @@ def main():
     _hip.profile(enable=False)
     loss = held['loss']
     loss_val = float(loss.detach())
+    replay_check = None
+    if strong:      # what the LAST timed step fed the loss, against the same expression evaluated now, eagerly
+        got, want = float(exchange.world_mean()), float(norm_factor_input())
+        replay_check = {'norm_factor_input_last_step': got, 'evaluated_eagerly': want, 'norm_factor': float(loss_mod.norm_factor)}
+        assert abs(got - want) <= 1e-5 * abs(want), ('the replayed step computed another norm_factor input', replay_check)
     my_ms = elapsed / args.steps * 1e3
     ranks = {'launcher': 'torch.distributed.run' if 'RANK' in os.environ else 'single process', 'process_group': None}
     if dist is not None:
@@ -507,12 +519,20 @@ def main():
                                  'ms_per_step_without_exchange': round(ms_without, 4),
                                  'share_of_step': round(max(0.0, ms - ms_without) / ms, 4),
                                  'bytes_per_rank': int(gathered['pose_opt'].numel() * 4 + 4),
-                                 'gathered_equals_local_bitwise': True}
+                                 'gathered_equals_local_bitwise': True,
+                                 'replayed_step_check': replay_check}
         if world == 1 and not args.no_cpu_baseline and dof == 6:
             out['cpu_baseline'] = cpu_baseline(N, S, K, L, args.cpu_sample if args.config == 'C2' else 8)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
         if world == 1 and not args.no_hipgraph and args.config == 'C2' and default_shape:
             out['hipgraph_replay'] = hipgraph_replay()      # informational: the same step replayed from a hipGraph
+        # RCCL writes its version banner through C stdio: into a pipe that is block-buffered and would land BEHIND this line at
+        # exit -- push it out first, so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -550,7 +550,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       }
       owned = mem;
     }
-    if (hipMemsetAsync(mem, 0xff, xbytes, st) != hipSuccess) {
+    if (launch_fill_u32(mem, 0xffffffffu, xbytes / 4, st) != EPROPNP_OK) {      // (a kernel, not a memset node: pnp_host.h)
       (void)hipGetLastError();
       return fail(EPROPNP_ELAUNCH, "amis_forward: could not fill the split scratch");
     }

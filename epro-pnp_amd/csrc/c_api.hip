@@ -217,6 +217,21 @@ int epropnp_mc_loss_backward(const float* logweights, const float* lse, const fl
                                       grad_cost_target, (hipStream_t)stream);
 }
 
+int epropnp_mc_loss_reduce(const float* loss, const float* weight, int32_t num_obj, float scale, float momentum,
+                           const float* norm_factor_in, float* norm_factor, float* out, void* stream) {
+  pnp::StageScope prof_("mc_loss_reduce", (hipStream_t)stream);
+  return pnp::launch_mc_loss_reduce(loss, weight, num_obj, scale, momentum, norm_factor_in, norm_factor, out,
+                                    (hipStream_t)stream);
+}
+
+int epropnp_mc_loss_reduce_backward(const float* logweights, const float* lse, const float* weight, const float* coef,
+                                    const float* grad_out, int32_t mc_samples, int32_t num_obj, float* grad_logweights,
+                                    float* grad_cost_target, void* stream) {
+  pnp::StageScope prof_("mc_loss_backward", (hipStream_t)stream);
+  return pnp::launch_mc_loss_reduce_backward(logweights, lse, weight, coef, grad_out, mc_samples, num_obj, grad_logweights,
+                                             grad_cost_target, (hipStream_t)stream);
+}
+
 int epropnp_rslm_draw(const float* w2d, int32_t num_obj, int32_t num_pts, int32_t num_proposals, int32_t n_pts,
                       uint64_t seed, uint64_t offset, int64_t* inds, void* stream) {
   return pnp::launch_rslm_draw(w2d, num_obj, num_pts, num_proposals, n_pts, seed, offset, (long long*)inds,

@@ -316,15 +316,55 @@ __global__ __launch_bounds__(512) void mc_loss_forward_kernel(const float* __res
   }
 }
 
+// g == nullptr: the reduced loss (mc_loss_reduce_kernel) -- every object's upstream gradient is the scalar
+// grad_out[0] * coef[0] (* weight[b]), read from device memory so that the node stays capturable.
 __global__ __launch_bounds__(256) void mc_loss_backward_kernel(const float* __restrict__ logw, const float* __restrict__ lse,
-                                                                const float* __restrict__ g, int S, int B,
-                                                                float* __restrict__ glogw, float* __restrict__ gct) {
+                                                                const float* __restrict__ g, const float* __restrict__ gout,
+                                                                const float* __restrict__ coef, const float* __restrict__ weight,
+                                                                int S, int B, float* __restrict__ glogw,
+                                                                float* __restrict__ gct) {
   const size_t total = (size_t)S * B;
+  const float gs = (g == nullptr) ? gout[0] * coef[0] : 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i % (size_t)B);
     const float l = lse[b];
-    glogw[i] = (l != l) ? 0.f : g[b] * expf(logw[i] - l);
-    if (gct != nullptr && i < (size_t)B) gct[b] = (l != l) ? 0.f : g[b];      // the first B threads cover b = 0..B-1
+    const float gb = (g != nullptr) ? g[b] : (weight != nullptr ? gs * weight[b] : gs);
+    glogw[i] = (l != l) ? 0.f : gb * expf(logw[i] - l);
+    if (gct != nullptr && i < (size_t)B) gct[b] = (l != l) ? 0.f : gb;      // the first B threads cover b = 0..B-1
+  }
+}
+
+// The scalar both reference loss modules return, from the per-object losses, in ONE single-workgroup launch instead of the
+// ~10 elementwise / reduce launches of its PyTorch statement (EPro-PnP-Det epropnp_det/models/losses/monte_carlo_pose_loss.py:
+// 41-66 with mmdet's weight_reduce_loss; EPro-PnP-6DoF lib/models/monte_carlo_pose_loss.py:20-35):
+//     norm_factor <- (1 - momentum) norm_factor + momentum * norm_factor_in          (training: nf_in != nullptr)
+//     out[0] = (sum_b weight[b] loss[b]) * scale / norm_factor,   out[1] = scale / norm_factor   (kept for the backward)
+// scale = loss_weight / B (mean) | loss_weight (sum) | loss_weight / avg_factor.  The sum runs in a fixed order (thread t takes
+// b = t, t + T, ...; then the block tree): bit-reproducible.  The running estimate is written with separately rounded
+// products, as the reference's mul_ / add_ pair does.
+__global__ __launch_bounds__(1024) void mc_loss_reduce_kernel(const float* __restrict__ loss, const float* __restrict__ weight,
+                                                               int B, float scale, float one_minus_m, float m,
+                                                               const float* __restrict__ nf_in, float* __restrict__ nf,
+                                                               float* __restrict__ out) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int b = (int)threadIdx.x; b < B; b += (int)blockDim.x) acc += (weight != nullptr) ? loss[b] * weight[b] : loss[b];
+  float v[1] = {acc};
+  block_sum<1>(v, red);
+  if (threadIdx.x == 0) {
+    float n = (nf != nullptr) ? nf[0] : 1.0f;
+    if (nf != nullptr && nf_in != nullptr) {
+#ifndef EPROPNP_EMU
+      n = __fadd_rn(__fmul_rn(n, one_minus_m), __fmul_rn(m, nf_in[0]));
+#else
+      const volatile float a = n * one_minus_m, c2 = m * nf_in[0];
+      n = a + c2;
+#endif
+      nf[0] = n;
+    }
+    const float c = scale / n;
+    out[0] = v[0] * c;
+    out[1] = c;
   }
 }
 
@@ -780,8 +820,8 @@ int launch_prepare_dense_backward(const float* noc_map, const float* dim, const 
   const PrepLayout L = {inds, H * W, W};
   const size_t plane = (size_t)H * W * sizeof(float);
 #ifndef EPROPNP_EMU
-  if (hipMemsetAsync(glogit_map, 0, (size_t)B * 2 * plane, st) != hipSuccess) return fail(EPROPNP_ELAUNCH, "prepare_dense_backward: memset");
-  if (gx3d != nullptr && hipMemsetAsync(gnoc_map, 0, (size_t)B * 3 * plane, st) != hipSuccess)
+  if (launch_fill_u32(glogit_map, 0u, (size_t)B * 2 * plane / 4, st) != EPROPNP_OK) return fail(EPROPNP_ELAUNCH, "prepare_dense_backward: memset");
+  if (gx3d != nullptr && launch_fill_u32(gnoc_map, 0u, (size_t)B * 3 * plane / 4, st) != EPROPNP_OK)
     return fail(EPROPNP_ELAUNCH, "prepare_dense_backward: memset");
 #else
   memset(glogit_map, 0, (size_t)B * 2 * plane);
@@ -812,6 +852,22 @@ int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, floa
   return check_launch("adaptive_delta_kernel");
 }
 
+// Fill `words` 32-bit words at p with v, as a KERNEL.  Every stream-ordered reset inside this library goes through it instead
+// of hipMemsetAsync: captured into a hipGraph, a memset node of this ROCm stack (7.0 user space) writes garbage once eager
+// launches have run between two replays (tools/ubench/graph_memset_node.py) -- a kernel node replays correctly.
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* __restrict__ p, unsigned v, size_t words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+int launch_fill_u32(void* p, unsigned v, size_t words, hipStream_t st) {
+  if (words == 0) return EPROPNP_OK;
+  if (p == nullptr || ((size_t)p & 3u) != 0) return fail(EPROPNP_EINVAL, "fill: NULL or unaligned buffer");
+  size_t blocks = (words + 1023) / 1024;        // four words per thread
+  if (blocks > 2048) blocks = 2048;
+  PNP_LAUNCH(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)p, v, words);
+  return check_launch("fill_u32_kernel");
+}
+
 int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, float* loss, float* lse, hipStream_t st) {
   if (B <= 0) return EPROPNP_OK;
   if (!logw || !loss || !lse || S < 1) return fail(EPROPNP_EINVAL, "mc_loss_forward: bad argument");
@@ -828,9 +884,33 @@ int launch_mc_loss_backward(const float* logw, const float* lse, const float* lo
     const size_t total = (size_t)S * B;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    PNP_LAUNCH(mc_loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logw, lse, g, S, B, glogw, gct);
+    PNP_LAUNCH(mc_loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logw, lse, g, (const float*)nullptr,
+               (const float*)nullptr, (const float*)nullptr, S, B, glogw, gct);
   }
   return check_launch("mc_loss_backward_kernel");
+}
+
+int launch_mc_loss_reduce(const float* loss, const float* weight, int B, float scale, float momentum, const float* nf_in,
+                          float* nf, float* out, hipStream_t st) {
+  if (B < 0) return fail(EPROPNP_EINVAL, "mc_loss_reduce: negative num_obj");
+  if (!out || (B > 0 && !loss)) return fail(EPROPNP_EINVAL, "mc_loss_reduce: NULL pointer");
+  if (nf_in != nullptr && nf == nullptr) return fail(EPROPNP_EINVAL, "mc_loss_reduce: norm_factor_in without norm_factor");
+  const float one_minus_m = (float)(1.0 - (double)momentum);       // the reference's `1 - self.momentum`, rounded once
+  PNP_LAUNCH(mc_loss_reduce_kernel, dim3(1), dim3(B > 4096 ? 1024 : 256), 0, st, loss, weight, B, scale, one_minus_m, momentum,
+             nf_in, nf, out);
+  return check_launch("mc_loss_reduce_kernel");
+}
+
+int launch_mc_loss_reduce_backward(const float* logw, const float* lse, const float* weight, const float* coef,
+                                   const float* gout, int S, int B, float* glogw, float* gct, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!logw || !lse || !coef || !gout || !glogw) return fail(EPROPNP_EINVAL, "mc_loss_reduce_backward: NULL pointer");
+  const size_t total = (size_t)S * B;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  PNP_LAUNCH(mc_loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logw, lse, (const float*)nullptr, gout, coef,
+             weight, S, B, glogw, gct);
+  return check_launch("mc_loss_backward_kernel (reduced loss)");
 }
 
 // ----------------------------------------------------------------------------------------------------------

@@ -165,6 +165,12 @@ int launch_rslm_draw(const float* w2d, int B, int N, int P, int n_pts, unsigned 
 int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, float rel, float* delta, float* stats,
                           hipStream_t st);
 int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, float* loss, float* lse, hipStream_t st);
+// stream-ordered fill as a kernel (never hipMemsetAsync: eval_kernels.hip, fill_u32_kernel)
+int launch_fill_u32(void* p, unsigned v, size_t words, hipStream_t st);
+int launch_mc_loss_reduce(const float* loss, const float* weight, int B, float scale, float momentum, const float* nf_in,
+                          float* nf, float* out, hipStream_t st);
+int launch_mc_loss_reduce_backward(const float* logw, const float* lse, const float* weight, const float* coef,
+                                   const float* gout, int S, int B, float* glogw, float* gct, hipStream_t st);
 int launch_mc_loss_backward(const float* logw, const float* lse, const float* loss, const float* g, int S, int B,
                             float* glogw, float* gct, hipStream_t st);
 int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,

@@ -102,6 +102,46 @@ struct McPoseLoss : public torch::autograd::Function<McPoseLoss> {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
+// the REDUCED Monte-Carlo pose loss of the two reference loss modules (include/epropnp_hip.h: epropnp_mc_loss_reduce):
+// (sum_b weight_b loss_b) * scale / norm_factor as a 0-dim tensor; norm_factor's running estimate is updated in place
+struct McPoseLossReduced : public torch::autograd::Function<McPoseLossReduced> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& logw, const OptTensor& cost_target, const OptTensor& weight,
+                        double scale, double momentum, const OptTensor& nf_in, const OptTensor& norm_factor, int64_t stream) {
+    const Tensor lw = logw.detach().contiguous();
+    const int64_t S = lw.size(0), B = lw.size(1);
+    Tensor ct, w;
+    if (cost_target.has_value() && cost_target->defined()) ct = cost_target->detach().contiguous();
+    if (weight.has_value() && weight->defined()) w = weight->detach().contiguous();
+    Tensor loss = torch::empty({B}, lw.options()), lse = torch::empty({B}, lw.options()), out = torch::empty({2}, lw.options());
+    check(epropnp_mc_loss_forward(fptr(lw), fptr(ct), (int32_t)S, (int32_t)B, fptr(loss), fptr(lse), (void*)stream),
+          "epropnp_mc_loss_forward");
+    check(epropnp_mc_loss_reduce(fptr(loss), fptr(w), (int32_t)B, (float)scale, (float)momentum, fptr(nf_in),
+                                 fptr(norm_factor), fptr(out), (void*)stream), "epropnp_mc_loss_reduce");
+    ctx->save_for_backward({lw, lse, out, w});
+    ctx->saved_data["stream"] = stream;
+    ctx->saved_data["has_cost_target"] = ct.defined();
+    ctx->set_materialize_grads(false);
+    return out.select(0, 0);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    if (!grads[0].defined()) return variable_list(8);
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &lw = saved[0], &lse = saved[1], &out = saved[2], &w = saved[3];
+    const Tensor g = grads[0].to(torch::kFloat32).reshape({1}).contiguous();
+    const int64_t S = lw.size(0), B = lw.size(1);
+    Tensor glw = torch::empty_like(lw), gct;
+    if (ctx->saved_data["has_cost_target"].toBool() && ctx->needs_input_grad(1)) gct = torch::empty({B}, lw.options());
+    check(epropnp_mc_loss_reduce_backward(fptr(lw), fptr(lse), fptr(w), fptr(out) + 1, fptr(g), (int32_t)S, (int32_t)B,
+                                          fptr(glw), fptr(gct), (void*)ctx->saved_data["stream"].toInt()),
+          "epropnp_mc_loss_reduce_backward");
+    variable_list r(8);
+    r[0] = glw;
+    r[1] = gct;
+    return r;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
 // monte_carlo_forward: (x3d, x2d, w2d, delta) -> pose_opt_n, samples_n, logweights [diff], cost, cost_init [diff],
 //                                               pose_opt, samples, x3d_centered, offset
 struct ProblemTensors {      // contiguous fp32 device tensors behind an epropnp_problem
@@ -365,6 +405,11 @@ Tensor mc_pose_loss(const Tensor& logw, const OptTensor& cost_target, int64_t st
   return McPoseLoss::apply(logw, cost_target, stream);
 }
 
+Tensor mc_pose_loss_reduced(const Tensor& logw, const OptTensor& cost_target, const OptTensor& weight, double scale,
+                            double momentum, const OptTensor& nf_in, const OptTensor& norm_factor, int64_t stream) {
+  return McPoseLossReduced::apply(logw, cost_target, weight, scale, momentum, nf_in, norm_factor, stream);
+}
+
 std::vector<OptTensor> fused_monte_carlo(const Tensor& x3d, const Tensor& x2d, const Tensor& w2d, const OptTensor& delta,
                                          const Tensor& x3d_c, const Tensor& x2d_c, const Tensor& w2d_c, const Tensor& cam_c,
                                          const OptTensor& lb_c, const OptTensor& ub_c, const Tensor& delta_c,
@@ -387,6 +432,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("mc_params_size", []() { return (int64_t)sizeof(epropnp_mc_params); });
   m.def("adaptive_delta", &adaptive_delta);
   m.def("mc_pose_loss", &mc_pose_loss);
+  m.def("mc_pose_loss_reduced", &mc_pose_loss_reduced);
   m.def("fused_monte_carlo", &fused_monte_carlo);
   m.def("gn_step", &gn_step);
   m.def("shift_poses", &shift_poses);

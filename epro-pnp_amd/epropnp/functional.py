@@ -619,6 +619,59 @@ def mc_pose_loss(logweights, cost_target):
     return _McPoseLoss.apply(logweights, cost_target)
 
 
+class _McPoseLossReduced(torch.autograd.Function):
+    """The reduced Monte-Carlo pose loss (mc_pose_loss_reduced) as three kernels: per-object forward, reduce, backward."""
+
+    @staticmethod
+    def forward(ctx, logw, cost_target, weight, scale, momentum, nf_in, norm_factor):
+        lw = _f32c(logw, 'pose_sample_logweights')
+        S, B = lw.shape
+        ct = None if cost_target is None else _f32c(cost_target, 'cost_target')
+        loss = torch.empty(B, dtype=torch.float32, device=lw.device)
+        lse = torch.empty_like(loss)
+        out = torch.empty(2, dtype=torch.float32, device=lw.device)
+        st = _hip.stream_of(lw)
+        _hip.call('epropnp_mc_loss_forward', _hip.ptr(lw), _hip.ptr(ct), S, B, _hip.ptr(loss), _hip.ptr(lse), st)
+        _hip.call('epropnp_mc_loss_reduce', _hip.ptr(loss), _hip.ptr(weight), B, float(scale), float(momentum),
+                  _hip.ptr(nf_in), _hip.ptr(norm_factor), _hip.ptr(out), st)
+        ctx.save_for_backward(lw, lse, out)
+        ctx.weight = weight
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 7
+        lw, lse, out = ctx.saved_tensors
+        S, B = lw.shape
+        g = g.to(torch.float32).reshape(1).contiguous()
+        glw = torch.empty_like(lw)
+        gct = torch.empty(B, dtype=torch.float32, device=lw.device) if ctx.needs_input_grad[1] else None
+        _hip.call('epropnp_mc_loss_reduce_backward', _hip.ptr(lw), _hip.ptr(lse), _hip.ptr(ctx.weight), _hip.ptr(out[1:]),
+                  _hip.ptr(g), S, B, _hip.ptr(glw), _hip.ptr(gct), _hip.stream_of(lw))
+        return glw, gct, None, None, None, None, None
+
+
+def mc_pose_loss_reduced(logweights, cost_target, weight=None, scale=1.0, momentum=0.0, norm_factor_in=None, norm_factor=None):
+    """-> the 0-dim loss  (sum_b weight[b] (cost_target[b] + logsumexp_S logweights[:, b])) * scale / norm_factor  of both
+    reference loss modules (losses.MonteCarloPoseLoss), NaN objects zeroed.  `norm_factor` (1,)/0-dim device buffer, updated IN
+    PLACE to (1 - momentum) norm_factor + momentum * norm_factor_in first when `norm_factor_in` (device scalar) is given.
+    weight (B,) without grad, or None."""
+    _f32c(logweights, 'pose_sample_logweights')
+    if cost_target is not None:
+        _f32c(cost_target, 'cost_target')
+    w = None if weight is None else _f32c(weight, 'weight')
+    nf_in = None if norm_factor_in is None else _f32c(norm_factor_in, 'norm_factor_in')
+    if norm_factor is not None and (norm_factor.dtype != torch.float32 or not norm_factor.is_contiguous()
+                                    or norm_factor.device != logweights.device):
+        raise ValueError('norm_factor must be a contiguous float32 scalar on the device of the log-weights')
+    ext = _hip.torch_ext()
+    if ext is not None:
+        return ext.mc_pose_loss_reduced(logweights, cost_target, w, float(scale), float(momentum), nf_in, norm_factor,
+                                        int(_hip.stream_of(logweights) or 0))
+    return _McPoseLossReduced.apply(logweights, cost_target, w, scale, momentum, nf_in, norm_factor)
+
+
 def rslm_draw(w2d, num_proposals, num_points, seed, offset):
     """(B,N,2) weights -> (P,B,n) int64 indices, weighted sampling without replacement per (proposal, object)."""
     w = _f32c(w2d, 'w2d')

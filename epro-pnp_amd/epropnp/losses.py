@@ -41,15 +41,26 @@ class MonteCarloPoseLoss(nn.Module):
 
     def forward(self, pose_sample_logweights, cost_target, norm_factor, weight=None, avg_factor=None,
                 reduction_override=None):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        nf = None
         if self.training:
             with torch.no_grad():
                 if hasattr(norm_factor, 'world_mean'):      # sharding.ObjectExchange: the scalar rode in the step's ONE
                     nf = norm_factor.world_mean().to(self.norm_factor.device)       # collective (no all-reduce here)
                 else:
                     nf = _world_mean(torch.as_tensor(norm_factor, dtype=torch.float, device=self.norm_factor.device))
+        scale = self._fused_scale(pose_sample_logweights, cost_target, weight, avg_factor, reduction)
+        if scale is not None:
+            # the reduced loss as THREE launches (per-object loss, reduce + running estimate + scaling, backward) instead of the
+            # ~15 elementwise / reduce launches of the statement below -- a quarter of the Det step when it is replayed from a
+            # hipGraph (profiles/r03_det_loss_fused.txt); same value to rounding
+            from .functional import mc_pose_loss_reduced
+            return mc_pose_loss_reduced(pose_sample_logweights, cost_target, weight, scale, self.momentum,
+                                        None if nf is None else nf.reshape(1), self.norm_factor)
+        if nf is not None:
+            with torch.no_grad():
                 self.norm_factor.mul_(1 - self.momentum).add_(self.momentum * nf)
-        assert reduction_override in (None, 'none', 'mean', 'sum')
-        reduction = reduction_override if reduction_override else self.reduction
         loss = monte_carlo_pose_loss(pose_sample_logweights, cost_target)
         if weight is not None:
             loss = loss * weight
@@ -60,3 +71,27 @@ class MonteCarloPoseLoss(nn.Module):
             if reduction == 'mean':
                 loss = loss.sum() / avg_factor
         return loss * (self.loss_weight / self.norm_factor)
+
+    def _fused_scale(self, logw, cost_target, weight, avg_factor, reduction):
+        """loss_weight / (what the sum over objects is divided by) when the fused kernels can produce the reduced loss, else
+        None: fp32 (S,B) log-weights on the HIP path, a scalar reduction, a plain (B,) weight that needs no gradient, a plain
+        number as avg_factor."""
+        import os
+        from . import _hip
+        if os.environ.get('EPROPNP_LOSS_FUSED', '1') == '0':        # measurements: the composite statement
+            return None
+        if reduction not in ('mean', 'sum') or logw.dim() != 2 or logw.numel() == 0:
+            return None
+        tensors = [logw, self.norm_factor] + [t for t in (cost_target, weight) if t is not None]
+        if not all(torch.is_tensor(t) for t in tensors) or not _hip.on_hip_path(*tensors):
+            return None
+        B = logw.shape[1]
+        if cost_target is not None and cost_target.shape != (B,):
+            return None
+        if weight is not None and (weight.shape != (B,) or weight.requires_grad):
+            return None
+        if avg_factor is None:
+            return self.loss_weight / B if reduction == 'mean' else float(self.loss_weight)
+        if reduction != 'mean' or torch.is_tensor(avg_factor):
+            return None
+        return self.loss_weight / float(avg_factor)

@@ -28,7 +28,7 @@ extern "C" {
 #define EPROPNP_ELAUNCH (-2)  /* HIP launch/runtime error                                         */
 #define EPROPNP_ENODEV (-3)   /* no HIP device / not a gfx950 code object                         */
 
-#define EPROPNP_ABI_VERSION 4
+#define EPROPNP_ABI_VERSION 5
 
 /* Correspondences + camera + robust-cost parameters of one batch of objects.
  * Mirrors the state of PerspectiveCamera (epropnp/camera.py:35-62) and HuberPnPCost.delta
@@ -251,6 +251,21 @@ int epropnp_mc_loss_forward(const float* logweights, const float* cost_target, i
 int epropnp_mc_loss_backward(const float* logweights, const float* lse, const float* loss, const float* grad_loss,
                              int32_t mc_samples, int32_t num_obj, float* grad_logweights, float* grad_cost_target,
                              void* stream);
+/* The SCALAR both reference loss modules return, from the per-object losses of epropnp_mc_loss_forward, in one
+ * single-workgroup launch (EPro-PnP-Det epropnp_det/models/losses/monte_carlo_pose_loss.py:41-66 incl. mmdet's
+ * weight_reduce_loss; EPro-PnP-6DoF lib/models/monte_carlo_pose_loss.py:20-35):
+ *   norm_factor[0] <- (1 - momentum) * norm_factor[0] + momentum * norm_factor_in[0]     if norm_factor_in != NULL (training)
+ *   out[0] = (sum_b weight[b] * loss[b]) * scale / norm_factor[0],    out[1] = scale / norm_factor[0]  (for the backward)
+ * scale = loss_weight / num_obj ('mean'), loss_weight ('sum') or loss_weight / avg_factor.  weight (B,) or NULL (ones),
+ * norm_factor (1,) device scalar or NULL (1.0), out (2,).  Fixed summation order: bit-reproducible. */
+int epropnp_mc_loss_reduce(const float* loss, const float* weight, int32_t num_obj, float scale, float momentum,
+                           const float* norm_factor_in, float* norm_factor, float* out, void* stream);
+/* Its backward through epropnp_mc_loss_forward: with g_b = grad_out[0] * coef[0] * weight[b] (coef = out + 1 of the forward),
+ *   grad_logweights[j,b] = g_b * exp(logweights[j,b] - lse[b]),  grad_cost_target[b] = g_b (or NULL)   (0 where the loss was NaN).
+ * grad_out and coef are device scalars: nothing is read back, the node is capturable. */
+int epropnp_mc_loss_reduce_backward(const float* logweights, const float* lse, const float* weight, const float* coef,
+                                    const float* grad_out, int32_t mc_samples, int32_t num_obj, float* grad_logweights,
+                                    float* grad_cost_target, void* stream);
 
 /* LMSolver.gn_step (epropnp/levenberg_marquardt.py:243-253), the differentiable Gauss-Newton step behind
  * `pose_opt_plus`:  step = -(J^T J + eps I)^-1 J^T r  at `pose` (clip_jac on).   pose (B,pose_len) -> step (B,dof). */

@@ -380,6 +380,48 @@ def test_forward_split_over_workgroups(monkeypatch, dof, bounds, B, N, S, K):
     assert all(torch.equal(o[1], w2) for o in both)
 
 
+@pytest.mark.gpu
+def test_split_kernels_in_a_hipgraph_survive_eager_work_between_replays():
+    """The workgroup-split forward and LM solve reset their exchange slots on the stream before every launch.  Captured into a
+    hipGraph that reset must be a KERNEL node: on this ROCm stack a captured hipMemsetAsync node writes garbage once eager
+    launches have run between two replays (tools/ubench/graph_memset_node.py reproduces it with PyTorch alone) -- stale
+    slots would pass for arrived data.  Replays before and after eager work + host syncs equal the eager result bit for bit."""
+    import install as emu
+    emu.uninstall()
+    from epropnp import functional as F
+    dev = torch.device('cuda:0')
+    for dof, B, N, S, K in ((6, 32, 512, 256, 4), (6, 32, 4096, 64, 2)):
+        prob = orc.make_problem(B, N, dof, seed=23)
+        noise = pack_noise(orc.make_noise(B, S, K, dof, seed=24), dof).to(dev)
+        p, cam, cf = make_layer_objects(prob, dev)
+
+        def body():
+            hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)        # (binds the current stream)
+            pose_opt, pose_cov, cost = F.lm_solve(hp, p['pose_init'], 4, with_pose_cov=True, with_cost=True)
+            smp, logw = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+            return pose_opt, cost, smp, logw
+        ref = [t.clone() for t in body()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = body()
+        for rnd in range(3):
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            F.flush_status()
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b), (N, rnd)
+            junk = torch.rand(1 << 20, device=dev)                # eager launches, a reduction with a memset, host syncs
+            assert 0.0 < float(junk.sum()) < float(junk.numel())
+            torch.cuda.synchronize()
+
+
 def test_von_mises_draws_match_oracle_over_kappa_range(backend):
     """The device's bounded Best-Fisher sampler (fp32, cancellation-free form, fp64 only for borderline decisions) makes
     the same accept/reject decisions and returns the same angles as the oracle's fp64 procedure, from nearly uniform

@@ -242,6 +242,69 @@ def test_loss_modules_match_reference_fixture():
         md(logw, ct, g['nf0'], reduction_override='max')
 
 
+def test_loss_modules_fused_path_matches_reference_fixture(backend, monkeypatch):
+    """The same fixture of the UNMODIFIED reference loss modules through the fused kernels (epropnp_mc_loss_forward +
+    epropnp_mc_loss_reduce: per-object loss, then weight / reduction / avg_factor / loss_weight / norm_factor and the running
+    estimate in one launch): every scalar reduction, the EMA over two training calls, the NaN object; 'none' stays on the
+    composite statement.  Gradients w.r.t. the log-weights and cost_target against the composite statement's autograd."""
+    from epropnp import functional as F
+    from epropnp.losses import MonteCarloPoseLoss
+    g = load_golden('losses')
+    dev = backend
+    logw, ct, weight, out = g['logw'].to(dev), g['cost_target'].to(dev), g['weight'].to(dev), g['out']
+    calls = []
+    real = F.mc_pose_loss_reduced
+    monkeypatch.setattr(F, 'mc_pose_loss_reduced', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    close = lambda a, b: torch.testing.assert_close(torch.as_tensor(a).cpu(), torch.as_tensor(b, dtype=torch.float32), rtol=2e-6, atol=1e-6)
+    m6 = MonteCarloPoseLoss(init_norm_factor=2.0, momentum=0.1).to(dev)
+    close(m6(logw.clone(), ct, g['nf0']), out['six.call0'])
+    close(m6(logw.clone(), ct, g['nf1']), out['six.call1'])
+    close(m6.norm_factor, out['six.norm_factor'])
+    m6.eval()
+    close(m6(logw.clone(), ct, g['nf0']), out['six.eval'])
+    close(m6.norm_factor, out['six.norm_factor'])                      # eval: the running estimate stays
+    md = MonteCarloPoseLoss(loss_weight=0.5, init_norm_factor=2.0, momentum=0.1).to(dev)
+    close(md(logw.clone(), ct, g['nf0']), out['det.call0'])
+    close(md(logw.clone(), ct, g['nf1'], weight=weight, avg_factor=3.5), out['det.call1'])
+    close(md.norm_factor, out['det.norm_factor'])
+    assert len(calls) == 5
+    md.eval()
+    for red in ('mean', 'sum'):
+        for wname, w in (('w0', None), ('w1', weight)):
+            for aname, af in (('a0', None), ('a1', 3.5)):
+                if af is not None and red == 'sum':
+                    continue
+                v = md(logw.clone(), ct, g['nf0'], weight=w, avg_factor=af, reduction_override=red)
+                assert v.dim() == 0
+                close(v, out[f'det.{red}.{wname}.{aname}'])
+    assert len(calls) == 5 + 6
+    close(md(logw.clone(), ct, g['nf0'], weight=weight, reduction_override='none'), out['det.none.w1.a0'])
+    assert len(calls) == 11                                             # per-object losses: the composite statement
+    # gradients: fused node vs autograd of the composite statement (a weight that requires grad keeps the fused path out)
+    for w, af in ((None, None), (weight, 3.5), (weight, None)):
+        grads = []
+        for fused in (True, False):
+            a, b = logw.clone().requires_grad_(True), ct.clone().requires_grad_(True)
+            ww = w if (fused or w is None) else w.clone().requires_grad_(True)
+            n0 = len(calls)
+            v = md(a, b, g['nf0'], weight=ww, avg_factor=af)
+            assert (len(calls) > n0) == (fused or w is None)
+            (v * 1.7).backward()
+            grads.append((v.detach().cpu(), a.grad.cpu(), b.grad.cpu()))
+        if w is None:
+            continue
+        for x, y in zip(*grads):
+            torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)
+    a, b = logw.clone().requires_grad_(True), ct.clone().requires_grad_(True)
+    v = md(a, b, g['nf0'])
+    v.backward()
+    ref_a, ref_b = logw.clone().requires_grad_(True), ct.clone().requires_grad_(True)
+    l = ref_b + torch.logsumexp(ref_a, 0)
+    (torch.where(torch.isnan(l), torch.zeros_like(l), l).mean() * (0.5 / md.norm_factor)).backward()
+    torch.testing.assert_close(a.grad.cpu(), torch.nan_to_num(ref_a.grad.cpu()), rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(b.grad.cpu(), torch.nan_to_num(ref_b.grad.cpu()), rtol=2e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize('dof', [6, 4])
 def test_amis_extension_hooks_reproduce_the_sampler(backend, dof):
     """allocate_buffer / initial_fit / gen_new_distr / gen_old_distr / estimate_params (epropnp.py:199-342): the AMIS
