@@ -269,7 +269,7 @@ struct FusedMonteCarlo : public torch::autograd::Function<FusedMonteCarlo> {
     }
     const Tensor samples_n = ctx->get_saved_variables()[0];
     const epropnp_problem q = pt.c();
-    Tensor glw = g_logw_in.defined() ? g_logw_in.contiguous() : torch::zeros({samples_n.size(0), samples_n.size(1)}, samples_n.options());
+    Tensor glw = g_logw_in.defined() ? g_logw_in.contiguous() : torch::full({samples_n.size(0), samples_n.size(1)}, 0.0, samples_n.options());   // (a fill kernel; zeros() is a memset node under capture)
     Tensor pin, gin;
     if (g_ci.defined() && !ctx->saved_data["pin"].isNone()) { pin = ctx->saved_data["pin"].toTensor(); gin = g_ci.contiguous(); }
     Tensor gx3d, gx2d, gw2d, gdel;

@@ -266,7 +266,7 @@ class _PoseCamGrad(torch.autograd.Function):
         ctx.prob, ctx.poses, ctx.sign, ctx.m_pose = prob, poses.detach(), float(sign), int(m_pose)
         ctx.cam_shape = None if cam_mats is None else cam_mats.shape
         _guard_inputs(ctx, prob)
-        return prob.new(poses.shape[0], prob.B).zero_()
+        return prob.new(poses.shape[0], prob.B).fill_(0.0)      # (fill_: a kernel; zero_() is a memset node under capture)
 
     @staticmethod
     def backward(ctx, g):
@@ -436,7 +436,7 @@ class _MonteCarloCost(torch.autograd.Function):
             return (None,) * 10
         _check_inputs(ctx)
         if g_logw is None:
-            g_logw = torch.zeros(samples.shape[:2], dtype=torch.float32, device=samples.device)
+            g_logw = torch.full(samples.shape[:2], 0.0, dtype=torch.float32, device=samples.device)
         gx3d, gx2d, gw2d, gdel = amis_backward(prob, samples, g_logw, ctx.pose_init, g_cost_init)
         gdelta = None
         if ctx.delta_shape is not None and ctx.needs_input_grad[3]:
@@ -505,7 +505,7 @@ class _FusedMonteCarlo(torch.autograd.Function):
             return (None,) * 9
         _check_inputs(ctx)
         if g_logw is None:
-            g_logw = torch.zeros(samples_n.shape[:2], dtype=torch.float32, device=samples_n.device)
+            g_logw = torch.full(samples_n.shape[:2], 0.0, dtype=torch.float32, device=samples_n.device)
         pin = ctx.keep[1]
         gx3d, gx2d, gw2d, gdel = amis_backward(prob, samples_n, g_logw, pin if g_cost_init is not None else None,
                                                g_cost_init, cstruct=ctx.bprob)

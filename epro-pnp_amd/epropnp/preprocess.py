@@ -46,7 +46,7 @@ class _Prepare(torch.autograd.Function):
         if gx3d is None and gw2d is None:
             return None, None, None, None, None
         B, N, _ = lg.shape
-        gw2d = torch.zeros_like(lg) if gw2d is None else gw2d.contiguous()
+        gw2d = torch.full_like(lg, 0.0) if gw2d is None else gw2d.contiguous()
         gx3d = None if gx3d is None else gx3d.contiguous()
         gl = torch.empty_like(lg)
         gnoc = None if gx3d is None else torch.empty_like(nc)
@@ -123,7 +123,7 @@ class _PrepareDense(torch.autograd.Function):
             return (None,) * 7
         B, _, H, W = lg.shape
         N = ix.shape[1]
-        gw2d = torch.zeros((B, N, 2), dtype=torch.float32, device=lg.device) if gw2d is None else gw2d.contiguous()
+        gw2d = torch.full((B, N, 2), 0.0, dtype=torch.float32, device=lg.device) if gw2d is None else gw2d.contiguous()
         gx3d = None if gx3d is None else gx3d.contiguous()
         gl = torch.empty_like(lg)
         gnoc = None if gx3d is None else torch.empty_like(nc)
