@@ -70,12 +70,15 @@ class EProPnPBase(torch.nn.Module):
         replay.  Also covers the RSLM initialiser of the solver.  Seeds are fixed now (no host sync later)."""
         if self.seed is None:
             self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=device)
+        # [the sampler's call counter, the RSLM initialiser's]: one tensor, so that a forward that advances both does it with
+        # ONE in-stream add (each tiny launch is ~2.5 us of a replayed Det step)
+        self._rng_pair = torch.full((2,), 0, dtype=torch.int64, device=device)
+        self.rng_counter = self._rng_pair[:1]
         init = getattr(self.solver, 'init_solver', None)
         if init is not None and hasattr(init, 'num_proposals'):
             if not hasattr(init, '_draw_seed'):
                 init._draw_seed, init._draw_calls = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
-            init.rng_counter = torch.zeros(1, dtype=torch.int64, device=device)     # its own call counter
+            init.rng_counter = self._rng_pair[1:]       # its own call counter
         return self
 
     # Extension hooks of the reference (epropnp.py:64-82).  monte_carlo_forward runs the fused sampler and does not call
@@ -246,10 +249,16 @@ class EProPnPBase(torch.nn.Module):
         pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
             x3d, x2d, w2d, delta, prob, pose_init, par, noise, bool(with_cost))
         del keep
-        if par.init_mode and inds is None and counter is not None:
-            counter.add_(1)
-        if self.rng_counter is not None and noise is None:
-            self.rng_counter.add_(1)              # in-stream: part of a captured graph
+        bump_init = bool(par.init_mode and inds is None and counter is not None)
+        bump_self = self.rng_counter is not None and noise is None
+        pair = getattr(self, '_rng_pair', None)
+        if bump_init and bump_self and pair is not None and counter.data_ptr() == pair[1:].data_ptr():
+            pair.add_(1)                          # both counters, one in-stream add: part of a captured graph
+        else:
+            if bump_init:
+                counter.add_(1)
+            if bump_self:
+                self.rng_counter.add_(1)
         pose_opt_plus = None
         if with_pose_opt_plus:      # differentiable Gauss-Newton step at pose_opt, in the solver frame, then denormalised
             if self.normalize:      # d/dx3d passes through the (detached) centring unchanged: differentiate w.r.t. x3d itself
