@@ -39,10 +39,9 @@ def test_runs_eagerly_off_device(backend):
     assert pose_opt.shape == (3, 7) and all(bool(torch.isfinite(t.grad).all()) for t in leaves)
 
 
-def _graphed_body():
+def _graphed_body(B=16, N=64):
     from epropnp.graphed import GraphedLoss
     dev = torch.device('cuda:0')
-    B, N = 16, 64
     p = orc.make_problem(B, N, 6, seed=3)
     d, cam, cf = make_layer_objects(p, dev, relative_delta=0.5)
     _, cam_e, cf_e = make_layer_objects(p, dev, relative_delta=0.5)
@@ -85,12 +84,15 @@ def _graphed_body():
 
 @pytest.mark.gpu
 def test_graphed_loss_matches_eager_segment():
-    """Own interpreter, as tests/test_graph_rng.py: keeps graph / private-pool teardown away from the other GPU tests."""
+    """Own interpreter, as tests/test_graph_rng.py: keeps graph / private-pool teardown away from the other GPU tests.
+    16 x 64 and 32 x 512: the second shape runs the AMIS forward split over workgroups, whose exchange slots are reset on the
+    stream before every launch -- by a kernel, because a captured memset node replays garbage after the eager work that sits
+    between two replays here (tests/test_amis.py::test_split_kernels_in_a_hipgraph_survive_eager_work_between_replays)."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    code = ('import sys; sys.path[:0] = [%r, %r, %r]; import test_graphed as t; t._graphed_body(); '
+    code = ('import sys; sys.path[:0] = [%r, %r, %r]; import test_graphed as t; t._graphed_body(); t._graphed_body(32, 512); '
             'print("GRAPHED-OK", flush=True)') % (here, os.path.join(os.path.dirname(here), 'oracle'),
                                                    os.path.join(os.path.dirname(here), 'epro-pnp_amd'))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
