@@ -260,6 +260,15 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   float one[1] = {gd * hs.delta};
   block_sum<1>(one, red);
   if (tid == 0) gdelta[v] = one[0];
+  // delta = mean(w2d) * std * rel came from THIS w2d (Problem.delta_stats): its gradient reaches w2d as one number per
+  // object, added here to what this workgroup has just written instead of by three launches of the caller's autograd.
+  // (With the object split over workgroups the sum of the parts is not known here: delta_path_kernel, amis_kernels.hip.)
+  if (p.delta_stats != nullptr && nsplit == 1) {
+    const float add = (one[0] * p.delta_stats[(size_t)b * 4 + 1]) * (p.delta_relative / (2.0f * (float)p.N));
+    __syncthreads();        // this workgroup's gw2d stores are visible to all of its threads behind the barrier
+    float* row = gw2d + (size_t)b * p.N * 2;
+    for (int i = tid; i < 2 * p.N; i += T) row[i] += add;
+  }
 }
 
 template <class F>

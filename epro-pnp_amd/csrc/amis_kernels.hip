@@ -390,6 +390,26 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   return check_launch("amis_forward_kernel");
 }
 
+// grad_w2d[b, :, :] += (sum over parts of grad_delta[b, part]) * d delta[b] / d w2d  for a Huber threshold that came from
+// AdaptiveHuberPnPCost on this w2d (epropnp_problem.delta_stats): the follow-up launch for the backward variants whose kernel
+// does not know the object's whole grad_delta at its end (object split over workgroups; the all-VALU kernel).
+__global__ __launch_bounds__(256) void delta_path_kernel(Problem p, const float* __restrict__ gdelta, int nparts,
+                                                          float* __restrict__ gw2d) {
+  const int b = (int)blockIdx.x;
+  float g = 0.f;
+  for (int q = 0; q < nparts; ++q) g += gdelta[(size_t)b * nparts + q];
+  const float add = (g * p.delta_stats[(size_t)b * 4 + 1]) * (p.delta_relative / (2.0f * (float)p.N));
+  float* row = gw2d + (size_t)b * p.N * 2;
+  for (int i = (int)threadIdx.x; i < 2 * p.N; i += (int)blockDim.x) row[i] += add;
+}
+
+int launch_delta_path(const epropnp_problem* prob, const float* gdelta, int nparts, float* gw2d, hipStream_t st) {
+  if (prob->delta_stats == nullptr) return EPROPNP_OK;
+  const Problem d = to_device_problem(prob);
+  PNP_LAUNCH(delta_path_kernel, dim3(d.B), dim3(256), 0, st, d, gdelta, nparts, gw2d);
+  return check_launch("delta_path_kernel");
+}
+
 // Few objects: one object's S x N point-poses keep a single CU busy for ~70 us at 512 x 512 whatever the wave count, so
 // the point chunks of an object are dealt to `nsplit` workgroups (each builds the pose table for itself).  The per-point
 // gradients are disjoint and bit-identical to the unsplit kernel; grad_delta comes back as (B, nsplit) partials for the
@@ -407,7 +427,8 @@ int launch_amis_backward_split(const epropnp_problem* prob, const float* pose_sa
   const int rc = launch_amis_backward_mfma(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init,
                                            grad_x3d, grad_x2d, grad_w2d, grad_delta_parts, nsplit, st);
   if (rc == 1) return fail(EPROPNP_EINVAL, "amis_backward_split: mc_samples %d does not fit the LDS pose table", mc_samples);
-  return rc;
+  if (rc != 0) return rc;
+  return nsplit > 1 ? launch_delta_path(prob, grad_delta_parts, nsplit, grad_w2d, st) : EPROPNP_OK;      // (1 part: the kernel's epilogue)
 }
 
 int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
@@ -442,7 +463,8 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
                grad_x2d, grad_w2d, grad_delta, backward_drop_eps());
     return 0;
   });
-  return check_launch("amis_backward_kernel");
+  if (int rc = check_launch("amis_backward_kernel")) return rc;
+  return launch_delta_path(prob, grad_delta, 1, grad_w2d, st);
 }
 
 }  // namespace pnp

@@ -372,7 +372,8 @@ int launch_gn_step_backward(const epropnp_problem* prob, float eps, const float*
                sizeof(float) * (block.x / 64) * kSumTStride<NormalEq<decltype(DOF)::value>::NV>, st, d, eps, pose, grad_step, grad_pose_plus, grad_x3d, grad_x2d, grad_w2d, grad_delta);
     return 0;
   });
-  return check_launch("gn_step_backward_kernel");
+  if (int rc = check_launch("gn_step_backward_kernel")) return rc;
+  return launch_delta_path(prob, grad_delta, 1, grad_w2d, st);      // (no-op unless epropnp_problem.delta_stats is set)
 }
 
 }  // namespace pnp

@@ -46,6 +46,7 @@ inline Problem to_device_problem(const epropnp_problem* p) {
   d.huber_eps = (p->huber_eps > 0.f) ? p->huber_eps : 1e-10f;
   d.inv_huber_eps = 1.0f / d.huber_eps;
   d.status = p->status ? p->status : default_status_word();
+  d.delta_stats = p->delta_stats; d.delta_relative = p->delta_relative;
   return d;
 }
 
@@ -165,6 +166,8 @@ int launch_rslm_draw(const float* w2d, int B, int N, int P, int n_pts, unsigned 
 int launch_adaptive_delta(const float* x2d, const float* w2d, int B, int N, float rel, float* delta, float* stats,
                           hipStream_t st);
 int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, float* loss, float* lse, hipStream_t st);
+// grad_w2d += grad_delta * d delta / d w2d for a threshold from AdaptiveHuberPnPCost (epropnp_problem.delta_stats); no-op without
+int launch_delta_path(const epropnp_problem* prob, const float* gdelta, int nparts, float* gw2d, hipStream_t st);
 // stream-ordered fill as a kernel (never hipMemsetAsync: eval_kernels.hip, fill_u32_kernel)
 int launch_fill_u32(void* p, unsigned v, size_t words, hipStream_t st);
 int launch_mc_loss_reduce(const float* loss, const float* weight, int B, float scale, float momentum, const float* nf_in,

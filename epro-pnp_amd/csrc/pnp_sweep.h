@@ -19,6 +19,8 @@ struct Problem {
   int B, N;
   float huber_eps, inv_huber_eps;   // HuberPnPCost.eps (default 1e-10) and its reciprocal
   int* status;                      // optional int32[2]: [0] |= flags, [1] = min(object index); see epropnp_hip.h
+  const float* delta_stats;         // optional (B,4): delta came from adaptive_delta on this w2d (epropnp_hip.h)
+  float delta_relative;
 };
 
 // record a numerical event for the caller (no-op without a status word); rare by construction, so plain atomics.  System

@@ -37,7 +37,7 @@ void check(int rc, const char* what) {
 // ---------------------------------------------------------------------------------------------------------------------
 // delta_b = mean(w2d_b) * sqrt(sum_xy var_N(x2d_b)) * relative_delta
 struct AdaptiveDelta : public torch::autograd::Function<AdaptiveDelta> {
-  static Tensor forward(AutogradContext* ctx, const Tensor& x2d, const Tensor& w2d, double rel, int64_t stream) {
+  static variable_list forward(AutogradContext* ctx, const Tensor& x2d, const Tensor& w2d, double rel, int64_t stream) {
     const Tensor x = x2d.detach().contiguous(), w = w2d.detach().contiguous();
     const int64_t B = x.size(0), N = x.size(1);
     Tensor delta = torch::empty({B}, x.options()), stats = torch::empty({B, 4}, x.options());
@@ -47,7 +47,8 @@ struct AdaptiveDelta : public torch::autograd::Function<AdaptiveDelta> {
     ctx->saved_data["rel"] = rel;
     ctx->saved_data["N"] = N;
     ctx->set_materialize_grads(false);
-    return delta;
+    ctx->mark_non_differentiable({stats});      // handed to the layer: epropnp_problem.delta_stats
+    return {delta, stats};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const Tensor g = grads[0];
@@ -145,17 +146,18 @@ struct McPoseLossReduced : public torch::autograd::Function<McPoseLossReduced> {
 // monte_carlo_forward: (x3d, x2d, w2d, delta) -> pose_opt_n, samples_n, logweights [diff], cost, cost_init [diff],
 //                                               pose_opt, samples, x3d_centered, offset
 struct ProblemTensors {      // contiguous fp32 device tensors behind an epropnp_problem
-  Tensor x3d, x2d, w2d, cam, lb, ub, delta, status;
-  double z_min = 0.1, huber_eps = 1e-10;
+  Tensor x3d, x2d, w2d, cam, lb, ub, delta, status, dstats;
+  double z_min = 0.1, huber_eps = 1e-10, drel = 0.0;
   int64_t dof = 6;
   epropnp_problem c() const {
-    epropnp_problem p;
+    epropnp_problem p = {};
     p.x3d = fptr(x3d); p.x2d = fptr(x2d); p.w2d = fptr(w2d); p.cam_mats = fptr(cam);
     p.lb = fptr(lb); p.ub = fptr(ub); p.delta = fptr(delta);
     p.z_min = (float)z_min;
     p.num_obj = (int32_t)x2d.size(0); p.num_pts = (int32_t)x2d.size(1); p.dof = (int32_t)dof;
     p.huber_eps = (float)huber_eps;
     p.status = status.defined() ? status.data_ptr<int32_t>() : nullptr;
+    p.delta_stats = fptr(dstats); p.delta_relative = (float)drel;
     return p;
   }
 };
@@ -184,7 +186,8 @@ struct FusedMonteCarlo : public torch::autograd::Function<FusedMonteCarlo> {
                                const Tensor& cam_c, const OptTensor& lb_c, const OptTensor& ub_c, const Tensor& delta_c,
                                const OptTensor& status, double z_min, double huber_eps, int64_t dof,
                                const OptTensor& pose_init, const OptTensor& noise, const std::string& mc_params,
-                               bool with_cost, int64_t nsplit, int64_t stream) {
+                               bool with_cost, int64_t nsplit, int64_t stream, const OptTensor& delta_stats,
+                               double delta_rel) {
     (void)x3d; (void)x2d; (void)w2d;      // graph inputs; the kernels read the contiguous fp32 views
     TORCH_CHECK(mc_params.size() == sizeof(epropnp_mc_params), "mc_params: ", mc_params.size(), " bytes, expected ",
                 sizeof(epropnp_mc_params));
@@ -230,6 +233,11 @@ struct FusedMonteCarlo : public torch::autograd::Function<FusedMonteCarlo> {
     ctx->saved_data["z_min"] = z_min; ctx->saved_data["huber_eps"] = huber_eps; ctx->saved_data["dof"] = dof;
     ctx->saved_data["nsplit"] = nsplit; ctx->saved_data["stream"] = stream;
     ctx->saved_data["delta_dim"] = (delta.has_value() && delta->defined()) ? (int64_t)delta->dim() : (int64_t)-1;
+    // delta = adaptive_delta(., w2d) of THIS w2d: the backward kernel adds grad_delta's way into grad_w2d itself
+    // (epropnp_problem.delta_stats) and delta receives no gradient from this node
+    const bool fold = delta_stats.has_value() && delta_stats->defined();
+    ctx->saved_data["dstats"] = fold ? c10::IValue(delta_stats->detach().contiguous()) : c10::IValue();
+    ctx->saved_data["drel"] = delta_rel;
     // version guard on the caller-visible inputs (the contiguous views share their version counters when no copy was made)
     std::vector<int64_t> vers;
     for (const Tensor* t : {&x3d_c, &x2d_c, &w2d_c, &delta_c, &cam_c}) vers.push_back((int64_t)t->_version());
@@ -247,7 +255,7 @@ struct FusedMonteCarlo : public torch::autograd::Function<FusedMonteCarlo> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(21);
+    variable_list out(23);
     const Tensor g_logw_in = grads[2], g_ci = grads[4];
     if (!g_logw_in.defined() && !g_ci.defined()) return out;
     const auto vers = ctx->saved_data["versions"].toIntVector();
@@ -259,6 +267,8 @@ struct FusedMonteCarlo : public torch::autograd::Function<FusedMonteCarlo> {
     if (!ctx->saved_data["lb"].isNone()) { pt.lb = ctx->saved_data["lb"].toTensor(); pt.ub = ctx->saved_data["ub"].toTensor(); }
     pt.z_min = ctx->saved_data["z_min"].toDouble(); pt.huber_eps = ctx->saved_data["huber_eps"].toDouble();
     pt.dof = ctx->saved_data["dof"].toInt();
+    const bool fold = !ctx->saved_data["dstats"].isNone();
+    if (fold) { pt.dstats = ctx->saved_data["dstats"].toTensor(); pt.drel = ctx->saved_data["drel"].toDouble(); }
     {
       const Tensor* ts[5] = {&gx3d0, &pt.x2d, &pt.w2d, &pt.delta, &pt.cam};
       for (int i = 0; i < 5; ++i)
@@ -279,7 +289,7 @@ struct FusedMonteCarlo : public torch::autograd::Function<FusedMonteCarlo> {
     if (ctx->needs_input_grad(1)) out[1] = gx2d;
     if (ctx->needs_input_grad(2)) out[2] = gw2d;
     const int64_t ddim = ctx->saved_data["delta_dim"].toInt();
-    if (ddim >= 0 && ctx->needs_input_grad(3)) out[3] = (ddim == 0) ? gdel.sum() : gdel;
+    if (!fold && ddim >= 0 && ctx->needs_input_grad(3)) out[3] = (ddim == 0) ? gdel.sum() : gdel;
     return out;
   }
 };
@@ -292,7 +302,7 @@ struct GnStep : public torch::autograd::Function<GnStep> {
                         const Tensor& x3d_c, const Tensor& x2d_c, const Tensor& w2d_c, const Tensor& cam_c,
                         const OptTensor& lb_c, const OptTensor& ub_c, const Tensor& delta_c, const OptTensor& status,
                         double z_min, double huber_eps, int64_t dof, const Tensor& pose, double eps, bool with_plus,
-                        int64_t stream) {
+                        int64_t stream, const OptTensor& delta_stats, double delta_rel) {
     (void)x3d; (void)x2d; (void)w2d;
     ProblemTensors pt;
     pt.x3d = x3d_c; pt.x2d = x2d_c; pt.w2d = w2d_c; pt.cam = cam_c; pt.delta = delta_c;
@@ -312,6 +322,9 @@ struct GnStep : public torch::autograd::Function<GnStep> {
     ctx->saved_data["ub"] = pt.ub.defined() ? c10::IValue(pt.ub) : c10::IValue();
     ctx->saved_data["z_min"] = z_min; ctx->saved_data["huber_eps"] = huber_eps; ctx->saved_data["dof"] = dof;
     ctx->saved_data["eps"] = eps; ctx->saved_data["with_plus"] = with_plus; ctx->saved_data["stream"] = stream;
+    const bool fold = delta_stats.has_value() && delta_stats->defined();     // epropnp_problem.delta_stats: see FusedMonteCarlo
+    ctx->saved_data["dstats"] = fold ? c10::IValue(delta_stats->detach().contiguous()) : c10::IValue();
+    ctx->saved_data["drel"] = delta_rel;
     ctx->saved_data["delta_dim"] = (delta.has_value() && delta->defined()) ? (int64_t)delta->dim() : (int64_t)-1;
     std::vector<int64_t> vers;
     for (const Tensor* t : {&x3d_c, &x2d_c, &w2d_c, &delta_c, &cam_c}) vers.push_back((int64_t)t->_version());
@@ -320,7 +333,7 @@ struct GnStep : public torch::autograd::Function<GnStep> {
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(19);
+    variable_list out(21);
     if (!grads[0].defined()) return out;
     ProblemTensors pt;
     pt.x3d = ctx->saved_data["x3d"].toTensor(); pt.x2d = ctx->saved_data["x2d"].toTensor();
@@ -328,6 +341,8 @@ struct GnStep : public torch::autograd::Function<GnStep> {
     pt.delta = ctx->saved_data["delta"].toTensor();
     if (!ctx->saved_data["lb"].isNone()) { pt.lb = ctx->saved_data["lb"].toTensor(); pt.ub = ctx->saved_data["ub"].toTensor(); }
     pt.z_min = ctx->saved_data["z_min"].toDouble(); pt.huber_eps = ctx->saved_data["huber_eps"].toDouble();
+    const bool fold = !ctx->saved_data["dstats"].isNone();
+    if (fold) { pt.dstats = ctx->saved_data["dstats"].toTensor(); pt.drel = ctx->saved_data["drel"].toDouble(); }
     pt.dof = ctx->saved_data["dof"].toInt();
     const auto vers = ctx->saved_data["versions"].toIntVector();
     const Tensor* ts[5] = {&pt.x3d, &pt.x2d, &pt.w2d, &pt.delta, &pt.cam};
@@ -352,7 +367,7 @@ struct GnStep : public torch::autograd::Function<GnStep> {
     if (ctx->needs_input_grad(1)) out[1] = gx2d;
     if (ctx->needs_input_grad(2)) out[2] = gw2d;
     const int64_t ddim = ctx->saved_data["delta_dim"].toInt();
-    if (ddim >= 0 && ctx->needs_input_grad(3)) out[3] = (ddim == 0) ? gdel.sum() : gdel;
+    if (!fold && ddim >= 0 && ctx->needs_input_grad(3)) out[3] = (ddim == 0) ? gdel.sum() : gdel;
     return out;
   }
 };
@@ -388,17 +403,17 @@ struct ShiftPoses : public torch::autograd::Function<ShiftPoses> {
 Tensor gn_step(const Tensor& x3d, const Tensor& x2d, const Tensor& w2d, const OptTensor& delta, const Tensor& x3d_c,
                const Tensor& x2d_c, const Tensor& w2d_c, const Tensor& cam_c, const OptTensor& lb_c, const OptTensor& ub_c,
                const Tensor& delta_c, const OptTensor& status, double z_min, double huber_eps, int64_t dof, const Tensor& pose,
-               double eps, bool with_plus, int64_t stream) {
+               double eps, bool with_plus, int64_t stream, const OptTensor& delta_stats, double delta_rel) {
   return GnStep::apply(x3d, x2d, w2d, delta, x3d_c, x2d_c, w2d_c, cam_c, lb_c, ub_c, delta_c, status, z_min, huber_eps, dof, pose,
-                       eps, with_plus, stream);
+                       eps, with_plus, stream, delta_stats, delta_rel);
 }
 
 Tensor shift_poses(const Tensor& pose, const Tensor& offset, double sign, int64_t stream) {
   return ShiftPoses::apply(pose, offset, sign, stream);
 }
 
-Tensor adaptive_delta(const Tensor& x2d, const Tensor& w2d, double rel, int64_t stream) {
-  return AdaptiveDelta::apply(x2d, w2d, rel, stream);
+variable_list adaptive_delta(const Tensor& x2d, const Tensor& w2d, double rel, int64_t stream) {
+  return AdaptiveDelta::apply(x2d, w2d, rel, stream);       // (delta, stats)
 }
 
 Tensor mc_pose_loss(const Tensor& logw, const OptTensor& cost_target, int64_t stream) {
@@ -415,10 +430,11 @@ std::vector<OptTensor> fused_monte_carlo(const Tensor& x3d, const Tensor& x2d, c
                                          const OptTensor& lb_c, const OptTensor& ub_c, const Tensor& delta_c,
                                          const OptTensor& status, double z_min, double huber_eps, int64_t dof,
                                          const OptTensor& pose_init, const OptTensor& noise, const py::bytes& mc_params,
-                                         bool with_cost, int64_t nsplit, int64_t stream) {
+                                         bool with_cost, int64_t nsplit, int64_t stream, const OptTensor& delta_stats,
+                                         double delta_rel) {
   const variable_list r = FusedMonteCarlo::apply(x3d, x2d, w2d, delta, x3d_c, x2d_c, w2d_c, cam_c, lb_c, ub_c, delta_c, status,
                                                  z_min, huber_eps, dof, pose_init, noise, std::string(mc_params), with_cost,
-                                                 nsplit, stream);
+                                                 nsplit, stream, delta_stats, delta_rel);
   std::vector<OptTensor> out;
   for (const Tensor& t : r) out.push_back((t.defined() && t.numel() > 0) ? OptTensor(t) : OptTensor());
   return out;

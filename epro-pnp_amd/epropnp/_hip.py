@@ -23,7 +23,8 @@ class Problem(C.Structure):
     _fields_ = [('x3d', C.c_void_p), ('x2d', C.c_void_p), ('w2d', C.c_void_p), ('cam_mats', C.c_void_p),
                 ('lb', C.c_void_p), ('ub', C.c_void_p), ('delta', C.c_void_p), ('z_min', C.c_float),
                 ('num_obj', C.c_int32), ('num_pts', C.c_int32), ('dof', C.c_int32),
-                ('huber_eps', C.c_float), ('status', C.c_void_p)]
+                ('huber_eps', C.c_float), ('status', C.c_void_p), ('delta_stats', C.c_void_p),
+                ('delta_relative', C.c_float)]
 
 
 class LmParams(C.Structure):

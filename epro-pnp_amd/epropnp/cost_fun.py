@@ -75,13 +75,20 @@ class AdaptiveHuberPnPCost(HuberPnPCost):
         self.delta = delta
         self.relative_delta = relative_delta
         self.eps = eps
+        self._delta_src = None
 
     def set_param(self, x2d, w2d):
         from . import _hip
         if x2d.dim() == 3 and x2d.shape == w2d.shape and x2d.size(0) > 0 and x2d.size(1) > 1 \
                 and _hip.on_hip_path(x2d, w2d):
             from .functional import adaptive_delta        # one fused pass (fwd) instead of ~8 ATen launches
-            self.delta = adaptive_delta(x2d, w2d, self.relative_delta)
+            self.delta, stats = adaptive_delta(x2d, w2d, self.relative_delta)
+            # what the layer needs to add this threshold's gradient to grad_w2d inside its own backward kernel when it is
+            # handed the SAME w2d (epropnp.py:_fused_forward; include/epropnp_hip.h: epropnp_problem.delta_stats)
+            import weakref      # (weak: neither the caller's w2d nor delta's autograd graph is kept alive from here)
+            self._delta_src = (weakref.ref(self.delta), weakref.ref(w2d), stats, float(self.relative_delta),
+                               bool(x2d.requires_grad))
             return
+        self._delta_src = None
         spread = torch.var(x2d, dim=-2).sum(dim=-1).sqrt()
         self.delta = w2d.mean(dim=(-2, -1)) * spread * self.relative_delta

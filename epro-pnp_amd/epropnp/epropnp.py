@@ -10,6 +10,8 @@ Extra (non-reference) knobs, all optional:
   * `seed`            : Philox key of the on-device sampler (default: drawn once from torch's global generator)
   * `noise=` kwarg of monte_carlo_forward : injected base draws, for bit-reproducible comparisons with the oracle.
 """
+import os
+
 import torch
 
 from . import functional as hip
@@ -246,8 +248,16 @@ class EProPnPBase(torch.nn.Module):
             par.rslm_scratch, par.rslm_scratch_bytes = _hip.ptr(rs), 0 if rs is None else rs.numel() * 4
             keep = (inds, rot, counter, split_scratch, rs, lm_scratch)
         delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
+        # AdaptiveHuberPnPCost.set_param on THIS w2d (x2d detached, as the reference's callers do): delta's gradient reaches
+        # w2d as one number per object, which the backward kernel adds in its epilogue -- the node then owes delta nothing,
+        # and autograd is spared two elementwise launches and the (B,N,2) add of AccumulateGrad (EPROPNP_DELTA_FOLD=0: off)
+        src, fold = getattr(cost_fun, '_delta_src', None), None
+        if src is not None and delta is not None and torch.is_grad_enabled() and w2d.requires_grad \
+                and os.environ.get('EPROPNP_DELTA_FOLD', '1') != '0' and src[0]() is delta and src[1]() is w2d and not src[4]:
+            fold = (src[2], src[3])
+            prob.fold_delta(*fold)          # (every backward built on `prob`, pose_opt_plus below included)
         pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
-            x3d, x2d, w2d, delta, prob, pose_init, par, noise, bool(with_cost))
+            x3d, x2d, w2d, None if fold else delta, prob, pose_init, par, noise, bool(with_cost))
         del keep
         bump_init = bool(par.init_mode and inds is None and counter is not None)
         bump_self = self.rng_counter is not None and noise is None

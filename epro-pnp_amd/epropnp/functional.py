@@ -140,6 +140,15 @@ class PnPProblem:
                               _hip.ptr(self.lb), _hip.ptr(self.ub), _hip.ptr(self.delta), self.z_min, B, N, dof,
                               self.huber_eps, _hip.ptr(self.status))
         self.stream = _hip.stream_of(self.x2d)
+        self.delta_fold = None
+
+    def fold_delta(self, stats, relative_delta):
+        """`delta` is AdaptiveHuberPnPCost's threshold of THIS w2d (stats (B,4), relative_delta of that set_param): the
+        backward entry points add its gradient to grad_w2d themselves (include/epropnp_hip.h: epropnp_problem.delta_stats) and
+        the autograd nodes built on this problem return no gradient for delta."""
+        self.delta_fold = (_f32c(stats, 'delta_stats'), float(relative_delta))
+        self.c.delta_stats, self.c.delta_relative = self.delta_fold[0].data_ptr(), self.delta_fold[1]
+        return self
 
     @staticmethod
     def _bound(v, B, dev):
@@ -485,7 +494,7 @@ class _FusedMonteCarlo(torch.autograd.Function):
                   p(start_pose), p(start_cost), p(pose_opt_n), p(pose_cov), p(cost), p(samples_n), p(logw), p(cost_init),
                   p(pose_opt), p(samples), prob.stream)
         if normalize:      # the backward differentiates the cost in the solver frame: same problem, centred points
-            bprob = _hip.Problem.from_buffer_copy(prob.c)
+            bprob = _hip.Problem.from_buffer_copy(prob.c)       # (prob.fold_delta travels with the copy)
             bprob.x3d = x3d_c.data_ptr()
         else:
             bprob = prob.c
@@ -530,8 +539,10 @@ def fused_monte_carlo(x3d, x2d, w2d, delta, prob, pose_init, par, noise, with_co
         pose_opt_n, samples_n, logw, cost, cost_init, pose_opt, samples, x3d_c, offset = ext.fused_monte_carlo(
             x3d, x2d, w2d, delta, prob.x3d, prob.x2d, prob.w2d, prob.cam, prob.lb, prob.ub, prob.delta, prob.status,
             prob.z_min, prob.huber_eps, prob.dof, pose_init, noise, bytes(par), bool(with_cost),
-            backward_split(prob.B, prob.N, par.amis.mc_samples), int(prob.stream or 0))
+            backward_split(prob.B, prob.N, par.amis.mc_samples), int(prob.stream or 0),
+            None if prob.delta_fold is None else prob.delta_fold[0], 0.0 if prob.delta_fold is None else prob.delta_fold[1])
     else:
+        assert prob.delta_fold is None or delta is None, 'a folded delta takes no gradient from this node'
         pose_opt_n, samples_n, logw, cost, cost_init, pose_opt, samples, x3d_c, offset = _FusedMonteCarlo.apply(
             x3d, x2d, w2d, delta, prob, pose_init, par, noise, with_cost)
     if pose_opt is None:
@@ -554,10 +565,11 @@ class _AdaptiveDelta(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, stats)
         ctx.rel, ctx.N = float(relative_delta), N
-        return delta
+        ctx.mark_non_differentiable(stats)
+        return delta, stats
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_stats=None):
         if g is None:
             return None, None, None
         x, stats = ctx.saved_tensors
@@ -573,10 +585,12 @@ class _AdaptiveDelta(torch.autograd.Function):
 
 
 def adaptive_delta(x2d, w2d, relative_delta):
+    """-> delta (B,) [differentiable], stats (B,4) = [mean_w, x2d_std, mean_x, mean_y] of the same pass"""
     ext = _hip.torch_ext()
     if ext is not None:
         _f32c(x2d, 'x2d'), _f32c(w2d, 'w2d')
-        return ext.adaptive_delta(x2d, w2d, float(relative_delta), int(_hip.stream_of(x2d) or 0))
+        delta, stats = ext.adaptive_delta(x2d, w2d, float(relative_delta), int(_hip.stream_of(x2d) or 0))
+        return delta, stats
     return _AdaptiveDelta.apply(x2d, w2d, relative_delta)
 
 
@@ -818,15 +832,17 @@ class _GnStep(torch.autograd.Function):
 
 def _ext_gn_step(ext, x3d, x2d, w2d, delta, prob, pose, eps, with_plus):
     _f32c(pose, 'pose')
-    return ext.gn_step(x3d, x2d, w2d, delta, prob.x3d, prob.x2d, prob.w2d, prob.cam, prob.lb, prob.ub, prob.delta, prob.status,
-                       prob.z_min, prob.huber_eps, prob.dof, pose, float(eps), with_plus, int(prob.stream or 0))
+    fold = prob.delta_fold
+    return ext.gn_step(x3d, x2d, w2d, None if fold else delta, prob.x3d, prob.x2d, prob.w2d, prob.cam, prob.lb, prob.ub,
+                       prob.delta, prob.status, prob.z_min, prob.huber_eps, prob.dof, pose, float(eps), with_plus,
+                       int(prob.stream or 0), None if fold is None else fold[0], 0.0 if fold is None else fold[1])
 
 
 def gn_step(x3d, x2d, w2d, delta, prob, pose, eps):
     ext = _hip.torch_ext()
     if ext is not None:
         return _ext_gn_step(ext, x3d, x2d, w2d, delta, prob, pose, eps, False)
-    return _GnStep.apply(x3d, x2d, w2d, delta, prob, pose, eps)
+    return _GnStep.apply(x3d, x2d, w2d, None if prob.delta_fold else delta, prob, pose, eps)
 
 
 class _PoseOptPlus(torch.autograd.Function):
@@ -868,4 +884,4 @@ def pose_opt_plus(x3d, x2d, w2d, delta, prob, pose, eps):
     ext = _hip.torch_ext()
     if ext is not None:
         return _ext_gn_step(ext, x3d, x2d, w2d, delta, prob, pose, eps, True)
-    return _PoseOptPlus.apply(x3d, x2d, w2d, delta, prob, pose, eps)
+    return _PoseOptPlus.apply(x3d, x2d, w2d, None if prob.delta_fold else delta, prob, pose, eps)

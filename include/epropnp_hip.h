@@ -53,6 +53,15 @@ typedef struct epropnp_problem {
                             torch.linalg.solve / torch.inverse raise in the reference (levenberg_marquardt.py:15-19,
                             :178-181) instead of receiving NaN poses silently.  NULL selects the library's default
                             status word (epropnp_async_status below).                                                 */
+  const float* delta_stats;  /* optional: the (B,4) `stats` of the epropnp_adaptive_delta call that produced `delta` from THIS
+                            w2d (AdaptiveHuberPnPCost.set_param, cost_fun.py:123-126), else NULL.  Then d delta[b] / d w2d[b,n,c]
+                            is the same number for every n, c -- stats[b][1] * delta_relative / (2 N) -- and the entry points
+                            that return grad_w2d together with grad_delta (epropnp_amis_backward[_split], epropnp_gn_step_backward,
+                            epropnp_pose_opt_plus_backward) add grad_delta[b] times it to every element of grad_w2d[b] themselves
+                            (the backward kernel's epilogue, or one follow-up launch) instead of leaving three elementwise
+                            launches and a (B,N,2) add to the caller's autograd; the caller must then NOT propagate grad_delta to
+                            w2d again.  Forward entry points ignore it.                                                    */
+  float delta_relative;      /* the relative_delta of that call (used only with delta_stats)                              */
 } epropnp_problem;
 
 /* status[0] flags */
