@@ -424,8 +424,12 @@ __global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__
 
 // pnp_normalize / pnp_denormalize (epropnp/common.py:103-136) as two launches instead of ~10 ATen launches each.
 // center: offset[b] = mean_n x3d[b,n,:];  out[b,n,:] = x3d[b,n,:] - offset[b]
+// DOF != 0: the object's pose_init is moved into the centred frame by the same launch (shift_poses_kernel's arithmetic with
+// sign = +1, by thread 0) -- pnp_normalize's two steps in one launch of the one-call forward.
+template <int DOF>
 __global__ __launch_bounds__(256) void center_points_kernel(const float* __restrict__ x3d, int B, int N,
-                                                             float* __restrict__ offset, float* __restrict__ out) {
+                                                             float* __restrict__ offset, float* __restrict__ out,
+                                                             const float* __restrict__ pose, float* __restrict__ pose_out) {
   __shared__ float scratch[3 * 4];
   const int b = object_of_block(B);
   if (b >= B) return;
@@ -442,6 +446,18 @@ __global__ __launch_bounds__(256) void center_points_kernel(const float* __restr
   }
   if (threadIdx.x == 0) {
     offset[(size_t)b * 3] = m0; offset[(size_t)b * 3 + 1] = m1; offset[(size_t)b * 3 + 2] = m2;
+    if (DOF != 0) {
+      constexpr int PL = PoseLen<DOF == 0 ? 6 : DOF>::value;
+      float ps[PL], R[9];
+#pragma unroll
+      for (int k = 0; k < PL; ++k) ps[k] = pose[(size_t)b * PL + k];
+      pose_to_rot<DOF == 0 ? 6 : DOF>(ps, R);
+      ps[0] += 1.0f * (R[0] * m0 + R[1] * m1 + R[2] * m2);
+      ps[1] += 1.0f * (R[3] * m0 + R[4] * m1 + R[5] * m2);
+      ps[2] += 1.0f * (R[6] * m0 + R[7] * m1 + R[8] * m2);
+#pragma unroll
+      for (int k = 0; k < PL; ++k) pose_out[(size_t)b * PL + k] = ps[k];
+    }
   }
 }
 
@@ -549,8 +565,23 @@ int launch_center_points(const float* x3d, int B, int N, float* offset, float* o
   if (!x3d || !offset || !out || N < 1) return fail(EPROPNP_EINVAL, "center_points: bad argument");
   int threads = 64;
   while (threads < 256 && threads * 2 < N) threads *= 2;
-  PNP_LAUNCH(center_points_kernel, dim3(padded_object_grid(B)), dim3(threads), 0, st, x3d, B, N, offset, out);
+  PNP_LAUNCH(center_points_kernel<0>, dim3(padded_object_grid(B)), dim3(threads), 0, st, x3d, B, N, offset, out,
+             (const float*)nullptr, (float*)nullptr);
   return check_launch("center_points_kernel");
+}
+
+int launch_center_points_shift(const float* x3d, int B, int N, float* offset, float* out, const float* pose, float* pose_out,
+                               int dof, hipStream_t st) {
+  if (B <= 0) return EPROPNP_OK;
+  if (!x3d || !offset || !out || !pose || !pose_out || N < 1 || (dof != 4 && dof != 6))
+    return fail(EPROPNP_EINVAL, "center_points_shift: bad argument");
+  int threads = 64;
+  while (threads < 256 && threads * 2 < N) threads *= 2;
+  if (dof == 6)
+    PNP_LAUNCH(center_points_kernel<6>, dim3(padded_object_grid(B)), dim3(threads), 0, st, x3d, B, N, offset, out, pose, pose_out);
+  else
+    PNP_LAUNCH(center_points_kernel<4>, dim3(padded_object_grid(B)), dim3(threads), 0, st, x3d, B, N, offset, out, pose, pose_out);
+  return check_launch("center_points_kernel (+ pose_init)");
 }
 
 int launch_shift_poses(const float* pose, const float* offset, int P, int B, int dof, float sign, float* out,

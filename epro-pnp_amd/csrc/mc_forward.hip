@@ -47,13 +47,14 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
   const float* pinit = pose_init;
   int rc;
   if (par->normalize) {       // pnp_normalize (common.py:103-124)
-    { StageScope ps("center_points", st); if ((rc = launch_center_points(prob->x3d, B, prob->num_pts, offset, x3d_centered, st))) return rc; }
-    q.x3d = x3d_centered;
-    if (pose_init) {
-      StageScope ps("shift_poses", st);
-      if ((rc = launch_shift_poses(pose_init, offset, 1, B, prob->dof, +1.0f, pose_init_n, st))) return rc;
-      pinit = pose_init_n;
+    {   // centred points and, in the same launch, pose_init in the centred frame
+      StageScope ps("center_points", st);
+      rc = pose_init ? launch_center_points_shift(prob->x3d, B, prob->num_pts, offset, x3d_centered, pose_init, pose_init_n, prob->dof, st)
+                     : launch_center_points(prob->x3d, B, prob->num_pts, offset, x3d_centered, st);
+      if (rc) return rc;
     }
+    q.x3d = x3d_centered;
+    if (pose_init) pinit = pose_init_n;
   }
   if (pinit) {                // cost of pose_init (:121-124)
     StageScope ps("evaluate_cost", st);
