@@ -43,6 +43,24 @@ __global__ void kern(const u32x4* __restrict__ A, const u32x4* __restrict__ B, f
                    "v_mov_b32 %0, v40\n\t"
                    : "=v"(r0) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b), "n"(K)
                    : "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51");
+    } else if (MODE == 4) {   // destination = the A source registers (what the register allocator may choose), K unused
+      asm volatile("v_mov_b32 v48, %1\n\tv_mov_b32 v49, %2\n\tv_mov_b32 v50, %3\n\tv_mov_b32 v51, %4\n\t" NOP16
+                   "v_mfma_f32_16x16x32_bf16 v[48:51], v[48:51], %5, 0\n\t" NOP64
+                   "v_mov_b32 %0, v48\n\t"
+                   : "=v"(r0) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b), "n"(K)
+                   : "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51");
+    } else if (MODE == 5) {   // destination = the B source registers
+      asm volatile("v_mov_b32 v48, %1\n\tv_mov_b32 v49, %2\n\tv_mov_b32 v50, %3\n\tv_mov_b32 v51, %4\n\t" NOP16
+                   "v_mfma_f32_16x16x32_bf16 v[48:51], %5, v[48:51], 0\n\t" NOP64
+                   "v_mov_b32 %0, v48\n\t"
+                   : "=v"(r0) : "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(a), "n"(K)
+                   : "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51");
+    } else if (MODE == 6) {   // back-to-back MFMAs into the SAME destination, K wait states apart, the first one's value must not survive
+      asm volatile("v_mfma_f32_16x16x32_bf16 v[40:43], %2, %1, 0\n\t"
+                   ".rept %3\n\ts_nop 0\n\t.endr\n\t"
+                   "v_mfma_f32_16x16x32_bf16 v[40:43], %1, %2, 0\n\t" NOP64
+                   "v_mov_b32 %0, v40\n\t"
+                   : "=v"(r0) : "v"(a), "v"(b), "n"(K) : "v40", "v41", "v42", "v43");
     } else {                  // WAW: VALU write to the destination behind the MFMA
       asm volatile("v_mfma_f32_16x16x32_bf16 v[40:43], %1, %2, 0\n\t"
                    ".rept %3\n\ts_nop 0\n\t.endr\n\t"
@@ -93,5 +111,20 @@ int main() {
   sweep<1>("RAW2", dA, dB, dOut, h, blocks);
   sweep<2>("WAR", dA, dB, dOut, h, blocks);
   sweep<3>("WAW", dA, dB, dOut, h, blocks);
+  {   // in-place destinations against the separate-destination result (MODE 0 with 64 wait states)
+    std::vector<float> ref(h.size());
+    run<0, 64>(dA, dB, dOut, ref, blocks);
+    run<4, 0>(dA, dB, dOut, h, blocks);
+    size_t n = 0; for (size_t i = 0; i < h.size(); ++i) n += h[i] != ref[i];
+    printf("D = A registers: %zu lanes differ from the separate-destination result\n", n);
+    // (MODE 5 swaps the operand roles: compare with the swapped reference)
+    std::vector<float> ref5(h.size());
+    hipLaunchKernelGGL((kern<1, 64>), dim3(blocks), dim3(256), 0, 0, dA, dB, dOut, 64);      // MODE 1 also computes mfma(b, a) into v[44:47] but returns D1
+    run<5, 0>(dA, dB, dOut, h, blocks);
+    run<5, 1>(dA, dB, dOut, ref5, blocks);
+    n = 0; for (size_t i = 0; i < h.size(); ++i) n += h[i] != ref5[i];
+    printf("D = B registers: run-to-run %zu lanes differ\n", n);
+  }
+  sweep<6>("WAWmm", dA, dB, dOut, h, blocks);
   return 0;
 }
