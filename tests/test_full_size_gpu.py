@@ -294,9 +294,15 @@ def test_c2_gn_step_fused_vs_composite_and_backward_variants(dev, monkeypatch):
     for impl in ('mfma', 'valu'):
         monkeypatch.setenv('EPROPNP_BWD_IMPL', impl)
         outs[impl] = F.amis_backward(hp_all, o[3], g, prob['pose_init'], gi)
-    for a, b in zip(outs['mfma'], outs['valu']):
-        den = b.abs().max().clamp(min=1e-20)
-        assert ((a - b).abs().max() / den) < 2e-4
+        # bit-identical from run to run at full occupancy (an instruction-hazard defect shows up exactly here and as
+        # run-to-run differences, while every small-shape test passes: profiles/r03_tune_bwd_bf16_split.txt)
+        again = F.amis_backward(hp_all, o[3], g, prob['pose_init'], gi)
+        assert all(torch.equal(x, y) for x, y in zip(outs[impl], again)), impl
+    for a, b in zip(outs['mfma'][:3], outs['valu'][:3]):      # per OBJECT: one wrong object must not hide behind the batch maximum
+        den = b.abs().amax(dim=(1, 2), keepdim=True).clamp(min=1e-20)
+        assert ((a - b).abs() / den).max() < 5e-4
+    a, b = outs['mfma'][3], outs['valu'][3]
+    assert ((a - b).abs().max() / b.abs().max().clamp(min=1e-20)) < 2e-4
 
 
 def test_c4_fused_rslm_vs_composite(dev, monkeypatch):
