@@ -43,6 +43,57 @@ __global__ void kern(const u32x4* __restrict__ A, const u32x4* __restrict__ B, f
                    "v_mov_b32 %0, v40\n\t"
                    : "=v"(r0) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b), "n"(K)
                    : "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51");
+    } else if (MODE == 7) {   // RAW with a PACKED reader: v_pk_mul_f32 reads the 64-bit pair D[0:1]
+      float r1;
+      asm volatile("v_mov_b32 v52, 1.0\n\tv_mov_b32 v53, 1.0\n\t" NOP16
+                   "v_mfma_f32_16x16x32_bf16 v[40:43], %2, %3, 0\n\t"
+                   ".rept %4\n\ts_nop 0\n\t.endr\n\t"
+                   "v_pk_mul_f32 v[54:55], v[40:41], v[52:53]\n\t" NOP64
+                   "v_mov_b32 %0, v54\n\tv_mov_b32 %1, v55\n\t"
+                   : "=v"(r0), "=v"(r1) : "v"(a), "v"(b), "n"(K) : "v40", "v41", "v42", "v43", "v52", "v53", "v54", "v55");
+      r0 += 3.0f * r1;
+    } else if (MODE == 8) {   // RAW with a packed reader of the UPPER pair D[2:3]
+      float r1;
+      asm volatile("v_mov_b32 v52, 1.0\n\tv_mov_b32 v53, 1.0\n\t" NOP16
+                   "v_mfma_f32_16x16x32_bf16 v[40:43], %2, %3, 0\n\t"
+                   ".rept %4\n\ts_nop 0\n\t.endr\n\t"
+                   "v_pk_mul_f32 v[54:55], v[42:43], v[52:53]\n\t" NOP64
+                   "v_mov_b32 %0, v54\n\tv_mov_b32 %1, v55\n\t"
+                   : "=v"(r0), "=v"(r1) : "v"(a), "v"(b), "n"(K) : "v40", "v41", "v42", "v43", "v52", "v53", "v54", "v55");
+      r0 += 3.0f * r1;
+    } else if (MODE == 9) {   // RAW through a copy: v_mov t <- D[3] after k wait states, v_pk_mul reads {t, D[2]} right behind it
+      float r1;
+      asm volatile("v_mov_b32 v52, 1.0\n\tv_mov_b32 v53, 1.0\n\t" NOP16
+                   "v_mfma_f32_16x16x32_bf16 v[40:43], %2, %3, 0\n\t"
+                   "v_mfma_f32_16x16x32_bf16 v[44:47], %3, %2, 0\n\t"
+                   ".rept %4\n\ts_nop 0\n\t.endr\n\t"
+                   "v_mov_b32 v56, v40\n\tv_mov_b32 v57, v44\n\t"
+                   "v_pk_mul_f32 v[54:55], v[56:57], v[52:53]\n\t" NOP64
+                   "v_mov_b32 %0, v54\n\tv_mov_b32 %1, v55\n\t"
+                   : "=v"(r0), "=v"(r1) : "v"(a), "v"(b), "n"(K)
+                   : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v52", "v53", "v54", "v55", "v56", "v57");
+      r0 += 3.0f * r1;
+    } else if (MODE == 10) {  // VALU write of the A source registers -> MFMA read, K wait states in between
+      asm volatile("v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\t" NOP16
+                   "v_mov_b32 v48, %1\n\tv_mov_b32 v49, %2\n\tv_mov_b32 v50, %3\n\tv_mov_b32 v51, %4\n\t"
+                   ".rept %6\n\ts_nop 0\n\t.endr\n\t"
+                   "v_mfma_f32_16x16x32_bf16 v[40:43], v[48:51], %5, 0\n\t" NOP64
+                   "v_mov_b32 %0, v40\n\t"
+                   : "=v"(r0) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b), "n"(K)
+                   : "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51");
+    } else if (MODE == 11) {  // ... with v_perm_b32 as the writer (the kernel's packing instruction)
+      asm volatile("v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\tv_mov_b32 v52, 0x03020100\n\t" NOP16
+                   "v_perm_b32 v48, %1, %1, v52\n\tv_perm_b32 v49, %2, %2, v52\n\tv_perm_b32 v50, %3, %3, v52\n\tv_perm_b32 v51, %4, %4, v52\n\t"
+                   ".rept %6\n\ts_nop 0\n\t.endr\n\t"
+                   "v_mfma_f32_16x16x32_bf16 v[40:43], v[48:51], %5, 0\n\t" NOP64
+                   "v_mov_b32 %0, v40\n\t"
+                   : "=v"(r0) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b), "n"(K)
+                   : "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51", "v52");
+    } else if (MODE == 12) {  // scalar read of the LAST result register D[3]
+      asm volatile("v_mfma_f32_16x16x32_bf16 v[40:43], %1, %2, 0\n\t"
+                   ".rept %3\n\ts_nop 0\n\t.endr\n\t"
+                   "v_mov_b32 %0, v43\n\t" NOP64
+                   : "=v"(r0) : "v"(a), "v"(b), "n"(K) : "v40", "v41", "v42", "v43");
     } else if (MODE == 4) {   // destination = the A source registers (what the register allocator may choose), K unused
       asm volatile("v_mov_b32 v48, %1\n\tv_mov_b32 v49, %2\n\tv_mov_b32 v50, %3\n\tv_mov_b32 v51, %4\n\t" NOP16
                    "v_mfma_f32_16x16x32_bf16 v[48:51], v[48:51], %5, 0\n\t" NOP64
@@ -126,5 +177,11 @@ int main() {
     printf("D = B registers: run-to-run %zu lanes differ\n", n);
   }
   sweep<6>("WAWmm", dA, dB, dOut, h, blocks);
+  sweep<7>("RAWpk", dA, dB, dOut, h, blocks);
+  sweep<8>("RAWpkH", dA, dB, dOut, h, blocks);
+  sweep<9>("RAWcp", dA, dB, dOut, h, blocks);
+  sweep<10>("VtoA", dA, dB, dOut, h, blocks);
+  sweep<11>("PtoA", dA, dB, dOut, h, blocks);
+  sweep<12>("RAWd3", dA, dB, dOut, h, blocks);
   return 0;
 }
