@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- EPro-PnP hot path throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4|C5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C3-train|C4|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--config ...]
 
@@ -23,6 +23,14 @@ One "step" = one pass of the hot path over one batch of synthetic objects:
       with ONE RCCL `all_gather_into_tensor` per step (`sharding.ObjectExchange`: the pose outputs and the detection
       loss's norm_factor scalar in the same payload) issued in stream order right after the forward -- INSIDE the timed
       region: strong scaling.  The line reports the collective's share of the step.
+  C1 (demo/fit_identity.ipynb cells 5-10, the plumbing case): 1 object x N=64, identity camera, RSLM(8,128,5) + LM 10 +
+      AMIS 512/4, with_pose_opt_plus and the notebook's derivative regularisation; launch-bound.
+  C3 (LineMOD shape as BASELINE.json words it): 32 crops x 64 x 64 = 4096 DENSE correspondences, per-object tensor bounds,
+      z_min 0.01, relative_delta 0.1, LM 5 + AMIS 512/4, fwd+bwd (lib/train.py:143-180 without the sub-sampling).
+  C3-train (the call lib/train.py:177-179 makes): 32 crops x 512 sub-sampled correspondences, RSLM(16,4,3) + LM 5,
+      force_init_solve, with_pose_opt_plus + the loop's translation / rotation regularisers.
+      C1 / C3 / C3-train are launch-bound: like C4 they are replayed from a hipGraph by default (`--launch auto`), and the
+      line carries the eagerly launched step time of the same run beside it (`eager`).
 fp32, inputs resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` is the Jacobian sweep: the fused LM kernel credited one 28 B/point read per
@@ -48,10 +56,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def synth_problem(B, N, device, seed, dof=6):
+def synth_problem(B, N, device, seed, dof=6, cam='pinhole800'):
     """SURVEY.md 8(d) generator, on `device`: x3d ~ N(0,0.5^2); gt t ~ N(0,I), t_z += 5; q ~ normalised N(0,I4);
     K = [[800,0,320],[0,800,240],[0,0,1]]; x2d = project(gt) + N(0,1 px); w2d = softmax_N(U(0,1)) * 2;
-    pose_init = gt perturbed (t += 0.1 N, q = normalize(q + 0.05 N))."""
+    pose_init = gt perturbed (t += 0.1 N, q = normalize(q + 0.05 N)).  cam='identity': K = I (the demo notebook's
+    normalised image plane), image noise 1/800."""
     from epropnp.camera import project_b
     g = torch.Generator(device=device).manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g, device=device)
@@ -63,22 +72,28 @@ def synth_problem(B, N, device, seed, dof=6):
         pose_gt = torch.cat((t, q), -1)
     else:
         pose_gt = torch.cat((t, rn(B, 1)), -1)
-    K = torch.tensor([[800., 0, 320], [0, 800., 240], [0, 0, 1]], device=device).expand(B, 3, 3)
-    x2d = project_b(x3d, pose_gt, K, 0.1)[0] + rn(B, N, 2)
+    if cam == 'identity':
+        K, px = torch.eye(3, device=device).expand(B, 3, 3), 1.0 / 800.0
+    else:
+        K, px = torch.tensor([[800., 0, 320], [0, 800., 240], [0, 0, 1]], device=device).expand(B, 3, 3), 1.0
+    x2d = project_b(x3d, pose_gt, K, 0.1)[0] + rn(B, N, 2) * px
     w2d = torch.softmax(torch.rand(B, N, 2, generator=g, device=device), dim=1) * 2.0
     if dof == 6:
         qi = torch.nn.functional.normalize(pose_gt[:, 3:] + 0.05 * rn(B, 4), dim=-1)
         pose_init = torch.cat((pose_gt[:, :3] + 0.1 * rn(B, 3), qi), -1)
     else:
         pose_init = torch.cat((pose_gt[:, :3] + 0.1 * rn(B, 3), pose_gt[:, 3:] + 0.05 * rn(B, 1)), -1)
-    return dict(x3d=x3d.contiguous(), x2d=x2d.contiguous(), w2d=w2d.contiguous(), cam_mats=K, pose_init=pose_init)
+    return dict(x3d=x3d.contiguous(), x2d=x2d.contiguous(), w2d=w2d.contiguous(), cam_mats=K, pose_init=pose_init,
+                pose_gt=pose_gt)
 
 
 def cpu_baseline(N, S, K, L, sample_objects, budget_s=25.0):
     """The oracle (oracle/epropnp_oracle.py) timed on the host cores on `sample_objects` objects of the same
     workload: monte_carlo_forward + MC loss + backward.  Test/baseline infrastructure -- never the product path.
     torch-CPU oversubscribes badly on many-core hosts (256 threads on small tensors is ~100x slower than 16),
-    so a few thread counts are tried and the best is reported together with the thread count actually used."""
+    so a few thread counts are tried and the best is reported together with the thread count actually used; BASELINE.md
+    section 3 also asks for the 1-thread and the all-cores figures: both are timed on a smaller sample of the same workload
+    (bounded: one warm-up + one timed run each) and reported beside the headline value."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import epropnp_oracle as orc
     host_cores = os.cpu_count() or 1
@@ -101,8 +116,25 @@ def cpu_baseline(N, S, K, L, sample_objects, budget_s=25.0):
             best, best_threads = t, threads
         if time.perf_counter() - t_start > budget_s:
             break
+    # 1 thread / every core, on `small` objects of the same workload (a 1-thread run of the full sample would take minutes)
+    small = max(1, min(sample_objects, 8))
+    sp = {k: v[:small].contiguous() for k, v in prob.items()}
+    sn = {k: v[:, :, :small].contiguous() for k, v in noise.items()}
+    extra = {}
+    for label, threads in (('one_thread', 1), ('all_cores', host_cores)):
+        torch.set_num_threads(threads)
+        ts = []
+        for it in range(2):
+            t0 = time.perf_counter()
+            orc.run_mc(sp, sn, 6, S, K, L)
+            ts.append(time.perf_counter() - t0)
+            if ts[-1] > 15.0:
+                break
+        extra[label] = {'value': round(small / min(ts), 2), 'unit': 'instances/s', 'cores': threads,
+                        'sample': f'{small} objects, best of {len(ts)} run(s)'}
+    torch.set_num_threads(best_threads)
     return dict(value=round(sample_objects / best, 2), unit='instances/s', cores=best_threads, kind='port',
-                host_cores=host_cores, tried_threads_inst_per_s=tried,
+                host_cores=host_cores, tried_threads_inst_per_s=tried, one_thread=extra['one_thread'], all_cores=extra['all_cores'],
                 sample=f'{sample_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd, oracle = PyTorch-CPU restatement '
                        f'with the reference op structure), best of 5 after 1 warm-up per thread count; larger CPU batches are slower per object (256 objects: 100/s)')
 
@@ -151,14 +183,25 @@ CONFIGS = {
     'C2': dict(objects=4096, points=512, samples=512, amis_iters=4, lm_iters=3, dof=6, scaling='weak'),
     'C5': dict(objects=8192, points=2048, samples=1024, amis_iters=4, lm_iters=3, dof=6, scaling='weak'),
     'C4': dict(objects=600, points=128, samples=128, amis_iters=4, lm_iters=5, dof=4, scaling='strong'),
+    # BASELINE.json configs[0] / configs[2]: the reference's own callers (demo notebook, EPro-PnP-6DoF lib/train.py)
+    'C1': dict(objects=1, points=64, samples=512, amis_iters=4, lm_iters=10, dof=6, scaling='weak'),
+    'C3': dict(objects=32, points=4096, samples=512, amis_iters=4, lm_iters=5, dof=6, scaling='weak'),
+    'C3-train': dict(objects=32, points=512, samples=512, amis_iters=4, lm_iters=5, dof=6, scaling='weak'),
 }
+# what the callers of those configurations set besides the sizes (demo/fit_identity.ipynb cell 5; lib/train.py:47-57,168-179)
+CALLER = {
+    'C1': dict(cam='identity', rslm=(8, 128, 5), relative_delta=0.5, z_min=0.1, crop_bounds=False, plus=True),
+    'C3': dict(cam='pinhole800', rslm=None, relative_delta=0.1, z_min=0.01, crop_bounds=True, plus=False),
+    'C3-train': dict(cam='pinhole800', rslm=(16, 4, 3), relative_delta=0.1, z_min=0.01, crop_bounds=True, plus=True),
+}
+LAUNCH_BOUND = ('C4', 'C1', 'C3', 'C3-train')       # `--launch auto` replays these from a hipGraph
 
 
 def measured_traffic(kernel, shape_key):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json, written by
     tools/pmc_traffic.py from separate --pmc runs; gfx950 corrections applied there) -- None when no profile of this
     exact shape is on file, so a stale number can never be attached to a changed workload."""
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):          # newest committed profile of this shape
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):      # newest committed profile of this shape
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name))).get(shape_key, {}).get(kernel)
         except (OSError, ValueError):
@@ -169,6 +212,8 @@ def measured_traffic(kernel, shape_key):
 
 
 IC_BYTES = 256 * 2 ** 20       # MI355X Infinity Cache (MI355X_MICROARCH.md); FETCH_SIZE counts its hits as fetches
+MAX_SWEEP_SETS = 256           # tiny workloads (C1: 2 KB per set) cannot be rotated out of the cache: the line says IC-warm
+LARGE_SWEEP = (8192, 2048)     # `roofline.large`: the C5-shard Jacobian sweep (470 MB per launch: no cache can serve it)
 
 
 def single_sweep(F, make_problem, pose, bytes_per_set, windows=8):
@@ -177,7 +222,7 @@ def single_sweep(F, make_problem, pose, bytes_per_set, windows=8):
     been evicted long before it comes round again and every read is served by HBM (back-to-back launches on ONE 59 MB set
     would be served by the Infinity Cache).  HIP events on the launch stream around windows of one full rotation
     -> (mean, median) ms per launch, number of sets."""
-    sets = max(2, -(-2 * IC_BYTES // int(bytes_per_set)) + 1)
+    sets = min(MAX_SWEEP_SETS, max(2, -(-2 * IC_BYTES // int(bytes_per_set)) + 1))
     probs = [make_problem() for _ in range(sets)]
     for _ in range(3):          # untimed rotations: first touch of the fresh copies (page tables), clocks back up after the
         for hp in probs:        # host-side pause that follows the step loop
@@ -195,7 +240,10 @@ def single_sweep(F, make_problem, pose, bytes_per_set, windows=8):
     return sum(ts) / len(ts), ts[len(ts) // 2], sets
 
 
-def main():
+def main(argv=None, device=None, backend='nccl'):
+    """`device` / `backend`: test hook (tests/test_distributed.py drives this very function with two gloo ranks on the CPU
+    emulation of the kernels, which the TEST installs from the outside): a non-HIP device skips everything that needs the
+    GPU -- hipGraph capture, HIP events, the roofline legs -- and prints a reduced line.  The driver's command never sets it."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -213,7 +261,10 @@ def main():
                     help="'graph': the rank's whole step (RCCL exchange included) captured once into a hipGraph; the timed "
                          "region replays it (fresh samples per replay).  'auto' (default): graph for the launch-bound Det "
                          "step (C4: 0.2 ms of kernels behind ~25 launches), eager for the GPU-bound C2 / C5")
-    args = ap.parse_args()
+    ap.add_argument('--route', choices=['direct', 'c10d'], default='direct',
+                    help="C4's collective: 'direct' = RCCL's ncclAllGather called on the step's own stream (sharding.RcclComm), "
+                         "'c10d' = torch.distributed.all_gather_into_tensor -- to bisect a failing direct route from the command line")
+    args = ap.parse_args(argv)
     cfg = dict(CONFIGS[args.config])
     for k in ('objects', 'points', 'samples', 'amis_iters', 'lm_iters'):
         if getattr(args, k) is not None:
@@ -226,15 +277,23 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    on_gpu = device is None
+    if on_gpu:
+        assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback)'
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    else:
+        dev = torch.device(device)
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     dist = None
     if world > 1 or 'RANK' in os.environ:          # under torchrun also with one rank: the RCCL path is then exercised
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', device_id=dev)
+        if on_gpu:
+            dist.init_process_group(backend, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1 and args.gpus == 1, f'WORLD_SIZE={world} but --gpus {args.gpus}'
 
     from epropnp import functional as F
@@ -246,6 +305,7 @@ def main():
     from epropnp.losses import MonteCarloPoseLoss, monte_carlo_pose_loss
 
     N, S, K, L, dof = cfg['points'], cfg['samples'], cfg['amis_iters'], cfg['lm_iters'], cfg['dof']
+    caller = CALLER.get(args.config)
     strong = cfg['scaling'] == 'strong'
     if strong:      # ONE batch (the same on every rank), split contiguously over the ranks
         total = cfg['objects']
@@ -256,10 +316,24 @@ def main():
     else:           # every rank owns its own shard of objects
         B = cfg['objects']
         total = B * world
-        prob = synth_problem(B, N, dev, seed=1000 + rank, dof=dof)
+        prob = synth_problem(B, N, dev, seed=1000 + rank, dof=dof, cam=caller['cam'] if caller else 'pinhole800')
     x3d, x2d, w2d = (prob[k].requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
-    cost_fun = AdaptiveHuberPnPCost(relative_delta=0.5)
-    if args.config == 'C4':
+    cost_fun = AdaptiveHuberPnPCost(relative_delta=caller['relative_delta'] if caller else 0.5)
+    pose_target, with_plus = prob['pose_init'], False
+    if caller:
+        lb = ub = None
+        if caller['crop_bounds']:       # lib/train.py:168-173: the crop box -/+ 30 output pixels, per object
+            lo_, hi_ = x2d.detach().amin(1), x2d.detach().amax(1)
+            unit = (hi_ - lo_).amax(-1, keepdim=True) / 64.0
+            lb, ub = (lo_ - 30 * unit).contiguous(), (hi_ + 30 * unit).contiguous()
+        camera = PerspectiveCamera(cam_mats=prob['cam_mats'], z_min=caller['z_min'], lb=lb, ub=ub)
+        init = None
+        if caller['rslm']:
+            init = RSLMSolver(dof=6, num_points=caller['rslm'][0], num_proposals=caller['rslm'][1], num_iter=caller['rslm'][2])
+            pose_target = prob['pose_gt']                   # pose_init = the ground truth, force_init_solve=True
+        layer = EProPnP6DoF(mc_samples=S, num_iter=K, solver=LMSolver(dof=6, num_iter=L, init_solver=init), seed=1 + rank)
+        loss_mod, force_init, with_plus = None, init is not None, caller['plus']
+    elif args.config == 'C4':
         camera = PerspectiveCamera(z_min=0.1, allowed_border=200)
         camera.set_param(prob['cam_mats'], img_shape=torch.tensor([[480., 640.]], device=dev).expand(B, 2))
         init = RSLMSolver(dof=4, num_points=16, num_proposals=64, num_iter=3)
@@ -279,7 +353,7 @@ def main():
     coll_events = []
     gathered, layer_last_pose = {}, {}
     # C4: the step's ONE collective (pose outputs + the loss's norm_factor scalar in one payload, sharding.ObjectExchange)
-    exchange = sharding.ObjectExchange(total, force_collective=dist is not None) if strong else None
+    exchange = sharding.ObjectExchange(total, force_collective=dist is not None, direct=args.route == 'direct') if strong else None
     nf_scale = 1.0 / max(2 * B, 1)
 
     def norm_factor_input():
@@ -293,15 +367,22 @@ def main():
         for t in (x3d, x2d, w2d):
             t.grad = None
         cost_fun.set_param(x2d.detach(), w2d)
-        pose_opt, _, _, _, logw, cost_init = layer.monte_carlo_forward(x3d, x2d, w2d, camera, cost_fun,
-                                                                      pose_init=prob['pose_init'], force_init_solve=force_init)
+        pose_opt, _, plus, _, logw, cost_init = layer.monte_carlo_forward(
+            x3d, x2d, w2d, camera, cost_fun, pose_init=pose_target, force_init_solve=force_init,
+            **({'with_pose_opt_plus': True} if with_plus else {}))
         if loss_mod is None:
             loss = monte_carlo_pose_loss(logw, cost_init).mean()       # Monte-Carlo pose (KL) loss, NaN -> 0
+            if with_plus:       # derivative regularisation of the callers (lib/train.py:184-193, notebook cell 9)
+                dist_t = (plus[:, :3] - pose_target[:, :3]).norm(dim=-1)
+                loss_t = torch.where(dist_t < 0.05, 0.5 * dist_t.square() / 0.05, dist_t - 0.025).mean()
+                dot = (plus[:, 3:] * pose_target[:, 3:]).sum(-1)
+                loss = loss + 0.1 * loss_t + 0.1 * ((1 - dot.square()) * 2).mean()
             loss.backward()
             return loss
         # Det step.  pose_opt is final here: its all-gather (with the rank's norm_factor input in the same payload) is issued
         # now, in stream order (sharding.ObjectExchange: why not a side stream); the loss takes the world mean out of the
         # exchange, the gathered poses are picked up after backward().
+        timed = timed and on_gpu
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -317,10 +398,10 @@ def main():
         return loss
 
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     # Device spin-up, before the W warm-up steps and outside everything that is timed.  In a fresh process the first
     # ~17 steps of this workload run slow on the MI355X and converge geometrically to the steady state (2.08, 2.02, 1.97,
@@ -328,18 +409,20 @@ def main():
     # does not change that, so it is not the idle -> busy clock ramp but the device settling on this instruction mix.
     # With W = 5 that transient sat inside the timed region (+3 % on a 20-step run).  SPINUP_STEPS untimed steps of the
     # workload itself take it out whatever W the caller picks; the JSON line reports them as `device_spinup_steps`.
-    for _ in range(SPINUP_STEPS):
+    for _ in range(SPINUP_STEPS if on_gpu else 0):
         step()
     for _ in range(args.warmup):
         step()
-    launch = args.launch if args.launch != 'auto' else ('graph' if args.config == 'C4' else 'eager')
+    launch = args.launch if args.launch != 'auto' else ('graph' if args.config in LAUNCH_BOUND else 'eager')
+    if not on_gpu:
+        launch = 'eager'
     launch_note = None
     # Per-kernel stage times: HIP events around every kernel stage inside the library.  In the GPU-bound configurations
     # they sit in the timed region itself (they cost nothing there: 1.76 ms per C2 step with or without); in the
     # launch-bound Det step their ~20 event records per step would slow the host-bound eager step by 40 % and cannot sit in a
     # graph at all, so there the stage times come from `prof_steps` eager steps just before the timed region.
-    prof_in_region = launch == 'eager' and args.config != 'C4'
-    prof_steps = args.steps if prof_in_region else 10
+    prof_in_region = launch == 'eager' and args.config not in LAUNCH_BOUND
+    prof_steps = args.steps if prof_in_region else (10 if on_gpu else 1)
     if not prof_in_region:
         fence()
         _hip.profile(enable=True, reset=True)
@@ -371,7 +454,7 @@ def main():
         except Exception as e:          # a capture that is refused falls back to eager launches, and the line says so
             graph, launch = None, 'eager'
             launch_note = 'hipGraph capture failed, eager launches timed instead: ' + repr(e)[:200]
-            torch.cuda.synchronize()
+            sync()
     run = graph.replay if graph is not None else (lambda: held.__setitem__('loss', step(timed=prof_in_region)))
     for _ in range(3 if graph is not None else 0):
         run()
@@ -398,12 +481,12 @@ def main():
         # of ones, and every rank's device index / step time gathered over RCCL
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
-        mine = torch.tensor([float(rank), float(torch.cuda.current_device()), my_ms], device=dev, dtype=torch.float64)
+        mine = torch.tensor([float(rank), float(torch.cuda.current_device() if on_gpu else rank), my_ms], device=dev, dtype=torch.float64)
         allr = torch.empty(world * 3, device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(allr, mine)
         allr = allr.view(world, 3).cpu()
         ranks.update(process_group=dist.get_backend(), rccl_world_size=dist.get_world_size(), all_reduce_of_ones=float(ones),
-                     devices=[int(v) for v in allr[:, 1]], device_name=torch.cuda.get_device_name(dev),
+                     devices=[int(v) for v in allr[:, 1]], device_name=torch.cuda.get_device_name(dev) if on_gpu else 'cpu (test hook)',
                      ms_per_step_per_rank=[round(float(v), 4) for v in allr[:, 2]],
                      ms_per_step_min=round(float(allr[:, 2].min()), 4), ms_per_step_max=round(float(allr[:, 2].max()), 4))
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -416,6 +499,21 @@ def main():
         lo_, hi_ = sharding.shard_range(total, rank, world)
         own = layer_last_pose['pose_opt']
         assert torch.equal(gathered['pose_opt'][lo_:hi_], own), 'gathered poses differ from the local ones'
+        gathered_bytes = int(gathered['pose_opt'].numel() * 4 + 4)      # (the A/B below re-runs the step WITHOUT the exchange)
+
+    eager_ms = None
+    if graph is not None:     # what a caller who just swaps the package gets: the same K steps launched eagerly, same run
+        for _ in range(max(args.warmup, 3)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        te = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        eager_ms = float(te) / args.steps * 1e3
 
     ms_without = None
     if strong:          # the collective's cost on the critical path, measured: the same steps without the exchange
@@ -439,7 +537,18 @@ def main():
         ms_without = float(tw) / args.steps * 1e3
         exchange.disabled = False
 
-    if rank == 0:
+    if rank == 0 and not on_gpu:      # test hook: the harness logic ran (sharding, exchange, loss, timing protocol); no GPU legs
+        ms = elapsed / args.steps * 1e3
+        out = {'metric': f'PnP instances/sec (fwd+bwd, N={N} pts, {S} samples)', 'value': round(total * args.steps / elapsed, 1),
+               'unit': 'instances/s', 'n_gpus': world, 'ranks': ranks, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(ms, 4), 'scaling': cfg['scaling'], 'device': str(dev), 'loss': round(loss_val, 5),
+               'config': {'name': args.config, 'objects_per_gpu': B, 'objects_total': total}}
+        if strong:
+            out['collective'] = {'route': exchange.route, 'ms_per_step_without_exchange': round(ms_without, 4),
+                                 'bytes_per_rank': gathered_bytes,
+                                 'gathered_equals_local_bitwise': True, 'replayed_step_check': replay_check}
+        print(json.dumps(out), flush=True)
+    if rank == 0 and on_gpu:
         ms = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
         stage_ms = {n: _hip.profile_read(n) for n in ('evaluate_cost', 'rslm_solve', 'lm_solve', 'amis_forward', 'amis_backward',
@@ -461,7 +570,29 @@ def main():
         ne_mean_ms, ne_median_ms, ne_sets = single_sweep(F, mk, prob['pose_init'], ne_bytes)
         ne_gbs = ne_bytes / (ne_mean_ms * 1e-3) / 1e9
         ne_traffic, ne_src = measured_traffic('normal_equations_kernel', shape_key) if shape_key else (None, None)
-        names = {'C2': 'C2 batched synthetic', 'C5': 'C5 stress (one shard per GPU)', 'C4': 'C4 EPro-PnP-Det nuScenes shape'}
+        names = {'C2': 'C2 batched synthetic', 'C5': 'C5 stress (one shard per GPU)', 'C4': 'C4 EPro-PnP-Det nuScenes shape',
+                 'C1': 'C1 demo/fit_identity.ipynb plumbing case', 'C3': 'C3 EPro-PnP-6DoF LineMOD shape, dense 64x64 crops',
+                 'C3-train': 'C3 EPro-PnP-6DoF LineMOD training call (512 sub-sampled correspondences)'}
+        ic_cold = ne_sets * ne_bytes >= 2 * IC_BYTES
+        # roofline.large (default C2 line only): the same kernel on the C5-shard sweep, 470 MB per launch -- IC-cold by
+        # construction and long enough (~0.1 ms) that launch ramp and tail do not set the figure
+        large = None
+        if args.config == 'C2' and default_shape and world == 1:
+            LB, LN = LARGE_SWEEP
+            lp = synth_problem(LB, LN, dev, seed=77, dof=6)
+            l_bytes = LB * (28.0 * LN + 4.0 * (7 + 9 + 1 + 4) + 4.0 * (21 + 6 + 1))
+            lcam = PerspectiveCamera(cam_mats=lp['cam_mats'], z_min=0.1)
+            lcf = AdaptiveHuberPnPCost(relative_delta=0.5)
+            lcf.set_param(lp['x2d'], lp['w2d'])
+            lmk = lambda: F.PnPProblem(lp['x3d'].clone(), lp['x2d'].clone(), lp['w2d'].clone(), lcam, lcf, 6)
+            l_mean, l_med, l_sets = single_sweep(F, lmk, lp['pose_init'], l_bytes, windows=6)
+            l_traffic, l_src = measured_traffic('normal_equations_kernel', f'C5:B{LB}:N{LN}:S1024:K4:L3')
+            large = {'workload': f'{LB} objects x N={LN} points (the C5 shard), one Jacobian sweep', 'achieved': round(l_bytes / (l_mean * 1e-3) / 1e9, 1),
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(l_bytes / (l_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     'algorithmic_bytes_per_launch': l_bytes, 'launch_ms': round(l_mean, 5), 'launch_ms_median': round(l_med, 5),
+                     'cache_state': f'IC-cold: {l_sets} copies x {l_bytes / 2 ** 20:.0f} MiB', 'traffic': l_traffic,
+                     'traffic_source': l_src}
+            del lp, lmk
         par = (f'one batch of {total} objects split x{world} ({B} on rank 0), ONE all_gather_into_tensor (pose outputs + '
                f'norm_factor) inside the step') if strong else f'objects sharded x{world}, no data-path collective'
         out = {
@@ -474,7 +605,10 @@ def main():
             'kernel_ms_source': 'HIP events inside the library over the timed region' if prof_in_region else f'HIP events inside the library over {prof_steps} eager steps before the timed region',
             'config': {'workload': f'{names[args.config]}: {B} objects/GPU x N={N} points, S={S} MC samples, '
                                    f'K={K} AMIS iters, L={L} LM iters, EProPnP{dof}DoF fwd+bwd'
-                                   + (', RSLM(16,64,3) init, normalize=True, Det loss' if args.config == 'C4' else ''),
+                                   + (', RSLM(16,64,3) init, normalize=True, Det loss' if args.config == 'C4' else '')
+                                   + ((f", RSLM{caller['rslm']} init" if caller['rslm'] else '') + (', per-object crop bounds' if caller['crop_bounds'] else '')
+                                      + f", z_min {caller['z_min']}, relative_delta {caller['relative_delta']}"
+                                      + (', with_pose_opt_plus + derivative regularisation' if caller['plus'] else '') if caller else ''),
                        'name': args.config, 'objects_per_gpu': B, 'objects_total': total, 'num_points': N, 'mc_samples': S,
                        'amis_iters': K, 'lm_iters': L, 'dof': dof, 'parallelism': par},
             # the Jacobian sweep against the HBM peak.  Headline = ONE physical sweep with the Infinity Cache out of the
@@ -484,8 +618,11 @@ def main():
                                    'correspondences)', 'bound': 'hbm',
                          'achieved': round(ne_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(ne_gbs / HBM_PEAK_GBS, 4),
-                         'cache_state': f'IC-cold: launches rotate over {ne_sets} distinct copies of the inputs '
-                                        f'({ne_sets * ne_bytes / 2 ** 20:.0f} MiB > 2 x 256 MiB Infinity Cache)',
+                         'cache_state': (f'IC-cold: launches rotate over {ne_sets} distinct copies of the inputs '
+                                         f'({ne_sets * ne_bytes / 2 ** 20:.0f} MiB > 2 x 256 MiB Infinity Cache)') if ic_cold else
+                                        (f'IC-WARM: {ne_sets} copies x {ne_bytes / 2 ** 20:.2f} MiB fit the 256 MiB Infinity Cache; '
+                                         f'this launch-bound shape says nothing about HBM'),
+                         'large': large,
                          # HBM bytes per launch from rocprofv3 PMC (separate passes; gfx950: 2 x FETCH_SIZE + WRITE_SIZE,
                          # MI355X_MICROARCH.md), read from the committed profile of this exact shape -- or null
                          'traffic': ne_traffic, 'traffic_source': ne_src,
@@ -508,6 +645,9 @@ def main():
             'kernel_ms': {n: round(v[0] * (v[1] / prof_steps), 4) for n, v in stage_ms.items() if v[1]},   # per step
             'loss': round(loss_val, 5),
         }
+        if eager_ms is not None:
+            out['eager'] = {'ms_per_step': round(eager_ms, 4), 'value': round(total / (eager_ms * 1e-3), 1), 'unit': 'instances/s',
+                            'note': 'the same steps launched eagerly in this run (host-bound: ~20 launches per step)'}
         if strong:
             c_ms = sum(a.elapsed_time(b) for a, b in coll_events) / max(len(coll_events), 1)
             out['collective'] = {'op': 'ONE all_gather_into_tensor per step: pose_opt chunk + the norm_factor scalar of the '
@@ -518,10 +658,10 @@ def main():
                                  # A/B in this run: the same K steps with the exchange switched off (every rank, below)
                                  'ms_per_step_without_exchange': round(ms_without, 4),
                                  'share_of_step': round(max(0.0, ms - ms_without) / ms, 4),
-                                 'bytes_per_rank': int(gathered['pose_opt'].numel() * 4 + 4),
+                                 'bytes_per_rank': gathered_bytes,
                                  'gathered_equals_local_bitwise': True,
                                  'replayed_step_check': replay_check}
-        if world == 1 and not args.no_cpu_baseline and dof == 6:
+        if world == 1 and not args.no_cpu_baseline and args.config in ('C2', 'C5'):
             out['cpu_baseline'] = cpu_baseline(N, S, K, L, args.cpu_sample if args.config == 'C2' else 8)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
         if world == 1 and not args.no_hipgraph and args.config == 'C2' and default_shape:
@@ -534,10 +674,19 @@ def main():
         except OSError:
             pass
         print(json.dumps(out), flush=True)
+    comms_closed = None
+    if exchange is not None:
+        exchange.close()                        # ncclCommDestroy of the direct route's communicator, on every rank ...
+    sharding.RcclComm.close_all()
+    comms_closed = len(sharding.RcclComm._live) == 0
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.destroy_process_group()            # ... before the torch group goes
+    if os.environ.get('BENCH_REPORT_TEARDOWN') == '1' and rank == 0:
+        sys.stderr.write(json.dumps({'teardown': {'rccl_comms_closed': comms_closed,
+                                                  'process_group_destroyed': dist is None or not dist.is_initialized()}}) + '\n')
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -73,6 +73,12 @@ class RcclComm:
         assert dist.is_initialized(), 'RcclComm needs an initialised torch.distributed group'
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self._comm = None
+        dev = torch.device('cuda', torch.cuda.current_device())
+        # Every step that can fail on SOME ranks only (library not found, bootstrap refused) is followed by an agreement
+        # over the torch group -- all_reduce(MIN) of a success flag -- so that either every rank ends up with the
+        # communicator or every rank raises: a rank that fell back to c10d on its own while the others sit in
+        # ncclCommInitRank / ncclAllGather would hang the job.
         lib = None
         for cand in (os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'), 'librccl.so', 'librccl.so.1'):
             try:
@@ -80,8 +86,7 @@ class RcclComm:
                 break
             except OSError:
                 continue
-        if lib is None:
-            raise RuntimeError('librccl.so not found (looked next to torch and on the loader path)')
+        self._agree(lib is not None, dev, 'librccl.so not found (looked next to torch and on the loader path)')
         self._lib = lib
 
         class UniqueId(ctypes.Structure):
@@ -93,16 +98,32 @@ class RcclComm:
                                       ctypes.c_void_p]
         lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         uid = UniqueId()
-        if self.rank == 0:
-            self._check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
-        dev = torch.device('cuda', torch.cuda.current_device())
+        rc = lib.ncclGetUniqueId(ctypes.byref(uid)) if self.rank == 0 else 0
+        self._agree(rc == 0, dev, 'ncclGetUniqueId failed on rank 0')
         box = torch.tensor(list(uid.internal), dtype=torch.uint8, device=dev)       # zeros on the other ranks
         dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ctypes.memmove(ctypes.byref(uid), bytes(box.cpu().tolist()), 128)
         comm = ctypes.c_void_p()
-        self._check(lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
-        self._comm = comm
+        rc = lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank)      # collective over the group
+        if rc == 0:
+            self._comm = comm
+        try:
+            self._agree(rc == 0, dev, 'ncclCommInitRank failed'
+                        + ('' if rc == 0 else ': ' + lib.ncclGetErrorString(rc).decode()))
+        except RuntimeError:
+            self.close()
+            raise
         self.device = dev
+        RcclComm._live.add(self)
+
+    _live = set()       # communicators not yet destroyed (ObjectExchange.close / close_all before destroy_process_group)
+
+    def _agree(self, ok, dev, what):
+        """Collective: raise on EVERY rank if `ok` is false on ANY rank."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag) == 0:
+            raise RuntimeError(what if not ok else f'direct RCCL communicator refused on another rank ({what.split(":")[0]})')
 
     def _check(self, rc, what):
         if rc != 0:
@@ -117,9 +138,25 @@ class RcclComm:
                                             stream), 'ncclAllGather')
 
     def close(self):
+        """ncclCommDestroy (idempotent).  Call on every rank before dist.destroy_process_group(): a communicator that is
+        still alive at interpreter exit is torn down by RCCL's own atexit handlers in an order that can hang or warn with
+        several ranks."""
         if getattr(self, '_comm', None) is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()            # no collective of ours may still be in flight
             self._lib.ncclCommDestroy(self._comm)
             self._comm = None
+        RcclComm._live.discard(self)
+
+    @property
+    def closed(self):
+        return self._comm is None
+
+    @classmethod
+    def close_all(cls):
+        """Destroy every live communicator of this process (bench.py / training scripts: before destroy_process_group)."""
+        for c in list(cls._live):
+            c.close()
 
 
 class ObjectExchange:
@@ -141,6 +178,10 @@ class ObjectExchange:
     On device tensors the collective is RCCL's ncclAllGather called directly on the current stream (`RcclComm`: +4 us per
     eager step against +11 us through c10d in the same probe, and no internal stream); `direct=False`, CPU tensors (gloo)
     or a failed communicator set-up take `torch.distributed.all_gather_into_tensor` (`self.route` says which ran).
+    The route is agreed on collectively (RcclComm's set-up raises on every rank or on none), so all ranks issue the same
+    collective.  `objects()` / `world_mean()` return VIEWS of the reused receive buffer: valid until the next `start()`
+    (clone them to keep them longer).  `close()` destroys the direct communicator; call it (or `RcclComm.close_all()`)
+    before `dist.destroy_process_group()`.
     Without a process group (or with one rank and `force_collective=False`) no collective is issued."""
 
     def __init__(self, num_obj, group=None, force_collective=False, direct=True):
@@ -181,8 +222,8 @@ class ObjectExchange:
         if self.direct and local.is_cuda and self._comm is None:
             try:
                 self._comm = RcclComm(self.group)
-            except Exception as e:         # no librccl / bootstrap refused: c10d's route still works, say so once
-                import warnings
+            except Exception as e:         # no librccl / bootstrap refused ON ANY RANK (RcclComm agrees collectively, so
+                import warnings            # every rank lands here together): c10d's route still works, say so once
                 warnings.warn(f'ObjectExchange: direct RCCL communicator unavailable ({e}); using torch.distributed')
                 self.direct = False
         if self.direct and local.is_cuda:
@@ -193,8 +234,16 @@ class ObjectExchange:
             self.route = f'torch.distributed.all_gather_into_tensor ({dist.get_backend(self.group)})'
         return self
 
+    def close(self):
+        """Destroy the direct RCCL communicator, if one was set up (idempotent; the exchange falls back to creating a new one
+        on the next start())."""
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+
     def world_mean(self):
-        """Mean over ranks of the scalars handed to start(): shape (n_scalars,), or () for a single scalar."""
+        """Mean over ranks of the scalars handed to start(): shape (n_scalars,), or () for a single scalar (a view of the
+        receive buffer: valid until the next start())."""
         assert self._scal is not None, 'start() was called without scalars'
         if not self._active():
             return self._scal.reshape(()) if self._n_scal == 1 else self._scal
@@ -202,7 +251,8 @@ class ObjectExchange:
         return m.reshape(()) if self._n_scal == 1 else m
 
     def objects(self):
-        """The gathered (num_obj, ...) per-object outputs, ranks in order, padding trimmed."""
+        """The gathered (num_obj, ...) per-object outputs, ranks in order, padding trimmed (with an even split a view of the
+        receive buffer: valid until the next start())."""
         if not self._active():
             return self._local
         world = self._world()

@@ -279,6 +279,46 @@ def test_backward_split_over_workgroups(backend, dof, bounds, N, S):
         F.amis_backward(*args, nsplit=(N + 63) // 64 + 1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,nsplit', [(2048, 8), (2048, 16), (4096, 8), (4096, 16)])
+def test_backward_split_dense_crops_matches_autograd_of_oracle(N, nsplit):
+    """The backward's split over 8 / 16 workgroups at the dense LineMOD point counts (32 crops x 64 x 64 correspondences take
+    nsplit = 16 in the layer, functional.backward_split): arbitrary upstream gradients at fixed samples against autograd
+    through the oracle's evaluate (what the reference's autograd replays), with per-object tensor bounds and z_min 0.01 as
+    lib/train.py:168-173 sets them, and bit-identical per-point gradients against the one-workgroup kernel."""
+    import install as emu
+    from epropnp import functional as F
+    emu.uninstall()
+    dev = torch.device('cuda:0')
+    B, S, dof = 4, 96, 6
+    prob = orc.make_problem(B, N, dof, seed=41, relative_delta=0.1)
+    lo, hi = prob['x2d'].amin(1), prob['x2d'].amax(1)
+    unit = (hi - lo).amax(-1, keepdim=True) / 64.0
+    prob['lb'], prob['ub'], prob['z_min'] = (lo - 30 * unit).contiguous(), (hi + 30 * unit).contiguous(), 0.01
+    g = torch.Generator().manual_seed(7)
+    poses = prob['pose_gt'].unsqueeze(0).repeat(S, 1, 1)
+    poses[..., :3] += 0.2 * torch.randn(S, B, 3, generator=g)
+    q = poses[..., 3:] + 0.1 * torch.randn(S, B, 4, generator=g)
+    poses[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+    poses[0, 0, 2] = -1.0                     # behind the camera: depth clamp active for every point of that sample
+    g_logw, g_init = torch.randn(S, B, generator=g), torch.randn(B, generator=g)
+    x3d, x2d, w2d, delta = (prob[k].double().clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d', 'delta'))
+    ocam = orc.Cam(prob['cam_mats'].double(), 0.01, prob['lb'].double(), prob['ub'].double())
+    c_s = orc.evaluate(x3d, x2d, w2d, poses.double(), ocam, delta, want_cost=True)[1]
+    c_i = orc.evaluate(x3d, x2d, w2d, prob['pose_init'].double(), ocam, delta, want_cost=True)[1]
+    ((-c_s) * g_logw.double()).sum().add((c_i * g_init.double()).sum()).backward()
+    p, cam, cf = make_layer_objects(prob, dev)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    args = (hp, poses.to(dev), g_logw.to(dev), p['pose_init'], g_init.to(dev))
+    many = F.amis_backward(*args, nsplit=nsplit)
+    for mine, ref in zip(many, (x3d.grad, x2d.grad, w2d.grad, delta.grad)):
+        assert _rel(mine.cpu().double(), ref) <= 2e-4, (N, nsplit, _rel(mine.cpu().double(), ref))
+    one = F.amis_backward(*args, nsplit=1)
+    for a, b in zip(many[:3], one[:3]):
+        assert torch.equal(a, b)
+    assert _rel(many[3].cpu(), one[3].cpu()) <= 1e-5
+
+
 def test_philox_sampler_statistics(backend):
     """Production mode (on-device Philox): loss agrees with the injected-noise oracle within Monte-Carlo error,
     and two calls draw different samples."""

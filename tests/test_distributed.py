@@ -90,6 +90,48 @@ def test_shard_range_covers_everything():
             assert max(e[1] - e[0] for e in edges) - min(e[1] - e[0] for e in edges) <= 1
 
 
+def _bench_worker(rank, world, port, ret):
+    """bench.py's own main() as one of two gloo ranks: the emulation build is installed HERE, from the outside; bench.py gets
+    a CPU device and the gloo backend through its test hook and skips only what needs the GPU (hipGraph, HIP events, roofline)."""
+    import contextlib
+    import io
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import conftest
+    import install as emu
+    emu.install(conftest._emu_lib())
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.main(['--gpus', str(world), '--config', 'C4', '--objects', '9', '--points', '24', '--samples', '16', '--amis-iters', '2',
+                         '--lm-iters', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-hipgraph'], device='cpu', backend='gloo')
+    ret[rank] = (rc, buf.getvalue(), dist.is_initialized())
+
+
+def test_bench_strong_scaling_step_two_gloo_ranks():
+    """bench.py --config C4 (ONE batch split over the ranks, ONE collective per step, detection loss with the world-mean
+    norm_factor) with TWO real ranks: 9 objects -> 5 + 4 (uneven tail), the exchange inside the timed region, the per-rank
+    evidence, `gathered == local` bit for bit, the replayed-step check, and a clean teardown (process group destroyed)."""
+    import json
+    import conftest
+    conftest._emu_lib()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bench_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        ret = dict(ret)
+    assert ret[0][0] == 0 and ret[1][0] == 0 and not ret[0][2] and not ret[1][2]        # both exited clean, groups destroyed
+    assert ret[1][1] == ''                                                              # only rank 0 prints
+    line = json.loads([ln for ln in ret[0][1].splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['value'] > 0
+    assert line['config'] == {'name': 'C4', 'objects_per_gpu': 5, 'objects_total': 9}
+    rk = line['ranks']
+    assert rk['process_group'] == 'gloo' and rk['rccl_world_size'] == 2 and rk['all_reduce_of_ones'] == 2.0
+    assert len(rk['ms_per_step_per_rank']) == 2 and line['ms_per_step'] >= rk['ms_per_step_max'] - 1e-3      # max over ranks
+    c = line['collective']
+    assert c['bytes_per_rank'] == 9 * 4 * 4 + 4 and c['gathered_equals_local_bitwise'] is True and 'gloo' in c['route']
+    chk = c['replayed_step_check']
+    assert abs(chk['norm_factor_input_last_step'] - chk['evaluated_eagerly']) <= 1e-5 * abs(chk['evaluated_eagerly'])
+
+
 def _nccl_worker(rank, world, port, ret):
     """Object sharding over RCCL on real GPUs: each rank solves its contiguous shard of ONE batch, pose outputs are
     all-gathered, the result equals the single-GPU run (objects are independent; the gather only moves data)."""
@@ -136,6 +178,56 @@ def test_object_sharding_all_gather_nccl():
         ret = mgr.dict()
         mp.spawn(_nccl_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert dict(ret) == {r: True for r in range(world)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['direct', 'c10d'])
+def test_bench_det_route_switch_and_clean_teardown(route):
+    """`bench.py --config C4 --route direct|c10d` under the self-launcher: the line names the route that ran, and the
+    teardown record (BENCH_REPORT_TEARDOWN=1, stderr) shows every direct RCCL communicator destroyed before the process
+    group -- an undestroyed communicator is an exit-time hang risk that only shows with several ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', BENCH_SELF_LAUNCH='1', BENCH_REPORT_TEARDOWN='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '3', '--warmup', '1', '--config', 'C4',
+           '--route', route, '--no-cpu-baseline', '--no-hipgraph']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    want = 'rccl ncclAllGather' if route == 'direct' else 'torch.distributed.all_gather_into_tensor'
+    assert line['collective']['route'].startswith(want), line['collective']['route']
+    td = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"teardown"')][-1])['teardown']
+    assert td == {'rccl_comms_closed': True, 'process_group_destroyed': True}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('config', ['C1', 'C3', 'C3-train'])
+def test_bench_reference_caller_configs(config):
+    """BASELINE.json configs[0] / configs[2] are reachable from the driver's command: `python bench.py --config C1 | C3 |
+    C3-train` (hipGraph replay by default, the eagerly launched step of the same run beside it)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', config, '--steps', '10', '--warmup', '2'],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['config']['name'] == config and line['value'] > 0 and line['n_gpus'] == 1 and line['launch_note'] is None
+    assert line['launch'].startswith('hipGraph') and line['eager']['ms_per_step'] > 0
+    assert line['kernel_ms']['amis_forward'] > 0 and line['kernel_ms']['amis_backward'] > 0
+    objects = {'C1': 1, 'C3': 32, 'C3-train': 32}[config]
+    assert line['config']['objects_per_gpu'] == objects and abs(line['value'] - objects / (line['ms_per_step'] * 1e-3)) < 0.01 * line['value']
+    if config != 'C3':
+        assert line['kernel_ms']['rslm_solve'] > 0
 
 
 @pytest.mark.gpu
