@@ -16,6 +16,24 @@ typedef PNP_FIT_T fit_t;
 #define PNP_SWEEP_PIPELINE 0
 #endif
 
+// Issue priority of the calling wave while it runs a SERIAL phase of the sampler (the single-wave proposal refit: three waves
+// of the workgroup are parked at a barrier until it is through, while the other workgroups of the CU sweep).  VALU issue on a
+// SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md "two waves per SIMD"): at equal priority the refitting wave
+// gets the slots the sweeping waves leave, and its ~2000 dependent instructions take ~12 us; raised, they take what a lone
+// wave needs and the parked waves return to the sweep sooner.  PNP_FWD_PRIO: the raised level (0 = off; tuning variants).
+#ifndef PNP_FWD_PRIO
+#define PNP_FWD_PRIO 0
+#endif
+__device__ __forceinline__ void serial_phase_priority(bool raised) {
+#ifndef EPROPNP_EMU
+  if (PNP_FWD_PRIO > 0) {
+    if (raised) __builtin_amdgcn_s_setprio(PNP_FWD_PRIO); else __builtin_amdgcn_s_setprio(0);
+  }
+#else
+  (void)raised;
+#endif
+}
+
 // min(x, 1) for x >= 0 through the clamp output modifier of a multiply by an opaque 1.0 (v_mul_f32 ... clamp, a full-rate
 // instruction; v_min_f32 issues at half that rate on gfx950, tools/ubench)
 __device__ __forceinline__ float sat_mul(float x, float one_v) {
@@ -93,6 +111,7 @@ struct AmisParams {
   unsigned long long seed, offset;
   const unsigned long long* offset_dev;   // optional device-side addend to `offset` (graph replay)
   int ablate;          // tuning builds only (-DPNP_TUNING): bit0 skip sweep, bit1 skip proposal refit, bit2 skip densities
+  unsigned split_timeout;   // split over workgroups: shader cycles a part waits for a sibling's partial costs (wave_ops.h)
 };
 
 // The fp64 proposal fits run on one lane a handful of times per object; keeping them out of line stops their
@@ -618,12 +637,14 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     return;
   }
   const int T = 64, tid = lane_id();
+  serial_phase_priority(true);        // the one wave the other three of the workgroup wait for
 #ifdef PNP_TUNING_REFIT
   long long refit_t0_ = clock64();
 #endif
 #ifdef PNP_TUNING
   if (a.ablate & 2) {
     for (int i = tid; i < kPropStride; i += T) nrec[i] = rec[i];
+    serial_phase_priority(false);
     __syncthreads();
     return;
   }
@@ -792,6 +813,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       for (int i = 19; i < 37; ++i) nrec[i] = 0.f;
     }
   }
+  serial_phase_priority(false);
   __syncthreads();
 }
 

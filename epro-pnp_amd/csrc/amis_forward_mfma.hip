@@ -116,7 +116,9 @@ struct MfmaShape {
 // (the reference has no such limit).  Same code: the arrays are reached through pointers either way, every hand-over
 // between threads goes through a workgroup barrier, and a workgroup's global accesses share one L1.
 template <int DOF, bool BOUNDS, int NPT, bool SPILL = false, bool SPLIT = false>
-__global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
+// (SPLIT grids are sized for one workgroup per CU: two waves per SIMD -- 256 VGPRs -- leave room for a second such launch and
+// for the part-recomputation path's second copy of the sweep without spilling)
+__global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
                                                                   const float* __restrict__ noise,
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   constexpr bool kRegs = NPT > 0;
   constexpr bool kFold = kRegs && !BOUNDS;
   const int WPs = kRegs ? (G > 1 ? G : W) : 1;      // point slices whose partial costs are summed in amis_weights
-  const int cpart_rows = (kRegs && G > W) ? G : (kRegs ? W : 1);
+  // split: W per-wave rows of the part in the registers + G gathered rows (one per part) + the missing-parts word
+  const int cpart_rows = kRegs ? (SPLIT ? W + G : W) : 1;
   float* ptab = smem;                 // [s16][12]   x | y | z rows of (K R | K t)          (16-B aligned)
   float* pB = ptab + 12 * s16;        // [NC][4]     (X, Y, Z, 1)        (NC = 0 in register mode)
   float* pW = pB + 4 * NC;            // [NC][4]     (wu, wv, -u wu, -v wv)
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   float* mixl = cst + S;              // [S]
   float* lgw = mixl + S;              // [S]
   float* cpart = SPILL ? pW + 4 * NC : lgw + S;                              // [WPs][s16]
-  float* prop = cpart + cpart_rows * s16;    // [K][kPropStride]
+  float* gath = cpart + W * s16;             // [G][s16] (SPLIT) the parts' partial costs of the current iteration
+  float* prop = cpart + cpart_rows * s16 + (SPLIT ? 4 : 0);    // [K][kPropStride]  (SPLIT: + the missing-parts word)
   float* red = prop + K * kPropStride;   // [256]
   float* nzb = (s <= T) ? ptab : red + 256;   // [s][8] base noise drawn ahead; shares the pose table's LDS when one
                                               // sample per lane suffices (amis_draw separates the two uses)
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   const float inv_delta = hs.inv_delta, delta_sq = hs.delta_sq;
 
   AmisCtx cx;
-  cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
+  cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = SPLIT ? gath : cpart; cx.prop = prop; cx.red = red;
   cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s16;
   cx.nzb = (noise == nullptr && W > 1) ? nzb : nullptr;
 
@@ -199,19 +203,22 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
       reinterpret_cast<float4*>(pW)[n] = make_float4(wu, wv, -q.u * wu, -q.v * wv);
     }
   };
-  // register mode: this wave's point tiles q = wv + W * i, lane = (point column, k)
+  // register mode: this wave's point tiles q = wv + W * i of part `pt`, lane = (point column, k)
   float rB[kRegs ? NPT : 1];
   float4 rW[kRegs ? NPT : 1];
-  if (kRegs) {
+  auto load_tiles = [&](int pt) {
 #pragma unroll
     for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
-      const Point q = load_point(p, b, ((part * W + wv) + G * W * i) * 16 + (lane & 15));      // zero weight beyond N
+      const Point q = load_point(p, b, ((pt * W + wv) + G * W * i) * 16 + (lane & 15));      // zero weight beyond N
       const int k4 = lane >> 4;
       rB[i] = (k4 == 0) ? q.X : (k4 == 1) ? q.Y : (k4 == 2) ? q.Z : 1.0f;
       // without a projection clamp the weights are folded into the B operands of the x and y rows (same 5 VGPRs)
       const float wu = q.wu * inv_delta, wv = q.wv * inv_delta;
       rW[i] = kFold ? make_float4(rB[i] * wu, rB[i] * wv, -q.u * wu, -q.v * wv) : make_float4(wu, wv, -q.u * wu, -q.v * wv);
     }
+  };
+  if (kRegs) {
+    load_tiles(part);
   } else if (nchunk == 1) {
     load_chunk(0);
   }
@@ -219,12 +226,40 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
   __syncthreads();
 
   const int g4 = (lane >> 4) * 4, col = lane & 15, kk = lane >> 4;
+  // register mode: every pose tile of the iteration against the point tiles in this wave's registers -> cpart[wv][pose]
+  // (issuing the next pose tile's first MFMAs ahead of the current tile's VALU work, to fill the wait states at the
+  // head of this loop, was measured: 0.655 vs 0.641 ms at C2 -- the hand-off copies cost more than the s_nops)
+  auto sweep_regs = [&]() {
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < (s16 >> 4); ++t) {
+      const float* arow = ptab + 12 * (t * 16 + col) + kk;
+      const float ax = arow[0], ay = arow[4], az = arow[8];
+      f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
+        const floatx4 hx = mfma_16x16x4(ax, kFold ? rW[i].x : rB[i], zero);
+        const floatx4 hy = mfma_16x16x4(ay, kFold ? rW[i].y : rB[i], zero);
+        const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
+        huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, one_v, bd, acc2);
+      }
+      float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
+      if (col == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpart[wv * s16 + t * 16 + g4 + r] = acc[r] * delta_sq;
+      }
+    }
+  };
   PNP_PHASE(0);
   for (int it = 0; it < K; ++it) {
 #ifdef PNP_TUNING
     if (!(a.ablate & 32) || it == 0)      // bit5: the sweep re-uses the first iteration's pose table (what the sweep alone costs)
 #endif
     amis_draw<DOF>(cx, p, a, it, Kc, noise, part == 0 ? pose_samples : nullptr);
+#ifdef PNP_FWD_PRIO_ALL
+    serial_phase_priority(false);
+#endif
     __syncthreads();
     PNP_PHASE(1);
 
@@ -235,28 +270,7 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
     } else
 #endif
     if (kRegs) {
-      // (issuing the next pose tile's first MFMAs ahead of the current tile's VALU work, to fill the wait states at the
-      // head of this loop, was measured: 0.655 vs 0.641 ms at C2 -- the hand-off copies cost more than the s_nops)
-      const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-      for (int t = 0; t < (s16 >> 4); ++t) {
-        const float* arow = ptab + 12 * (t * 16 + col) + kk;
-        const float ax = arow[0], ay = arow[4], az = arow[8];
-        f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-#pragma unroll
-        for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
-          const floatx4 hx = mfma_16x16x4(ax, kFold ? rW[i].x : rB[i], zero);
-          const floatx4 hy = mfma_16x16x4(ay, kFold ? rW[i].y : rB[i], zero);
-          const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
-          huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, one_v, bd, acc2);
-        }
-        float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
-        if (col == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cpart[wv * s16 + t * 16 + g4 + r] = acc[r] * delta_sq;
-        }
-      }
+      sweep_regs();
     } else
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * NC;
@@ -300,47 +314,54 @@ __global__ __launch_bounds__(512, (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (N
     }
     __syncthreads();
     if (kRegs && SPLIT) {
-      // ---- exchange of the partial costs between the G parts of this object ----
-      // own row = sum over this workgroup's waves (fixed order) -> global slot [b][it][part][s16]; every thread then polls the
-      // words it gathers from the other parts until they are no longer the fill pattern the launcher wrote into the (per-launch,
-      // per-iteration) slots: the data is its own arrival flag -- one store and one load round trip, no counter, one barrier.
-      // Every access to the exchanged words is a relaxed AGENT-scope atomic (sc1 stores / loads: they bypass the per-CU L1
-      // and the non-coherent L2 lines of other XCDs); no release / acquire fences -- at agent scope those write back and
-      // invalidate the whole L2, 20 us per exchange (profiles/r03_fwd_split_timing.txt).  A cost can never BE the fill
-      // pattern: it is a negative NaN with a full payload, and NaN costs are stored as the canonical quiet NaN.
-      float* slot = xch + (((size_t)b * K + it) * G) * s16;
+      // ---- exchange of the partial costs between the G parts of this object (wave_ops.h: xwg_*) ----
+      // own row = sum over this workgroup's waves (fixed order) -> global slot [b][it][part][s16] and gath[part]; every
+      // thread then polls the words it gathers from the other parts -- one store and one load round trip, no counter, one
+      // barrier.  A part that does not show up within the timeout (not resident: CU mask, partitioned GPU, a foreign kernel
+      // holding CUs) is RECOMPUTED here: its point tiles are loaded into this workgroup's registers and swept with the same
+      // lanes in the same order, i.e. to the same bits, so the outputs never depend on co-residency, only the time does.
+      unsigned* slot = reinterpret_cast<unsigned*>(xch) + (((size_t)b * K + it) * G) * s16;
+      unsigned* missw = reinterpret_cast<unsigned*>(gath + G * s16);
       for (int m = tid; m < s; m += T) {
         float c = cpart[m];
         for (int w = 1; w < W; ++w) c += cpart[w * s16 + m];
-#ifndef EPROPNP_EMU
-        unsigned bits = __float_as_uint(c);
-        bits = (c != c) ? 0x7fc00000u : bits;
-        __hip_atomic_store(reinterpret_cast<unsigned*>(slot) + part * s16 + m, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        slot[part * s16 + m] = c;
-#endif
+        const unsigned bits = xwg_payload(c);
+        xwg_store(slot + part * s16 + m, bits);
+        gath[part * s16 + m] = bits_f32(bits);
       }
-#ifndef EPROPNP_EMU
-      __syncthreads();             // every wave has read the per-wave rows of cpart: they may be overwritten now
-      bool timed_out = false;
+      if (tid == 0) *missw = 0u;
+      __syncthreads();
+      unsigned miss = 0u;
       for (int i = tid; i < G * s; i += T) {
         const int q = i / s, m = i - q * s;
-        const unsigned* src = reinterpret_cast<const unsigned*>(slot) + q * s16 + m;
-        unsigned v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // every part of every object is resident (the launcher sizes the grid for one workgroup per CU), so this wait is
-        // short; the bound turns a scheduling accident into a reported event instead of a hang
-        for (int spins = 0; v == 0xffffffffu && spins < (1 << 22); ++spins) {
-          __builtin_amdgcn_s_sleep(1);
-          v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        timed_out |= (v == 0xffffffffu);
-        cpart[q * s16 + m] = __uint_as_float(v);
+        if (q == part) continue;
+        const unsigned v = xwg_poll(slot + q * s16 + m, a.split_timeout);
+        if (v == kXwgEmpty) miss |= 1u << q; else gath[q * s16 + m] = bits_f32(v);
       }
-      if (timed_out) raise_status(p, EPROPNP_ST_SPLIT_TIMEOUT, b);
+      if (miss) atomicOr(reinterpret_cast<int*>(missw), (int)miss);
       __syncthreads();
-#endif
+      unsigned todo = *missw;                   // the same in every thread
+      if (todo) {
+        if (tid == 0) raise_status(p, EPROPNP_ST_SPLIT_TIMEOUT, b);        // informational: this launch ran slower, not wrong
+        for (int q = 0; q < G; ++q) {
+          if (!((todo >> q) & 1u)) continue;
+          load_tiles(q);
+          sweep_regs();
+          __syncthreads();
+          for (int m = tid; m < s; m += T) {
+            float c = cpart[m];
+            for (int w = 1; w < W; ++w) c += cpart[w * s16 + m];
+            gath[q * s16 + m] = bits_f32(xwg_payload(c));
+          }
+          __syncthreads();
+        }
+        load_tiles(part);
+      }
     }
     PNP_PHASE(2);
+#ifdef PNP_FWD_PRIO_ALL      // tuning variant: every phase between two sweeps (weights, refit, draw) runs prioritised
+    serial_phase_priority(true);
+#endif
 
     amis_weights<DOF>(cx, a, it, WPs);
     __syncthreads();
@@ -407,29 +428,27 @@ static int dispatch_npt(int npt, F&& f) {
 }
 
 // Parts per object for the split over workgroups: the most parts (<= 8) that leave every wave two point tiles and keep the
-// whole grid resident at ONE workgroup per CU -- the parts of an object wait for each other, so they must all be running
-// (256 CUs; each CU holds at least two of these workgroups, which leaves room for a second such launch on another stream).
+// whole grid at ONE workgroup per CU of THIS device (hipDeviceProp.multiProcessorCount: a partitioned MI355X reports its own
+// count) -- the parts of an object exchange partial costs every iteration, which is fast only while they all run at once
+// (each CU holds at least two of these workgroups, which leaves room for a second such launch on another stream).  Results
+// never depend on that: a part that is not there in time is recomputed by its siblings (kernel comment).
 // Two parts do not pay for the exchange.  EPROPNP_FWD_SPLIT=<G> overrides (1: off).
 static int forward_split_parts(int B, int ptiles) {
-  const long wgs = padded_object_grid(B);
+  const long wgs = padded_object_grid(B), cus = device_cu_count();
   int g = 8;
-  while (g > 1 && (wgs * g > 256 || 8 * g > ptiles)) g >>= 1;
+  while (g > 1 && (wgs * g > cus || 8 * g > ptiles)) g >>= 1;
   if (g < 4) g = 1;
-  { int ov[1]; if (env_ints("EPROPNP_FWD_SPLIT", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && wgs * ov[0] <= 512 && 4 * ov[0] <= ptiles) g = ov[0]; }
+  { int ov[1]; if (env_ints("EPROPNP_FWD_SPLIT", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && wgs * ov[0] <= 4096 && 4 * ov[0] <= ptiles) g = ov[0]; }
   return g;
 }
 
 unsigned long long amis_forward_split_bytes(const epropnp_problem* prob, int mc_samples, int num_iter) {
-#ifdef EPROPNP_EMU
-  return 0;
-#else
   if (prob == nullptr || prob->num_obj <= 0 || num_iter <= 0 || mc_samples % num_iter != 0) return 0;
   const int ptiles = (prob->num_pts + 15) / 16;
   const int g = forward_split_parts(prob->num_obj, ptiles);
   if (g <= 1 || (ptiles + 4 * g - 1) / (4 * g) > 8) return 0;      // a part must fit 4 waves x 8 register-resident tiles
   const int s16 = ((mc_samples / num_iter + 15) / 16) * 16;
   return sizeof(float) * (unsigned long long)prob->num_obj * num_iter * g * s16;
-#endif
 }
 
 int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_params* am, const float* pose_opt,
@@ -468,7 +487,6 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   // (Decided on the tiles of a PART: 32 objects x 4096 points do not fit one workgroup's registers -- 0.415 ms streaming the
   // points through LDS on 32 CUs -- but an eighth of them does.)
   int G = 1;
-#ifndef EPROPNP_EMU
   {
     const int g = forward_split_parts(d.B, ptiles);
     const size_t need = sizeof(float) * (size_t)d.B * K * g * sh.s16;
@@ -480,14 +498,14 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       if (o <= 8) { G = g; waves = 4; npt = o; sh.chunk = 0; }
     }
   }
-#endif
   AmisParams k;
   k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
+  k.split_timeout = split_timeout_cycles();
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
   auto lds_bytes = [&](bool spilled) {
     return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (size_t)(PL + 3) * S) +
-                            (size_t)(npt ? (G > waves ? G : waves) : 1) * sh.s16 + (size_t)K * kPropStride + 256 +
+                            (size_t)(npt ? (G > 1 ? waves + G : waves) : 1) * sh.s16 + (G > 1 ? 4 : 0) + (size_t)K * kPropStride + 256 +
                             (s <= 64 * waves ? 0 : 8 * (size_t)s));
   };
   size_t smem = lds_bytes(false);
@@ -503,41 +521,29 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
     smem = lds_bytes(true);
     if (smem > 160 * 1024)
       return fail(EPROPNP_EINVAL, "amis_forward: %d samples per iteration need %zu B of LDS (> 160 KiB)", s, smem);
-#ifndef EPROPNP_EMU
     if (hipMallocAsync((void**)&spill, sizeof(float) * (size_t)(PL + 3) * S * d.B, st) != hipSuccess) {
       (void)hipGetLastError();
       return fail(EPROPNP_ELAUNCH, "amis_forward: mc_samples %d needs a %zu B scratch buffer and hipMallocAsync failed "
                   "(stream capture?)", S, sizeof(float) * (size_t)(PL + 3) * S * d.B);
     }
-#else
-    spill = (float*)malloc(sizeof(float) * (size_t)(PL + 3) * S * d.B);
-#endif
   }
   const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
   if (spill != nullptr) {
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, 0, true>;
-#ifndef EPROPNP_EMU
-      if (smem > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
+      allow_dynamic_lds((const void*)kern, smem);
       PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals, spill, 1,
                  (float*)nullptr);
       return 0;
     });
     const int rc = check_launch("amis_forward_mfma_kernel (sampler state in global scratch)");
-#ifndef EPROPNP_EMU
     (void)hipFreeAsync(spill, st);
-#else
-    free(spill);
-#endif
     return rc;
   }
   float* xch = nullptr;
   char* owned = nullptr;
   dim3 grid_split = grid;
   if (G > 1) {
-#ifndef EPROPNP_EMU
     // exchange buffer [B][K][G][s16], filled with the "not yet written" pattern on the stream: the caller's scratch (no
     // allocation: in a hipGraph an alloc / free node pair costs more than the split saves), or for EPROPNP_FWD_SPLIT
     // experiments a stream-ordered allocation
@@ -556,16 +562,12 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
     }
     xch = (float*)mem;
     grid_split = dim3(padded_object_grid(d.B) * G);
-#endif
   }
   if (G > 1) {
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       auto go = [&](auto NPT) -> int {
         auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value, false, true>;
-#ifndef EPROPNP_EMU
-        if (smem > 64 * 1024)
-          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
+        allow_dynamic_lds((const void*)kern, smem);
         PNP_LAUNCH(kern, grid_split, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
                    (float*)nullptr, G, xch);
         return 0;
@@ -581,19 +583,14 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       return dispatch_npt(npt, [&](auto NPT) -> int {
         auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
-#ifndef EPROPNP_EMU
-        if (smem > 64 * 1024)
-          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
+        allow_dynamic_lds((const void*)kern, smem);
         PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
                    (float*)nullptr, 1, (float*)nullptr);
         return 0;
       });
     });
   }
-#ifndef EPROPNP_EMU
   if (owned != nullptr) (void)hipFreeAsync(owned, st);
-#endif
   return check_launch("amis_forward_mfma_kernel");
 }
 

@@ -369,6 +369,7 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
     WS = ov[0]; WP = ov[1]; ppl = ov[2];
   }
   AmisParams k;
+  k.split_timeout = 0;
   k.S = S; k.K = K; k.WP = WP; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev;
   k.ablate = 0;

@@ -11,6 +11,7 @@ namespace pnp {
 struct LmParams {
   int num_iter, fast_mode;
   float min_diag, max_diag, min_rel_decrease, radius0, radius_max, eps;
+  unsigned split_timeout;   // split over workgroups: shader cycles a part waits for a sibling's partial sums (wave_ops.h)
 };
 
 // acc (upper-tri JtJ | Jtr | cost)  ->  dense symmetric matrix

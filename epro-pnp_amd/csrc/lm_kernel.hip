@@ -30,7 +30,7 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
   static_assert(!SPLIT || (MAXW > 0 && MAXW <= 4 && PPL > 0), "the split serves the register-resident <= 4-wave variants");
   // dynamic LDS: transposed reduction scratch (waves * kSumTStride<NV>) for <= 4 waves, NV * 16 for the DPP fallback
-  // (+ NV floats for the split's exchange)
+  // (+ 32 + 8 NV + 4 floats for the split's exchange)
   PNP_DYN_SMEM(float, scratch);
   constexpr bool kRow = (MAXW == 0);
   const int G = SPLIT ? nsplit : 1;
@@ -90,35 +90,57 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
     } else {
       block_sum<NV>(acc, scratch);
     }
-#ifndef EPROPNP_EMU
     if (SPLIT) {
-      // this part's NV sums -> slot [b][sweep][part][NV]; lanes 0..NV-1 then add the G rows in part order (their own from
-      // the register, the siblings' polled until no longer the fill pattern) and hand the totals to everyone through LDS
-      const int tid = (int)threadIdx.x;
-      float* xl = scratch + (int)(blockDim.x >> 6) * kSumTStride<NV>;
+      // this part's NV sums -> slot [b][sweep][part][NV] and xq[part]; lanes 0..NV-1 gather the siblings' rows (polled until
+      // no longer the fill pattern, wave_ops.h: xwg_*).  A part that does not show up within the timeout (not resident: CU
+      // mask, partitioned GPU, a foreign kernel holding CUs) is RECOMPUTED here from its points by the same lanes in the same
+      // order -- the same bits -- so the result never depends on co-residency.  Then the G rows are added in part order and
+      // the totals handed to everyone through LDS.
+      const int tid = (int)threadIdx.x, T = (int)blockDim.x;
+      float* xl = scratch + (T >> 6) * kSumTStride<NV>;        // [32] totals
+      float* xq = xl + 32;                                     // [8][NV] the parts' rows
+      unsigned* missw = reinterpret_cast<unsigned*>(xq + 8 * NV);
       unsigned* slot = reinterpret_cast<unsigned*>(xch) + (((size_t)b * NS + sweep_idx) * G) * NV;
-      float mine = acc[0];
+      auto mine_of = [&](const float (&v)[NV]) {
+        float m = v[0];
 #pragma unroll
-      for (int i = 1; i < NV; ++i) mine = (tid == i) ? acc[i] : mine;
+        for (int i = 1; i < NV; ++i) m = (tid == i) ? v[i] : m;
+        return m;
+      };
+      if (tid == 0) *missw = 0u;
+      __syncthreads();
       if (tid < NV) {
-        const unsigned bits = (mine != mine) ? 0x7fc00000u : __float_as_uint(mine);
-        __hip_atomic_store(slot + part * NV + tid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        float tot = 0.f;
-        bool timed_out = false;
+        const unsigned bits = xwg_payload(mine_of(acc));
+        xwg_store(slot + part * NV + tid, bits);
+        xq[part * NV + tid] = bits_f32(bits);
+        unsigned miss = 0u;
         for (int q = 0; q < G; ++q) {
-          float v = mine;
-          if (q != part) {
-            unsigned u = __hip_atomic_load(slot + q * NV + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int spins = 0; u == 0xffffffffu && spins < (1 << 22); ++spins) {
-              __builtin_amdgcn_s_sleep(1);
-              u = __hip_atomic_load(slot + q * NV + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            timed_out |= (u == 0xffffffffu);
-            v = __uint_as_float(u);
-          }
-          tot += v;
+          if (q == part) continue;
+          const unsigned u = xwg_poll(slot + q * NV + tid, lm.split_timeout);
+          if (u == kXwgEmpty) miss |= 1u << q; else xq[q * NV + tid] = bits_f32(u);
         }
-        if (timed_out) raise_status(p, EPROPNP_ST_SPLIT_TIMEOUT, b);
+        if (miss) atomicOr(reinterpret_cast<int*>(missw), (int)miss);
+      }
+      __syncthreads();
+      const unsigned todo = *missw;                 // the same in every thread
+      if (todo) {
+        if (tid == 0) raise_status(p, EPROPNP_ST_SPLIT_TIMEOUT, b);      // informational: slower, not wrong
+        for (int q = 0; q < G; ++q) {
+          if (!((todo >> q) & 1u)) continue;
+          float a2[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) a2[i] = 0.f;
+#pragma unroll
+          for (int k = 0; k < PPL; ++k)
+            point_normal_eq<DOF, BOUNDS>(load_point(p, b, q * PPL * T + tid + k * T), K, R, t, z_min, delta, inv_eps, bd, clip, a2);
+          block_sum_t<NV>(a2, scratch);
+          if (tid < NV) xq[q * NV + tid] = bits_f32(xwg_payload(mine_of(a2)));
+          __syncthreads();
+        }
+      }
+      if (tid < NV) {
+        float tot = 0.f;
+        for (int q = 0; q < G; ++q) tot += xq[q * NV + tid];
         xl[tid] = tot;
       }
       __syncthreads();
@@ -127,7 +149,6 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
       __syncthreads();
       ++sweep_idx;
     }
-#endif
   };
 
   float cur[NV];
@@ -165,10 +186,10 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
 // 51.5 -> 55.6, 32 x 512: 28.9 -> 50).  Then: the most parts (<= 8) with at least 256 points each that keep the grid at one
 // workgroup per CU (the parts of an object wait for each other).  EPROPNP_LM_SPLIT=<G> overrides (1: off).
 static int lm_split_parts(int B, int N) {
-  const long wgs = padded_object_grid(B);
+  const long wgs = padded_object_grid(B), cus = device_cu_count();
   int g = (N > 2048) ? 8 : 1;
-  while (g > 1 && (wgs * g > 256 || (long)N < 256L * g)) g >>= 1;
-  { int ov[1]; if (env_ints("EPROPNP_LM_SPLIT", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && wgs * ov[0] <= 512 && (long)N >= 64L * ov[0]) g = ov[0]; }
+  while (g > 1 && (wgs * g > cus || (long)N < 256L * g)) g >>= 1;
+  { int ov[1]; if (env_ints("EPROPNP_LM_SPLIT", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && wgs * ov[0] <= 4096 && (long)N >= 64L * ov[0]) g = ov[0]; }
   return g;
 }
 
@@ -177,15 +198,11 @@ static int lm_sweeps(const epropnp_lm_params* lm) {
 }
 
 unsigned long long lm_split_bytes(const epropnp_problem* prob, const epropnp_lm_params* lm) {
-#ifdef EPROPNP_EMU
-  return 0;
-#else
   if (prob == nullptr || lm == nullptr || prob->num_obj <= 0 || prob->num_pts <= 16 || prob->num_pts > kMaxResidentPoints) return 0;
   const int g = lm_split_parts(prob->num_obj, prob->num_pts);
   const int NV = prob->dof == 6 ? NormalEq<6>::NV : NormalEq<4>::NV;
   if (g <= 1 || (prob->num_pts + g - 1) / g > 1024) return 0;       // a part: 4 waves x <= 4 points per lane
   return sizeof(float) * (unsigned long long)prob->num_obj * lm_sweeps(lm) * g * NV;
-#endif
 }
 
 int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
@@ -201,7 +218,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
   k.num_iter = lm->num_iter; k.fast_mode = lm->fast_mode;
   k.min_diag = lm->min_lm_diagonal; k.max_diag = lm->max_lm_diagonal;
   k.min_rel_decrease = lm->min_relative_decrease; k.radius0 = lm->initial_trust_region_radius;
-  k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps;
+  k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps; k.split_timeout = split_timeout_cycles();
   if (d.N <= 16 && !getenv("EPROPNP_LM_NO_ROWS")) {   // RSLM sub-problems: 16 objects per 256-thread block
     const dim3 grid((d.B + 15) / 16), block(256);
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
@@ -221,7 +238,6 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
     });
     return check_launch("lm_solve_kernel (streaming)");
   }
-#ifndef EPROPNP_EMU
   {   // few objects with many points: G workgroups per object (kernel comment); 4 waves per part, <= 2 points per lane
     const int G = lm_split_parts(d.B, d.N);
     const int NVh = prob->dof == 6 ? NormalEq<6>::NV : NormalEq<4>::NV;
@@ -236,7 +252,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
       const dim3 grid(padded_object_grid(d.B) * G), block(256);
       dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
         constexpr int NVc = NormalEq<decltype(DOF)::value>::NV;
-        const size_t smem = sizeof(float) * (4 * kSumTStride<NVc> + 32);
+        const size_t smem = sizeof(float) * (4 * kSumTStride<NVc> + 32 + 8 * NVc + 4);
         if (ppl == 4) {
           PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 4, decltype(BND)::value, 4, true>), grid, block, smem, st, d, k,
                      pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch);
@@ -252,7 +268,6 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
       return check_launch("lm_solve_kernel (split over workgroups)");
     }
   }
-#endif
   // fewest waves per object at every batch size: more waves only add cross-wave reduction + barrier latency to each of
   // the 1+L dependent sweeps (measured on MI355X at B = 32 / 256 / 600: 1 wave 38 / 30 / 30 us vs 86 / 62 / 41 us)
   Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/0);

@@ -94,6 +94,35 @@ inline bool env_ints(const char* name, int* out, int n) {
   return true;
 }
 
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount, cached): what the workgroup-split variants
+// size their grids against -- a partitioned (CPX) MI355X or another part reports its own count; the CPU emulation of the
+// tests is a "device" with ONE compute unit (it runs one workgroup at a time), which switches the splits off by default.
+inline int device_cu_count() {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
+
+// How long (shader cycles) a part of a split kernel waits for a sibling's exchange words before it recomputes them itself
+// (wave_ops.h: xwg_poll).  Default 2^18 (~0.1 ms: siblings normally arrive within ~2 us); EPROPNP_SPLIT_TIMEOUT_CYCLES
+// overrides, 0 = never wait (every part recomputes whatever is not there yet: the tests' way of forcing that path).
+inline unsigned split_timeout_cycles() {
+  int ov[1];
+  if (env_ints("EPROPNP_SPLIT_TIMEOUT_CYCLES", ov, 1) && ov[0] >= 0) return (unsigned)ov[0];
+  return 1u << 18;
+}
+
+// kernels with more than 64 KiB of dynamic LDS have to be told so once
+inline void allow_dynamic_lds(const void* kern, size_t bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 // Fraction of an object's total |weight| that the backward may leave out (see mass_drop_threshold, amis_common.h).
 // Default 2^-24; EPROPNP_BWD_DROP=<float> overrides it, 0 = exact (every non-zero sample is evaluated).
 inline float backward_drop_eps() {

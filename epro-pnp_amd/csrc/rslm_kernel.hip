@@ -368,7 +368,7 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
   k.num_iter = lm->num_iter; k.fast_mode = lm->fast_mode;
   k.min_diag = lm->min_lm_diagonal; k.max_diag = lm->max_lm_diagonal;
   k.min_rel_decrease = lm->min_relative_decrease; k.radius0 = lm->initial_trust_region_radius;
-  k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps;
+  k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps; k.split_timeout = 0;
   const int Np = (d.N + 3) & ~3;
   const size_t smem = sizeof(float) * ((size_t)(7 + kRslmRows) * Np + 128);
   int parts = 1;

@@ -144,6 +144,47 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
   return ab < cd ? ab : cd;
 }
 
+// ---- words exchanged between the workgroups of ONE launch (the split-over-workgroups variants of the AMIS forward and
+// the LM solve) ------------------------------------------------------------------------------------------------------
+// A slot is pre-filled with kXwgEmpty by the launcher; its producer overwrites it with the payload (never kXwgEmpty: NaNs
+// are stored canonical), so the data is its own arrival flag.  Every access is a relaxed AGENT-scope atomic (sc1 stores /
+// loads: they bypass the per-CU L1 and the non-coherent L2 lines of other XCDs); no release / acquire fences -- at agent
+// scope those write back / invalidate whole caches, 20 us per exchange (profiles/r03_fwd_split_timing.txt).
+// A consumer waits for a slot for at most `timeout_cycles` shader cycles and then gets kXwgEmpty back: the caller computes
+// the missing value ITSELF from the object's points (same lanes, same order: same bits), so correctness never depends on
+// the sibling workgroups being resident -- a CU mask, a partitioned GPU or a foreign kernel holding CUs costs time, not
+// results.  (CPU emulation: workgroups run one after another, a slot is either there or it is not.)
+constexpr unsigned kXwgEmpty = 0xffffffffu;
+
+__device__ __forceinline__ unsigned f32_bits(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); return u; }
+__device__ __forceinline__ float bits_f32(unsigned u) { float x; __builtin_memcpy(&x, &u, 4); return x; }
+// payload of a float: its bits, NaNs canonical (so that no payload equals kXwgEmpty, a negative NaN with a full payload)
+__device__ __forceinline__ unsigned xwg_payload(float x) { return (x != x) ? 0x7fc00000u : f32_bits(x); }
+
+__device__ __forceinline__ void xwg_store(unsigned* p, unsigned v) {
+#ifndef EPROPNP_EMU
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+
+__device__ __forceinline__ unsigned xwg_poll(const unsigned* p, unsigned timeout_cycles) {
+#ifndef EPROPNP_EMU
+  unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v != kXwgEmpty || timeout_cycles == 0) return v;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  do {
+    __builtin_amdgcn_s_sleep(1);
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } while (v == kXwgEmpty && (unsigned long long)__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)timeout_cycles);
+  return v;
+#else
+  (void)timeout_cycles;
+  return *p;
+#endif
+}
+
 // Orders this wave's earlier LDS writes before its later LDS reads of OTHER lanes' data.  The hardware executes a
 // wave's DS instructions in order, so no s_barrier is needed; this only stops the compiler from reordering.
 __device__ __forceinline__ void wave_lds_fence() {

@@ -19,7 +19,7 @@ def _f32c(t, name):
 
 
 # ---- device-side status word (include/epropnp_hip.h: epropnp_problem.status) -----------------------------------------
-ST_LM_NOT_SPD, ST_NONFINITE_POSE, ST_CHOL_FALLBACK, ST_NONFINITE_WEIGHT = 1, 2, 4, 8
+ST_LM_NOT_SPD, ST_NONFINITE_POSE, ST_CHOL_FALLBACK, ST_NONFINITE_WEIGHT, ST_SPLIT_TIMEOUT = 1, 2, 4, 8, 16
 _status = threading.local()
 
 
@@ -68,6 +68,8 @@ class numerics_check:
         for key, buf in _status.bufs.items():
             flags, first = buf.tolist()            # the one synchronisation
             buf.copy_(torch.tensor([0, 2 ** 31 - 1], dtype=torch.int32))
+            if flags & ST_SPLIT_TIMEOUT:           # a performance event (a split kernel recomputed a sibling's share), never an error
+                _hip._warn_split_degraded(first, key)
             if flags & ST_LM_NOT_SPD:
                 events.append(f'linalg.solve: the damped normal equations of object {first} on {key} are singular or not finite')
             elif flags & ST_NONFINITE_POSE:

@@ -70,8 +70,11 @@ typedef struct epropnp_problem {
 #define EPROPNP_ST_CHOL_FALLBACK 4     /* a proposal covariance was replaced by its default (cholesky_wrapper,
                                           epropnp.py:16-33: what the reference does silently as well)                  */
 #define EPROPNP_ST_NONFINITE_WEIGHT 8  /* an AMIS log-weight is NaN / +inf                                              */
-#define EPROPNP_ST_SPLIT_TIMEOUT 16    /* amis_forward split over workgroups (few objects): a part gave up waiting for its
-                                          siblings' partial costs -- the object's outputs are invalid                   */
+#define EPROPNP_ST_SPLIT_TIMEOUT 16    /* PERFORMANCE event, results unaffected: in a launch that splits an object over several
+                                          workgroups (amis_forward at few objects, lm_solve beyond 2048 points) a part did
+                                          not see a sibling's partial sums within EPROPNP_SPLIT_TIMEOUT_CYCLES (the
+                                          siblings were not all resident: CU mask, partitioned GPU, a foreign kernel holding
+                                          CUs) and recomputed them itself from the object's points, to the same bits     */
 
 /* Trust-region parameters of LMSolver.__init__ (epropnp/levenberg_marquardt.py:31-53). */
 typedef struct epropnp_lm_params {

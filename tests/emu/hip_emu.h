@@ -39,6 +39,14 @@ typedef int hipError_t;
 #define hipSuccess 0
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+// host-side runtime calls the launchers make: the emulated "device" is this process (one compute unit: workgroups run one
+// after another), stream-ordered allocations are plain malloc / free
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+enum { hipDeviceAttributeMultiprocessorCount = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 2 };
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 1; return 0; }
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+inline hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
+inline hipError_t hipFreeAsync(void* p, hipStream_t) { std::free(p); return 0; }
 
 namespace emu {
 

@@ -420,6 +420,79 @@ def test_forward_split_over_workgroups(monkeypatch, dof, bounds, B, N, S, K):
     assert all(torch.equal(o[1], w2) for o in both)
 
 
+@pytest.mark.parametrize('dof,bounds,N,G,S,K', [(6, None, 300, 4, 48, 3), (4, 'tensor', 260, 4, 32, 2), (6, 'tight', 520, 8, 40, 2)])
+def test_forward_split_recomputes_missing_parts(backend, monkeypatch, dof, bounds, N, G, S, K):
+    """The split AMIS forward never depends on its sibling workgroups being resident: partial costs that are not there within
+    EPROPNP_SPLIT_TIMEOUT_CYCLES are recomputed -- the missing part's point tiles loaded into this workgroup's registers and
+    swept by the same lanes in the same order.  CPU emulation (workgroups run one after another): every part recomputes the
+    later ones, the log-weights must still be the oracle's at the kernel's own samples.  GPU: a zero timeout forces the path
+    wherever a sibling is late -- bit-identical to the patient run."""
+    from epropnp import functional as F
+    B = 2
+    prob = orc.make_problem(B, N, dof, seed=29, bounds=bounds)
+    noise = pack_noise(orc.make_noise(B, S, K, dof, seed=30), dof).to(backend)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
+    monkeypatch.setenv('EPROPNP_FWD_SPLIT', '1')
+    s1, w1 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+    monkeypatch.setenv('EPROPNP_FWD_SPLIT', str(G))
+    assert F.split_scratch(hp, S, K) is not None
+    s2, w2, pr2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise, with_proposals=True)
+    assert (s1 - s2).abs().max().item() <= 5e-4 * max(1.0, s1.abs().max().item())
+    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3
+    samples, logw, props = s2.cpu(), w2.cpu(), pr2.cpu()
+    ocam = orc.Cam(prob['cam_mats'].double(), 0.1, None if bounds is None else prob['lb'].double(),
+                   None if bounds is None else prob['ub'].double())
+    cost = orc.evaluate(prob['x3d'].double(), prob['x2d'].double(), prob['w2d'].double(), samples.double(), ocam,
+                        prob['delta'].double(), want_cost=True)[1]
+    expect = -cost.float() - _mixture_logq(samples, props, dof, K)
+    assert (logw - expect).abs().max().item() <= 2e-4 * max(1.0, expect.abs().max().item())
+    if backend.type == 'cuda':
+        monkeypatch.setenv('EPROPNP_SPLIT_TIMEOUT_CYCLES', '0')
+        s3, w3 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+        torch.cuda.synchronize()
+        assert torch.equal(s3, s2) and torch.equal(w3, w2)
+
+
+@pytest.mark.gpu
+def test_split_kernels_beside_a_kernel_that_holds_the_cus():
+    """LineMOD training runs the layer beside a backbone on other streams.  With large GEMMs in flight on a second stream the
+    parts of a split launch are not all resident at once; they must neither hang nor return other numbers: the dense C3
+    forward (split LM + 8-part split forward) and the C3-training forward give the quiet run's bits, every time."""
+    import warnings
+    import install as emu
+    emu.uninstall()
+    from epropnp import functional as F
+    dev = torch.device('cuda:0')
+    hog = torch.randn(8192, 8192, device=dev)
+    side = torch.cuda.Stream()
+    for B, N, S, K in ((32, 4096, 128, 4), (32, 512, 512, 4)):
+        prob = orc.make_problem(B, N, 6, seed=31)
+        noise = pack_noise(orc.make_noise(B, S, K, 6, seed=32), 6).to(dev)
+        p, cam, cf = make_layer_objects(prob, dev)
+        hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6)
+
+        def body():
+            pose_opt, pose_cov, cost = F.lm_solve(hp, p['pose_init'], 5, with_pose_cov=True, with_cost=True)
+            return (pose_opt, cost) + tuple(F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise))
+        quiet = [t.clone() for t in body()]
+        torch.cuda.synchronize()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)          # "a sibling was recomputed" is the expected performance note
+            for rnd in range(4):
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(6):
+                        hog @ hog                                    # ~10 ms each: every CU busy
+                for _ in range(3):
+                    busy = body()
+                    for a, b in zip(busy, quiet):
+                        assert torch.equal(a, b), (N, rnd)
+                torch.cuda.synchronize()
+            F.flush_status()
+
+
 @pytest.mark.gpu
 def test_split_kernels_in_a_hipgraph_survive_eager_work_between_replays():
     """The workgroup-split forward and LM solve reset their exchange slots on the stream before every launch.  Captured into a

@@ -128,3 +128,37 @@ def test_lm_split_over_workgroups(monkeypatch, dof, bounds, B, N, lm_iter, fast)
     torch.cuda.synchronize()
     F.flush_status()
     assert all(torch.equal(o[0], outs[0][0]) for o in both)
+
+
+@pytest.mark.parametrize('dof,bounds,N,G,fast', [(6, None, 300, 4, False), (4, 'tight', 200, 2, False), (6, 'tensor', 520, 8, True)])
+def test_lm_split_recomputes_missing_parts(backend, monkeypatch, dof, bounds, N, G, fast):
+    """The split LM solve never depends on its sibling workgroups being resident: a part whose partial normal equations are
+    not there within EPROPNP_SPLIT_TIMEOUT_CYCLES is recomputed from its points by the same lanes in the same order.
+    On the CPU emulation workgroups run one after another, so EVERY later part is missing for the earlier ones: the whole
+    solve then goes through the recomputation path and must match the one-workgroup kernel to summation order.  On the GPU
+    a zero timeout forces the path wherever a sibling is not there at the first look: bit-identical to the patient run."""
+    from epropnp import functional as F
+    B, L = 3, 4
+    prob = orc.make_problem(B, N, dof, seed=77, bounds=bounds)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    kw = dict(fast_mode=fast, with_pose_cov=True, with_cost=True, with_accepts=True)
+    monkeypatch.setenv('EPROPNP_LM_SPLIT', '1')
+    one = F.lm_solve(hp, p['pose_init'], L, **kw)
+    monkeypatch.setenv('EPROPNP_LM_SPLIT', str(G))
+    par = F._hip.LmParams(L, int(fast), 1e-6, 1e32, 1e-3, 30.0, 1e16, 1e-5)
+    assert F.lm_split_scratch(hp, par) is not None
+    many = F.lm_solve(hp, p['pose_init'], L, **kw)
+    assert torch.equal(many[3], one[3])                                          # the same accept / reject history
+    assert (many[0] - one[0]).abs().max().item() <= 2e-5 and _close(many[2], one[2], 2e-5)
+    assert _close(many[1], one[1], 2e-3)
+    if backend.type == 'cuda':
+        monkeypatch.setenv('EPROPNP_SPLIT_TIMEOUT_CYCLES', '0')
+        hasty = F.lm_solve(hp, p['pose_init'], L, **kw)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(hasty, many))
+
+
+def _close(a, b, rel):
+    return bool(((a - b).abs() <= rel * b.abs().clamp(min=1e-30) + 1e-30).all()) if a.dim() == 1 else \
+        bool((a - b).abs().max() <= rel * b.abs().max())
