@@ -153,57 +153,119 @@ PNP_FIT_FN void fit_translation(fit_t (&C)[3][3], const float* fallback_diag, fl
   rec[15] = student_t3_log_norm(sl);
 }
 
-// rot_cov (4x4 SPD, trace ~ 1) -> + det^(1/4) * dispersion * I -> Cholesky -> rec[16..36]   (epropnp.py:301-302,341-342)
-PNP_FIT_FN void fit_rotation_acg(fit_t (&Rc)[4][4], float dispersion, float* rec) {
-  fit_t Lc[4][4];
+// ---- the refit's reductions: NV per-lane partial sums -> NV totals, ONE wave, through LDS -------------------------------
+// A wave_sum per value costs 11 VALU instructions (4 DPP adds, 4 v_readlane, 3 adds: DPP and readlane issue at half rate),
+// 231 for the 21 moments of the 6-DoF refit -- on the one wave the other three of the workgroup are waiting for.  Transposed
+// instead: every lane parks its NV partials (row v, column = lane: NV ds_write), lane 4 v' + j then adds columns
+// [16 j, 16 j + 16) of row v = base + v' (4 ds_read_b128, 15 adds), two quad-DPP adds join the four quarters, and the NV
+// totals come back as broadcast reads: ~35 VALU instructions for 21 values.  Fixed order: bit-reproducible.
+constexpr int kRefitMaxVals = 21;
+constexpr int kRefitRedFloats = kRefitMaxVals * kSumTRow + 24;     // rows of 64 + 4 floats, then the totals
+
+template <int NV>
+PNP_FN void wave_sum_t(float (&v)[NV], float* lds) {
+  static_assert(NV <= kRefitMaxVals, "scratch rows");
+  const int lane = lane_id();
+  float* tot = lds + kRefitMaxVals * kSumTRow;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NV; ++i) lds[i * kSumTRow + lane] = v[i];
+  wave_lds_fence();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Lc[i][j] = Rc[i][j];
+  for (int base = 0; base < NV; base += 16) {
+    const int row = base + (lane >> 2);
+    float part = 0.f;
+    if (row < NV) {
+      const float4* r = reinterpret_cast<const float4*>(lds + row * kSumTRow + 16 * (lane & 3));
+      const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+      part = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+    }
+    part = quad_sum(part);
+    if (row < NV && (lane & 3) == 0) tot[row] = part;
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = tot[i];
+  wave_lds_fence();
+}
+
+// the refit's cross-lane sums: transposed through `scratch`, or (no scratch: the all-VALU forward kernel) wave_sum chains
+template <int NV>
+PNP_FN void refit_sum(float (&v)[NV], float* scratch) {
+  if (scratch != nullptr) {
+    wave_sum_t<NV>(v, scratch);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  }
+}
+
+// Translation (3x3) and rotation (4x4, ACG) factors of a proposal fitted by TWO lanes in lockstep: lane 0 takes the rotation
+// shape matrix, lane 1 the translation covariance padded to 4x4 with a unit pivot -- the same instructions serve both, so the
+// translation fit rides for free on the ~250 fp64 instructions of the rotation fit (it used to follow it on the same lane).
+// Rotation (epropnp.py:301-302,341-342): rot_cov (4x4 SPD, trace ~ 1) + det^(1/4) * dispersion * I -> Cholesky -> rec[16..36],
+// identity factor when not SPD.  Translation: the same operations per matrix as fit_translation -- lane 1 has dispersion 0 (its diagonal
+// shift is exactly 0, the second factorisation repeats the first) and a unit last pivot (log 1 = 0 in the normaliser).
+// A: this lane's 4x4 matrix (lower triangle read); which = 0 rotation / 1 translation; fallback: diagonal used when A is not SPD.
+PNP_FIT_FN void fit_factor_pair(fit_t (&A)[4][4], int which, float dispersion, const float (&fallback)[4], float* rec) {
+  // det A by 2x2 minors of rows (0,1) and (2,3) (fp64: cancellation costs cond * 1e-16): 30 operations and no copy of A,
+  // where a first Cholesky factorisation for its pivots cost 75 and ten more live doubles
+  const fit_t m01 = A[0][0] * A[1][1] - A[0][1] * A[1][0], m02 = A[0][0] * A[1][2] - A[0][2] * A[1][0],
+               m03 = A[0][0] * A[1][3] - A[0][3] * A[1][0], m12 = A[0][1] * A[1][2] - A[0][2] * A[1][1],
+               m13 = A[0][1] * A[1][3] - A[0][3] * A[1][1], m23 = A[0][2] * A[1][3] - A[0][3] * A[1][2];
+  const fit_t n01 = A[2][0] * A[3][1] - A[2][1] * A[3][0], n02 = A[2][0] * A[3][2] - A[2][2] * A[3][0],
+               n03 = A[2][0] * A[3][3] - A[2][3] * A[3][0], n12 = A[2][1] * A[3][2] - A[2][2] * A[3][1],
+               n13 = A[2][1] * A[3][3] - A[2][3] * A[3][1], n23 = A[2][2] * A[3][3] - A[2][3] * A[3][2];
+  const float det = (float)(m01 * n23 - m02 * n13 + m03 * n12 + m12 * n03 - m13 * n02 + m23 * n01);
+  // det^(1/4) * dispersion; a negative determinant (indefinite matrix) gives NaN here as torch.det(...) ** 0.25 does in the
+  // reference, the factorisation below then fails and the factor falls back to its default
+  const fit_t add = (which == 0) ? (fit_t)(sqrtf(sqrtf(det)) * dispersion) : fit_t(0);
   fit_t invd[4];
-  bool ok = cholesky<4, fit_t>(Lc, invd);
-  // det^(1/4) = sqrt(prod of the Cholesky pivots).  reference: torch.det on a possibly indefinite matrix; in the
-  // non-SPD case any value leads to the Cholesky fallback below, so the SPD determinant is all that matters
-  const float pivots = (float)(Lc[0][0] * Lc[1][1] * Lc[2][2] * Lc[3][3]);
-  const fit_t add = ok ? (fit_t)(sqrtf(pivots) * dispersion) : fit_t(0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) Rc[i][i] += add;
-  ok = cholesky<4, fit_t>(Rc, invd) && ok;
-  rec[38] = ok ? 0.f : 1.f;
+  for (int i = 0; i < 4; ++i) A[i][i] += add;
+  const bool ok = cholesky<4, fit_t>(A, invd) && (add == add);
   if (!ok) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Rc[i][j] = (i == j) ? fit_t(1) : fit_t(0);
-      invd[i] = fit_t(1);
+      for (int j = 0; j < 4; ++j) A[i][j] = (i == j) ? (fit_t)fallback[i] : fit_t(0);
+      invd[i] = fit_t(1) / (fit_t)fallback[i];
     }
   }
   fit_t Li[4][4];
-  tri_inverse<4, fit_t>(Rc, invd, Li);
+  tri_inverse<4, fit_t>(A, invd, Li);
   float sl = 0.f;
+  const int oL = which ? 3 : 16, oLi = which ? 9 : 26;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    sl += fast_log((float)Rc[i][i]);
+    sl += fast_log((float)A[i][i]);
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
-      rec[16 + tri(i, j)] = (float)Rc[i][j];
-      rec[26 + tri(i, j)] = (float)Li[i][j];
+      if (which == 0 || i < 3) {
+        rec[oL + tri(i, j)] = (float)A[i][j];
+        rec[oLi + tri(i, j)] = (float)Li[i][j];
+      }
     }
   }
-  rec[36] = sl;
+  rec[which ? 15 : 36] = which ? student_t3_log_norm(sl) : sl;
+  rec[which ? 37 : 38] = ok ? 0.f : 1.f;
 }
 
-// proposal #0 from the Laplace approximation at the LM solution
+// proposal #0 from the Laplace approximation at the LM solution.  6-DoF: called by lanes 0 AND 1 of a wave (`which` = lane):
+// both run the same instructions, lane 1's translation factor comes out of the rotation fit's instruction stream
+// (fit_factor_pair).  4-DoF: lane 0 only.
 template <int DOF>
-PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, float dispersion, float* rec) {
-  rec[0] = pose_opt[0]; rec[1] = pose_opt[1]; rec[2] = pose_opt[2];
-  rec[37] = rec[38] = rec[39] = 0.f;
-  fit_t Ct[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) Ct[i][j] = (fit_t)cov[i * DOF + j];
+PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, float dispersion, float* rec, int which = 0) {
+  if (which == 0) {
+    rec[0] = pose_opt[0]; rec[1] = pose_opt[1]; rec[2] = pose_opt[2];
+    rec[39] = 0.f;
+  }
   if (DOF == 4) {
+    rec[37] = rec[38] = 0.f;
+    fit_t Ct[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Ct[i][j] = (fit_t)cov[i * DOF + j];
     const float dflt[3] = {1.0f, 1.0f, 4.0f};
     fit_translation(Ct, dflt, rec);
     rec[16] = pose_opt[3];
@@ -213,8 +275,6 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
 #pragma unroll
     for (int i = 19; i < 37; ++i) rec[i] = 0.f;      // unused in the 4-DoF record: the records are an output, no stale LDS in them
   } else {
-    const float dflt[3] = {1.0f, 1.0f, 1.0f};
-    fit_translation(Ct, dflt, rec);
     fit_t Cr[3][3], Ci[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -256,7 +316,14 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) Ai[i][j] *= itr;
-    fit_rotation_acg(Ai, dispersion, rec);
+    if (which == 1) {      // this lane factors the translation covariance instead (padded with a unit pivot)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ai[i][j] = (i < 3 && j < 3) ? (fit_t)cov[i * DOF + j] : ((i == j) ? fit_t(1) : fit_t(0));
+    }
+    const float dflt[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    fit_factor_pair(Ai, which, dispersion, dflt, rec);
   }
 }
 
@@ -421,6 +488,7 @@ struct AmisCtx {
   float* prop;    // [K][kPropStride] fitted proposals
   float* red;     // [256]        block-reduction scratch
   float* nzb;     // [s][8] base noise of the NEXT draw, generated ahead by the idle waves (nullptr: drawn inline)
+  float* rred;    // [kRefitRedFloats] scratch of the refit's single-wave transposed reductions (nullptr: DPP / readlane chains)
   int S, K, s, T, tid, b;
   int cstride;    // row stride of cpart (s, or s rounded up to 16 for the MFMA kernel)
 };
@@ -622,10 +690,16 @@ PNP_FN void amis_weights(const AmisCtx& cx, const AmisParams& a, int it, int WP)
 }
 
 // ---------------- 5. fit proposal it+1 to the weighted samples (epropnp.py:238-260 / :317-342) ---------
+// Runs on wave 0 only: with <= a few hundred samples the moment passes are short, and a single wave needs no workgroup
+// barriers (the other waves pre-generate the next draw's base noise and wait at the end).  What the phase costs is the
+// number of instructions that one wave issues while three are parked (profiles/r02_tune_fwd_serial_phases.txt, r04): the
+// cross-lane sums go through LDS transposed (wave_sum_t: ~35 instead of 231 VALU instructions for the 21 moments), the
+// fixed point hands the samples L^-1 instead of Sigma^-1 (|L^-1 q|^2 = q^T Sigma^-1 q: no L^-T L^-1 product on the fitting
+// lane, 14 instead of 20 operations per sample, and a sum of squares instead of a cancelling quadratic form), the weights
+// are divided by hardware reciprocals, and the translation factor is fitted by lane 1 inside the instruction stream of lane
+// 0's rotation fit (fit_factor_pair).
 template <int DOF>
 PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
-  // Runs on wave 0 only: with <= a few hundred samples the moment passes are short, and a single wave needs no
-  // workgroup barriers and a quarter of the cross-lane reduction instructions (the other waves wait at the end).
   float* smp = cx.smp; float* lgw = cx.lgw; float* prop = cx.prop; float* red = cx.red;
   const int S = cx.S, s = cx.s;
   const float* rec = prop + it * kPropStride;
@@ -672,7 +746,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       mom[4] += e * d0 * d0; mom[5] += e * d1 * d0; mom[6] += e * d1 * d1;
       mom[7] += e * d2 * d0; mom[8] += e * d2 * d1; mom[9] += e * d2 * d2;
       const float q0 = smp[3 * S + m], q1 = smp[4 * S + m], q2 = smp[5 * S + m], q3 = smp[6 * S + m];
-      const float iw = e / fmaxf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3, a.eps);    // M = q^T I q
+      const float iw = e * fast_rcp(fmaxf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3, a.eps));    // M = q^T I q
       mom[10] += iw * q0 * q0;
       mom[11] += iw * q1 * q0; mom[12] += iw * q1 * q1;
       mom[13] += iw * q2 * q0; mom[14] += iw * q2 * q1; mom[15] += iw * q2 * q2;
@@ -682,8 +756,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
 #ifdef PNP_TUNING
     if (!(a.ablate & 16))
 #endif
-#pragma unroll
-    for (int i = 0; i < 21; ++i) mom[i] = wave_sum(mom[i]);
+    refit_sum<21>(mom, cx.rred);
     const float invZ = 1.0f / mom[0];
     const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
     const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;
@@ -694,9 +767,9 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
 #pragma unroll
     for (int i = 0; i < 11; ++i) acc[i] = mom[10 + i];
     PNP_REFIT_PHASE(0);
-    float Si[10];
+    float Li[10];
     for (int r = 1; r < a.mle_iter; ++r) {
-      // Sigma^-1 of the previous fixed-point iterate (one lane, fp64), broadcast through LDS
+      // L^-1 of the previous fixed-point iterate Sigma = L L^T (one lane, fp64), broadcast through LDS
       if (tid == 0) {
         fit_t Sg[4][4], Sgi[4][4], invd[4];
         const fit_t inorm = fit_t(1) / (fit_t)acc[10];
@@ -708,7 +781,8 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
             Sg[i][j] = v;
             Sg[j][i] = v;
           }
-        spd_inverse<4, fit_t>(Sg, invd, Sgi);
+        cholesky<4, fit_t>(Sg, invd);
+        tri_inverse<4, fit_t>(Sg, invd, Sgi);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -716,41 +790,34 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       }
       wave_lds_fence();
 #pragma unroll
-      for (int i = 0; i < 10; ++i) Si[i] = red[i];
+      for (int i = 0; i < 10; ++i) Li[i] = red[i];
       wave_lds_fence();
 #pragma unroll
       for (int i = 0; i < 11; ++i) acc[i] = 0.f;
       for (int m = tid; m < M; m += T) {
         const float e = fast_exp(lgw[m] - mx);
         const float q0 = smp[3 * S + m], q1 = smp[4 * S + m], q2 = smp[5 * S + m], q3 = smp[6 * S + m];
-        const float Mq = Si[0] * q0 * q0 + Si[2] * q1 * q1 + Si[5] * q2 * q2 + Si[9] * q3 * q3 +
-                         2.f * (Si[1] * q1 * q0 + Si[3] * q2 * q0 + Si[4] * q2 * q1 + Si[6] * q3 * q0 + Si[7] * q3 * q1 +
-                                Si[8] * q3 * q2);
-        const float iw = e / fmaxf(Mq, a.eps);     // the reference normalises w first; the ratio below is scale-free
+        const float y0 = Li[0] * q0;
+        const float y1 = fmaf(Li[2], q1, Li[1] * q0);
+        const float y2 = fmaf(Li[5], q2, fmaf(Li[4], q1, Li[3] * q0));
+        const float y3 = fmaf(Li[9], q3, fmaf(Li[8], q2, fmaf(Li[7], q1, Li[6] * q0)));
+        const float Mq = fmaf(y3, y3, fmaf(y2, y2, fmaf(y1, y1, y0 * y0)));       // q^T Sigma^-1 q = |L^-1 q|^2
+        const float iw = e * fast_rcp(fmaxf(Mq, a.eps));     // the reference normalises w first; the ratio below is scale-free
         acc[10] += iw;
         acc[0] += iw * q0 * q0;
         acc[1] += iw * q1 * q0; acc[2] += iw * q1 * q1;
         acc[3] += iw * q2 * q0; acc[4] += iw * q2 * q1; acc[5] += iw * q2 * q2;
         acc[6] += iw * q3 * q0; acc[7] += iw * q3 * q1; acc[8] += iw * q3 * q2; acc[9] += iw * q3 * q3;
       }
-#pragma unroll
-      for (int i = 0; i < 11; ++i) acc[i] = wave_sum(acc[i]);
+      refit_sum<11>(acc, cx.rred);
     }
     PNP_REFIT_PHASE(1);
-    if (tid == 0) {
-      nrec[0] = mu0; nrec[1] = mu1; nrec[2] = mu2;
-      fit_t Ct[3][3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-          Ct[i][j] = (fit_t)c6[tri(i, j)];
-          Ct[j][i] = (fit_t)c6[tri(i, j)];
-        }
-      const float dflt[3] = {1.f, 1.f, 1.f};
-      nrec[38] = nrec[39] = 0.f;
-      fit_translation(Ct, dflt, nrec);
-      fit_t Sg[4][4];
+    if (tid < 2) {      // lane 0: rotation factor, lane 1: translation factor (the same instructions)
+      if (tid == 0) {
+        nrec[0] = mu0; nrec[1] = mu1; nrec[2] = mu2;
+        nrec[39] = 0.f;
+      }
+      fit_t A4[4][4];
       const fit_t inorm = (a.mle_iter > 0) ? fit_t(1) / (fit_t)acc[10] : fit_t(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -758,10 +825,12 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
         for (int j = 0; j <= i; ++j) {
           fit_t v = (a.mle_iter > 0) ? (fit_t)acc[tri(i, j)] * inorm + ((i == j) ? (fit_t)a.eps : fit_t(0))
                                       : ((i == j) ? fit_t(1) : fit_t(0));
-          Sg[i][j] = v;
-          Sg[j][i] = v;
+          if (tid == 1) v = (i < 3) ? (fit_t)c6[tri(i, j)] : ((i == j) ? fit_t(1) : fit_t(0));
+          A4[i][j] = v;
+          A4[j][i] = v;
         }
-      fit_rotation_acg(Sg, a.dispersion, nrec);
+      const float dflt[4] = {1.f, 1.f, 1.f, 1.f};
+      fit_factor_pair(A4, tid, a.dispersion, dflt, nrec);
     }
     PNP_REFIT_PHASE(2);
   } else {
@@ -781,8 +850,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       mom[10] += e * sy;
       mom[11] += e * cy;
     }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) mom[i] = wave_sum(mom[i]);
+    refit_sum<12>(mom, cx.rred);
     const float invZ = 1.0f / mom[0];
     const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
     const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;

@@ -172,8 +172,9 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
   float* gath = cpart + W * s16;             // [G][s16] (SPLIT) the parts' partial costs of the current iteration
   float* prop = cpart + cpart_rows * s16 + (SPLIT ? 4 : 0);    // [K][kPropStride]  (SPLIT: + the missing-parts word)
   float* red = prop + K * kPropStride;   // [256]
-  float* nzb = (s <= T) ? ptab : red + 256;   // [s][8] base noise drawn ahead; shares the pose table's LDS when one
-                                              // sample per lane suffices (amis_draw separates the two uses)
+  float* rred = red + 256;               // [kRefitRedFloats] the refit's transposed reductions (amis_common.h: wave_sum_t)
+  float* nzb = (s <= T) ? ptab : rred + kRefitRedFloats;   // [s][8] base noise drawn ahead; shares the pose table's LDS when
+                                              // one sample per lane suffices (amis_draw separates the two uses)
 
   float Kc[9], delta;
   Bounds bd;
@@ -187,11 +188,13 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
   cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = SPLIT ? gath : cpart; cx.prop = prop; cx.red = red;
   cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s16;
   cx.nzb = (noise == nullptr && W > 1) ? nzb : nullptr;
+  cx.rred = rred;
 
   for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last tile
-  if (tid == 0) initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop);
+  if (tid < (DOF == 6 ? 2 : 1))      // 6-DoF: lane 1 fits the translation factor inside lane 0's rotation fit
+    initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop, tid);
 #ifdef PNP_TUNING_DOUBLE_INIT    // what one initial fit costs: a second one, on the neighbour's data, into a slot the first refit overwrites
-  if (tid == 0 && K > 1) initial_fit<DOF>(pose_opt + (size_t)((b + 1) % p.B) * PL, pose_cov + (size_t)((b + 1) % p.B) * DOF * DOF, a.eps, a.dispersion, prop + kPropStride);
+  if (tid < (DOF == 6 ? 2 : 1) && K > 1) initial_fit<DOF>(pose_opt + (size_t)((b + 1) % p.B) * PL, pose_cov + (size_t)((b + 1) % p.B) * DOF * DOF, a.eps, a.dispersion, prop + kPropStride, tid);
 #endif
   const int nchunk = kRegs ? 1 : (p.N + NC - 1) / NC;
   auto load_chunk = [&](int c0) {
@@ -506,6 +509,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   auto lds_bytes = [&](bool spilled) {
     return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (size_t)(PL + 3) * S) +
                             (size_t)(npt ? (G > 1 ? waves + G : waves) : 1) * sh.s16 + (G > 1 ? 4 : 0) + (size_t)K * kPropStride + 256 +
+                            kRefitRedFloats +
                             (s <= 64 * waves ? 0 : 8 * (size_t)s));
   };
   size_t smem = lds_bytes(false);

@@ -63,13 +63,15 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) vo
   // (profiles/r01_ubench_valu_rates.txt: v_fma_f32 1.05 ns vs 1.84 ns per wave-instruction with an SGPR operand)
   const float zmin_v = to_vgpr(p.z_min), delta_v = to_vgpr(delta);
 
-  if (tid == 0) initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop);
+  if (tid < (DOF == 6 ? 2 : 1))
+    initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop, tid);
   __syncthreads();
 
   AmisCtx cx;
   cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = cpart; cx.prop = prop; cx.red = red;
   cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s;
   cx.nzb = nullptr;
+  cx.rred = nullptr;      // (this kernel's LDS budget is its sample table: the refit sums stay on DPP / readlane chains)
 
   for (int it = 0; it < K; ++it) {
     amis_draw<DOF>(cx, p, a, it, Kc, noise, pose_samples);

@@ -249,17 +249,18 @@ PNP_FN float huber_exact(float rho, float delta) {
 // ---------------------------------------------------------------------------------------------------
 // tiny dense linear algebra, fully unrolled
 // ---------------------------------------------------------------------------------------------------
-// 1/sqrt(d) without the long IEEE sqrt/divide sequences: hardware rsq (fp32, 1 ulp) + Newton steps in the
-// working precision (one step: ~full fp32 accuracy; two steps from an fp32 seed: ~1e-14 relative in fp64).
+// 1/sqrt(d) without the long IEEE sqrt/divide sequences: hardware rsq (fp32, 1 ulp) + one Newton step in the working
+// precision.  fp32: ~full accuracy.  fp64: the seed is good to ~1e-7 (fp32 rounding of d + 1 ulp of v_rsq_f32), one step
+// squares that: ~1.5e-14 relative -- what the fp64 proposal fits need is freedom from cancellation, not the last two digits
+// (their results are stored as fp32), and each further step is five dependent fp64 instructions on the one lane the rest of
+// the workgroup waits for.
 PNP_FN float rsqrt_newton(float d) {
   const float r = fast_rsqrt(d);
   return r * fmaf(-0.5f * d * r, r, 1.5f);
 }
 PNP_FN double rsqrt_newton(double d) {
-  double r = (double)fast_rsqrt((float)d);
-  r = r * (1.5 - 0.5 * d * r * r);
-  r = r * (1.5 - 0.5 * d * r * r);
-  return r;
+  const double r = (double)fast_rsqrt((float)d);
+  return r * (1.5 - 0.5 * d * r * r);
 }
 
 // Cholesky A = L L^T in place on the lower triangle; invd[j] = 1 / L[j][j].

@@ -102,6 +102,19 @@ __device__ __forceinline__ float row_sum16(float x) {
 #endif
 }
 
+// sum over the 4 lanes of a quad (lanes 4q .. 4q+3; every lane of the quad receives (x0 + x1) + (x2 + x3))
+__device__ __forceinline__ float quad_sum(float x) {
+#ifndef EPROPNP_EMU
+  x += dpp_mov<0xB1>(x);      // quad_perm:[1,0,3,2]
+  x += dpp_mov<0x4E>(x);      // quad_perm:[2,3,0,1]
+  return x;
+#else
+  x += emu::shfl(x, lane_id() ^ 1);
+  x += emu::shfl(x, lane_id() ^ 2);
+  return x;
+#endif
+}
+
 // max over the 16 lanes of a DPP row (every lane of the row receives it)
 __device__ __forceinline__ float row_max16(float x) {
 #ifndef EPROPNP_EMU

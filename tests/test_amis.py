@@ -439,8 +439,12 @@ def test_forward_split_recomputes_missing_parts(backend, monkeypatch, dof, bound
     monkeypatch.setenv('EPROPNP_FWD_SPLIT', str(G))
     assert F.split_scratch(hp, S, K) is not None
     s2, w2, pr2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise, with_proposals=True)
-    assert (s1 - s2).abs().max().item() <= 5e-4 * max(1.0, s1.abs().max().item())
-    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3
+    # the first iteration's samples are the same draws from the same initial proposal; later ones come from proposals refitted
+    # to weights whose costs were summed in another order (with 16 samples per iteration a refit amplifies that: loose bar)
+    s = S // K
+    assert torch.equal(s1[:s], s2[:s])
+    assert (s1 - s2).abs().max().item() <= 5e-3 * max(1.0, s1.abs().max().item())
+    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 2e-2
     samples, logw, props = s2.cpu(), w2.cpu(), pr2.cpu()
     ocam = orc.Cam(prob['cam_mats'].double(), 0.1, None if bounds is None else prob['lb'].double(),
                    None if bounds is None else prob['ub'].double())
