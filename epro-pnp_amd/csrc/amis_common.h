@@ -477,6 +477,25 @@ PNP_FN float vm_sample_bounded(float loc, float kappa, Uniforms next) {
 }
 
 
+// A sample's pose -> the (S, B, pose_len) output: 28 (16) contiguous bytes that are only dword-aligned.  Two (one) wide
+// stores with 4-byte alignment instead of seven (four) dword stores per lane (global memory takes unaligned wide accesses).
+template <int PL>
+PNP_FN void store_pose(float* dst, const float (&ps)[PL]) {
+#ifndef EPROPNP_EMU
+  typedef float f4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+  const f4_a4 head = {ps[0], ps[1], ps[2], ps[3]};
+  *reinterpret_cast<f4_a4*>(dst) = head;
+  if (PL == 7) {
+    const f3_a4 tail = {ps[PL > 4 ? 4 : 0], ps[PL > 5 ? 5 : 0], ps[PL > 6 ? 6 : 0]};
+    *reinterpret_cast<f3_a4*>(dst + 4) = tail;
+  }
+#else
+#pragma unroll
+  for (int i = 0; i < PL; ++i) dst[i] = ps[i];
+#endif
+}
+
 // Per-thread view of one object's LDS-resident sampler state (shared by the VALU and the MFMA forward kernels).
 struct AmisCtx {
   float* ptab;    // [s_pad][12]  x|y|z rows of (K R | K t) of the current iteration's samples (A operands / broadcast rows)
@@ -544,9 +563,11 @@ PNP_FN void amis_base_noise(const AmisCtx& cx, const AmisParams& a, int it, int 
 }
 
 // ---------------- 1. draw s samples from proposal `it` (lane = sample) ----------------
+// n0, cnt: the iteration's samples [n0, n0 + cnt) are drawn, their pose-table rows are 0 .. cnt-1 (cnt < 0: all s samples;
+// the forward tiles an iteration whose pose table would not fit LDS)
 template <int DOF>
 PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, int it, const float (&Kc)[9],
-                      const float* __restrict__ noise, float* __restrict__ pose_samples) {
+                      const float* __restrict__ noise, float* __restrict__ pose_samples, int n0 = 0, int cnt = -1) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NZ = (DOF == 6) ? 8 : 4 + 3 * kVmTries;
   float* ptab = cx.ptab; float* smp = cx.smp;
@@ -563,7 +584,8 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
     }
     __syncthreads();
   }
-  for (int n = tid; n < s; n += T) {
+  const int n_end = (cnt < 0) ? s : n0 + cnt;
+  for (int n = n0 + tid; n < n_end; n += T) {
     const int m = it * s + n;
     float z[3], chi2, g[4];
     if (noise != nullptr) {
@@ -633,15 +655,13 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
     if (tid == 0) atomicAdd(&g_refit_phase[3], (unsigned long long)(clock64() - rot_t0_));
 #endif
 #pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      smp[i * S + m] = ps[i];
-      if (pose_samples != nullptr) pose_samples[((size_t)m * p.B + b) * PL + i] = ps[i];
-    }
+    for (int i = 0; i < PL; ++i) smp[i * S + m] = ps[i];
+    if (pose_samples != nullptr) store_pose<PL>(pose_samples + ((size_t)m * p.B + b) * PL, ps);
     {   // project_b operands of this sample -> LDS row (read back as broadcast by every lane of the sweep)
       float R[9], KR[9], Kt[3];
       pose_to_rot<DOF>(ps, R);
       compose_kr_kt(Kc, R, ps, KR, Kt);
-      float4* row = reinterpret_cast<float4*>(ptab + 12 * n);
+      float4* row = reinterpret_cast<float4*>(ptab + 12 * (n - n0));
       // [x-row | y-row | z-row] of (K R | K t): doubles as the A operand of the MFMA sweep
       row[0] = make_float4(KR[0], KR[1], KR[2], Kt[0]);
       row[1] = make_float4(KR[3], KR[4], KR[5], Kt[1]);
@@ -666,9 +686,11 @@ PNP_FN void amis_weights(const AmisCtx& cx, const AmisParams& a, int it, int WP)
     for (int i = 0; i < PL; ++i) ps[i] = smp[i * S + m];
     float mix;
     if (m >= it * s) {   // new sample: every proposal so far
-      float c = cpart[m - it * s];
-      for (int q = 1; q < WP; ++q) c += cpart[q * cx.cstride + (m - it * s)];
-      cst[m] = c;
+      if (WP > 0) {      // (WP == 0: the tiled sweep has stored the costs already)
+        float c = cpart[m - it * s];
+        for (int q = 1; q < WP; ++q) c += cpart[q * cx.cstride + (m - it * s)];
+        cst[m] = c;
+      }
 #ifdef PNP_TUNING
       if (a.ablate & 4) mix = 0.f; else {
 #endif
@@ -694,8 +716,9 @@ PNP_FN void amis_weights(const AmisCtx& cx, const AmisParams& a, int it, int WP)
 // barriers (the other waves pre-generate the next draw's base noise and wait at the end).  What the phase costs is the
 // number of instructions that one wave issues while three are parked (profiles/r02_tune_fwd_serial_phases.txt, r04): the
 // cross-lane sums go through LDS transposed (wave_sum_t: ~35 instead of 231 VALU instructions for the 21 moments), the
-// fixed point hands the samples L^-1 instead of Sigma^-1 (|L^-1 q|^2 = q^T Sigma^-1 q: no L^-T L^-1 product on the fitting
-// lane, 14 instead of 20 operations per sample, and a sum of squares instead of a cancelling quadratic form), the weights
+// fixed point hands the samples the Cholesky factor L of Sigma instead of Sigma^-1 (|L^-1 q|^2 = q^T Sigma^-1 q by forward
+// substitution: no triangular inverse and no L^-T L^-1 product on the fitting lane, 14 instead of 20 operations per sample,
+// and a sum of squares instead of a cancelling quadratic form), the weights
 // are divided by hardware reciprocals, and the translation factor is fitted by lane 1 inside the instruction stream of lane
 // 0's rotation fit (fit_factor_pair).
 template <int DOF>
@@ -767,11 +790,13 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
 #pragma unroll
     for (int i = 0; i < 11; ++i) acc[i] = mom[10 + i];
     PNP_REFIT_PHASE(0);
-    float Li[10];
+    float Lf[10], Ld[4];
     for (int r = 1; r < a.mle_iter; ++r) {
-      // L^-1 of the previous fixed-point iterate Sigma = L L^T (one lane, fp64), broadcast through LDS
+      // Cholesky factor of the previous fixed-point iterate Sigma = L L^T (one lane, fp64) -> the strict lower triangle and the
+      // reciprocal pivots, broadcast through LDS: every sample then solves L y = q by forward substitution (10 operations,
+      // as many as a product with L^-1 would take -- which the fitting lane therefore does not have to form)
       if (tid == 0) {
-        fit_t Sg[4][4], Sgi[4][4], invd[4];
+        fit_t Sg[4][4], invd[4];
         const fit_t inorm = fit_t(1) / (fit_t)acc[10];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -782,25 +807,28 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
             Sg[j][i] = v;
           }
         cholesky<4, fit_t>(Sg, invd);
-        tri_inverse<4, fit_t>(Sg, invd, Sgi);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          red[10 + i] = (float)invd[i];
 #pragma unroll
-          for (int j = 0; j <= i; ++j) red[tri(i, j)] = (float)Sgi[i][j];
+          for (int j = 0; j < i; ++j) red[tri(i, j)] = (float)Sg[i][j];
+        }
       }
       wave_lds_fence();
 #pragma unroll
-      for (int i = 0; i < 10; ++i) Li[i] = red[i];
+      for (int i = 0; i < 10; ++i) Lf[i] = red[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Ld[i] = red[10 + i];
       wave_lds_fence();
 #pragma unroll
       for (int i = 0; i < 11; ++i) acc[i] = 0.f;
       for (int m = tid; m < M; m += T) {
         const float e = fast_exp(lgw[m] - mx);
         const float q0 = smp[3 * S + m], q1 = smp[4 * S + m], q2 = smp[5 * S + m], q3 = smp[6 * S + m];
-        const float y0 = Li[0] * q0;
-        const float y1 = fmaf(Li[2], q1, Li[1] * q0);
-        const float y2 = fmaf(Li[5], q2, fmaf(Li[4], q1, Li[3] * q0));
-        const float y3 = fmaf(Li[9], q3, fmaf(Li[8], q2, fmaf(Li[7], q1, Li[6] * q0)));
+        const float y0 = q0 * Ld[0];
+        const float y1 = fmaf(-Lf[tri(1, 0)], y0, q1) * Ld[1];
+        const float y2 = fmaf(-Lf[tri(2, 1)], y1, fmaf(-Lf[tri(2, 0)], y0, q2)) * Ld[2];
+        const float y3 = fmaf(-Lf[tri(3, 2)], y2, fmaf(-Lf[tri(3, 1)], y1, fmaf(-Lf[tri(3, 0)], y0, q3))) * Ld[3];
         const float Mq = fmaf(y3, y3, fmaf(y2, y2, fmaf(y1, y1, y0 * y0)));       // q^T Sigma^-1 q = |L^-1 q|^2
         const float iw = e * fast_rcp(fmaxf(Mq, a.eps));     // the reference normalises w first; the ratio below is scale-free
         acc[10] += iw;

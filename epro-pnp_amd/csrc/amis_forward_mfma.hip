@@ -102,7 +102,9 @@ constexpr int kChunk = 1024;   // points per LDS chunk (32 KiB of point tables)
 
 struct MfmaShape {
   int chunk;     // points per chunk, multiple of 16
-  int s16;       // samples per iteration rounded up to 16
+  int s16;       // rows of the LDS pose table: the samples of an iteration rounded up to 16 -- or, in the SPILL variant, of
+                 // one TILE of an iteration's samples when a whole iteration does not fit LDS (draw -> sweep per tile)
+  int ahead;     // 1: LDS holds the [s][8] buffer for base noise drawn ahead of the proposal fit (0: drawn inline)
 };
 
 // NPT > 0: the workgroup's waves split the POINTS, each wave keeps its NPT point tiles (B operand + residual
@@ -184,13 +186,15 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
   const HuberScale hs = huber_scale(delta);
   const float inv_delta = hs.inv_delta, delta_sq = hs.delta_sq;
 
+  const bool tiled = SPILL && s > s16;          // an iteration's samples go through the pose table in tiles of s16
   AmisCtx cx;
   cx.ptab = ptab; cx.smp = smp; cx.cst = cst; cx.mixl = mixl; cx.lgw = lgw; cx.cpart = SPLIT ? gath : cpart; cx.prop = prop; cx.red = red;
   cx.S = S; cx.K = K; cx.s = s; cx.T = T; cx.tid = tid; cx.b = b; cx.cstride = s16;
-  cx.nzb = (noise == nullptr && W > 1) ? nzb : nullptr;
+  cx.nzb = (noise == nullptr && W > 1 && sh.ahead) ? nzb : nullptr;
   cx.rred = rred;
 
-  for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last tile
+  if (!tiled)
+    for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last pose tile
   if (tid < (DOF == 6 ? 2 : 1))      // 6-DoF: lane 1 fits the translation factor inside lane 0's rotation fit
     initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop, tid);
 #ifdef PNP_TUNING_DOUBLE_INIT    // what one initial fit costs: a second one, on the neighbour's data, into a slot the first refit overwrites
@@ -256,10 +260,16 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
   };
   PNP_PHASE(0);
   for (int it = 0; it < K; ++it) {
+    for (int n0 = 0; n0 < (SPILL ? s : 1); n0 += (SPILL ? s16 : 1)) {        // (exactly one pass unless `tiled`)
+    const int cnt = min(s16, s - n0), cnt16 = (cnt + 15) & ~15;
+    if (tiled) {
+      if (n0 > 0) __syncthreads();              // the previous tile's costs have left cpart, its poses are done with
+      for (int i = tid; i < 12 * (cnt16 - cnt); i += T) ptab[12 * cnt + i] = 0.f;
+    }
 #ifdef PNP_TUNING
     if (!(a.ablate & 32) || it == 0)      // bit5: the sweep re-uses the first iteration's pose table (what the sweep alone costs)
 #endif
-    amis_draw<DOF>(cx, p, a, it, Kc, noise, part == 0 ? pose_samples : nullptr);
+    amis_draw<DOF>(cx, p, a, it, Kc, noise, part == 0 ? pose_samples : nullptr, n0, tiled ? cnt : -1);
 #ifdef PNP_FWD_PRIO_ALL
     serial_phase_priority(false);
 #endif
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
         __syncthreads();
       }
       const int npt = (min(NC, p.N - c0) + 15) >> 4;
-      for (int t = wv; t < (s16 >> 4); t += W) {
+      for (int t = wv; t < (cnt16 >> 4); t += W) {
         const float* arow = ptab + 12 * (t * 16 + col) + kk;
         const float ax = arow[0], ay = arow[4], az = arow[8];
         f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
@@ -316,6 +326,9 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
       }
     }
     __syncthreads();
+    if (tiled)      // this tile's costs -> the (global) cost array; amis_weights is told they are there
+      for (int m = tid; m < cnt; m += T) cst[it * s + n0 + m] = cpart[m];
+    }             // tiles of the iteration
     if (kRegs && SPLIT) {
       // ---- exchange of the partial costs between the G parts of this object (wave_ops.h: xwg_*) ----
       // own row = sum over this workgroup's waves (fixed order) -> global slot [b][it][part][s16] and gath[part]; every
@@ -366,7 +379,8 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
     serial_phase_priority(true);
 #endif
 
-    amis_weights<DOF>(cx, a, it, WPs);
+    if (tiled) __syncthreads();
+    amis_weights<DOF>(cx, a, it, tiled ? 0 : WPs);
     __syncthreads();
     PNP_PHASE(3);
     if (it == K - 1) break;
@@ -506,25 +520,35 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
   k.split_timeout = split_timeout_cycles();
   { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
+  sh.ahead = 1;
   auto lds_bytes = [&](bool spilled) {
     return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (size_t)(PL + 3) * S) +
                             (size_t)(npt ? (G > 1 ? waves + G : waves) : 1) * sh.s16 + (G > 1 ? 4 : 0) + (size_t)K * kPropStride + 256 +
                             kRefitRedFloats +
-                            (s <= 64 * waves ? 0 : 8 * (size_t)s));
+                            ((s <= 64 * waves || !sh.ahead) ? 0 : 8 * (size_t)s));      // (s <= lanes: the noise shares the pose table)
   };
   size_t smem = lds_bytes(false);
   float* spill = nullptr;
   if (smem > 160 * 1024) {
     // the sampler state does not fit LDS: stream the points (NPT = 0, 8 waves) and keep the per-sample arrays in a global
-    // scratch buffer, allocated and released in stream order
+    // scratch buffer, allocated and released in stream order.  If one ITERATION's pose table (48 B per sample) and noise
+    // buffer do not fit either, the noise is drawn inline and, if need be, the iteration's samples go through the table in
+    // tiles (draw -> sweep -> costs to the scratch, per tile): no limit on mc_samples / num_iter (the reference has none,
+    // epropnp.py:55-59)
     waves = 8; npt = 0; G = 1;
     sh.chunk = ((d.N + 15) / 16) * 16;
     if (sh.chunk > kChunk) sh.chunk = kChunk;
     const int tiles = sh.s16 / 16;
     while (waves > 1 && waves > tiles) waves /= 2;
     smem = lds_bytes(true);
-    if (smem > 160 * 1024)
-      return fail(EPROPNP_EINVAL, "amis_forward: %d samples per iteration need %zu B of LDS (> 160 KiB)", s, smem);
+    if (smem > 160 * 1024) {
+      sh.ahead = 0;
+      const size_t fixed = sizeof(float) * (8 * (size_t)sh.chunk + (size_t)K * kPropStride + 256 + kRefitRedFloats);
+      const size_t rows = (160 * 1024 - fixed) / (sizeof(float) * 13);         // 12 pose-table floats + 1 cost per sample
+      if ((size_t)sh.s16 > rows) sh.s16 = (int)(rows / 16) * 16;
+      if (sh.s16 < 16) return fail(EPROPNP_EINVAL, "amis_forward: no LDS left for a pose tile (%d points per chunk)", sh.chunk);
+      smem = lds_bytes(true);
+    }
     if (hipMallocAsync((void**)&spill, sizeof(float) * (size_t)(PL + 3) * S * d.B, st) != hipSuccess) {
       (void)hipGetLastError();
       return fail(EPROPNP_ELAUNCH, "amis_forward: mc_samples %d needs a %zu B scratch buffer and hipMallocAsync failed "

@@ -48,6 +48,10 @@ class EProPnPBase(torch.nn.Module):
     """
 
     dof = None
+    # `layer.check_numerics = True`: monte_carlo_forward / forward raise the reference's RuntimeError (singular normal
+    # equations, non-finite pose: levenberg_marquardt.py:15-19,178-181) from the call that produced it, after ONE host
+    # synchronisation at the end of the call.  Default False: asynchronous report at the next entry into the package.
+    check_numerics = False
 
     def __init__(self, mc_samples=512, num_iter=4, normalize=False, eps=1e-5, solver=None, seed=None):
         super().__init__()
@@ -104,6 +108,9 @@ class EProPnPBase(torch.nn.Module):
         return tuple(torch.empty((self.num_iter, num_obj) + t, dtype=dtype, device=device) for t in tails)
 
     def forward(self, *args, **kwargs):
+        if self.check_numerics and not hip.numerics_check.active():
+            with hip.numerics_check():
+                return self.solver(*args, **kwargs)
         return self.solver(*args, **kwargs)
 
     def _amis_config(self, noise):
@@ -134,6 +141,10 @@ class EProPnPBase(torch.nn.Module):
                  pose_sample_logweights (S,B) [differentiable], cost_init (B,)|None [differentiable].
         """
         assert x3d.dim() == x2d.dim() == w2d.dim() == 3
+        if self.check_numerics and not hip.numerics_check.active() and x3d.size(0) > 0:
+            with hip.numerics_check():
+                return self.monte_carlo_forward(x3d, x2d, w2d, camera, cost_fun, pose_init=pose_init,
+                                                force_init_solve=force_init_solve, noise=noise, **kwargs)
         cam_grad = isinstance(camera.cam_mats, torch.Tensor) and camera.cam_mats.requires_grad
         if torch.is_grad_enabled() and x3d.size(0) > 0 and ((pose_init is not None and pose_init.requires_grad) or cam_grad):
             # The reference's cost_init = evaluate_pnp(pose=pose_init) and its log-weights are recorded by autograd w.r.t.
@@ -148,6 +159,15 @@ class EProPnPBase(torch.nn.Module):
                                                          1.0, 0)[0]
             if cam_grad:        # logweights = -cost(samples) - log mixture: d/d cam_mats through the cost of every sample
                 out[4] = out[4] + hip.pose_cam_grad_term(prob, out[3].detach(), None, camera.cam_mats, -1.0, -1)
+                if kwargs.get('with_pose_opt_plus'):
+                    # the reference's pose_opt_plus (LMSolver.gn_step + pose_add under autograd, levenberg_marquardt.py:70-72,
+                    # 243-265) is differentiable w.r.t. camera.cam_mats as well; the fused Gauss-Newton kernels differentiate
+                    # w.r.t. the correspondences only
+                    import warnings
+                    warnings.warn('EProPnP: camera.cam_mats requires grad and with_pose_opt_plus=True -- pose_opt_plus carries no '
+                                  'gradient to the intrinsics here (cost_init and the log-weights do); compute pose_opt_plus with '
+                                  'solver.pose_add(pose_opt, solver.gn_step(...)) on a pose that requires grad to get the PyTorch '
+                                  'composite', RuntimeWarning, stacklevel=2)
             return tuple(out)
         if self._fusable(x3d, x2d, w2d, pose_init, force_init_solve, kwargs):
             return self._fused_forward(x3d, x2d, w2d, camera, cost_fun, pose_init, force_init_solve, noise, **kwargs)
@@ -252,7 +272,9 @@ class EProPnPBase(torch.nn.Module):
         # w2d as one number per object, which the backward kernel adds in its epilogue -- the node then owes delta nothing,
         # and autograd is spared two elementwise launches and the (B,N,2) add of AccumulateGrad (EPROPNP_DELTA_FOLD=0: off)
         src, fold = getattr(cost_fun, '_delta_src', None), None
-        if src is not None and delta is not None and torch.is_grad_enabled() and w2d.requires_grad \
+        # (delta.requires_grad: a threshold that set_param computed under no_grad is a constant, as in the reference -- nothing
+        # to fold then)
+        if src is not None and delta is not None and delta.requires_grad and torch.is_grad_enabled() and w2d.requires_grad \
                 and os.environ.get('EPROPNP_DELTA_FOLD', '1') != '0' and src[0]() is delta and src[1]() is w2d and not src[4]:
             fold = (src[2], src[3])
             prob.fold_delta(*fold)          # (every backward built on `prob`, pose_opt_plus below included)

@@ -58,6 +58,11 @@ class numerics_check:
     def __init__(self, strict=False):
         self.strict = strict
 
+    @staticmethod
+    def active():
+        """True inside a `with numerics_check():` block of this thread."""
+        return getattr(_status, 'bufs', None) is not None
+
     def __enter__(self):
         self.prev = getattr(_status, 'bufs', None)
         _status.bufs = {}

@@ -24,7 +24,16 @@ def solve_wrapper(b, A):
 
 class LMSolver(nn.Module):
     """Fixed-iteration Levenberg-Marquardt solver.
-    4-DoF pose = [x, y, z, yaw] (yaw about the Y axis); 6-DoF pose = [x, y, z, w, i, j, k] (unit quaternion)."""
+    4-DoF pose = [x, y, z, yaw] (yaw about the Y axis); 6-DoF pose = [x, y, z, w, i, j, k] (unit quaternion).
+
+    `check_numerics` (attribute, not a constructor argument: the reference's signature is kept): set
+    `solver.check_numerics = True` to get the reference's error convention -- a singular / non-finite damped system raises
+    RuntimeError from the very call that produced it, as torch.linalg.solve / torch.inverse do in
+    levenberg_marquardt.py:15-19,178-181 -- at the price of ONE host synchronisation per call.  Default False: the event
+    is reported asynchronously at the next entry into the package (RuntimeWarning, or RuntimeError with
+    EPROPNP_ASYNC_STATUS=raise), and nothing on the path synchronises."""
+
+    check_numerics = False
 
     def __init__(self, dof=4, num_iter=10, min_lm_diagonal=1e-6, max_lm_diagonal=1e32, min_relative_decrease=1e-3,
                  initial_trust_region_radius=30.0, max_trust_region_radius=1e16, eps=1e-5, normalize=False,
@@ -78,6 +87,11 @@ class LMSolver(nn.Module):
               with_cost=False, force_init_solve=False, fast_mode=False):
         """x3d (B,N,3), x2d/w2d (B,N,2) -> pose_opt (B,4|7), pose_cov (B,d,d) | None, cost (B,) | None.
         Runs entirely without autograd."""
+        if self.check_numerics and not hip.numerics_check.active() and x2d.size(0) > 0:
+            with hip.numerics_check():          # raises here, after one synchronisation, what the reference raises here
+                return self.solve(x3d, x2d, w2d, camera, cost_fun, pose_init=pose_init, cost_init=cost_init,
+                                  with_pose_cov=with_pose_cov, with_cost=with_cost, force_init_solve=force_init_solve,
+                                  fast_mode=fast_mode)
         with torch.no_grad():
             num_obj = x2d.size(0)
             pose_len = 4 if self.dof == 4 else 7

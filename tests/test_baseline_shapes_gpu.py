@@ -212,6 +212,14 @@ def test_many_samples_layer_matches_oracle(dev):
     check_6dof_slice(dev, 'S4096', 16, 128, 4096, 4, 3, nslice=16, seed=808, trials=4)
 
 
+def test_many_samples_per_iteration_layer_matches_oracle(dev):
+    """EProPnP6DoF(mc_samples=8192, num_iter=4): 2048 samples per iteration, more than one LDS pose table beside the sampler
+    arrays' global scratch takes at once -- the forward tiles each iteration's samples (draw -> sweep -> costs per tile), the
+    backward takes the all-VALU kernel.  The whole layer, forward and backward, against the oracle on the same injected noise
+    at 16 x 128 (every object)."""
+    check_6dof_slice(dev, 'S8192', 16, 128, 8192, 4, 3, nslice=16, seed=909, trials=3)
+
+
 def c3_training_problem(B, N, seed):
     """LineMOD training shape (EPro-PnP-6DoF/lib/train.py:47-57,163-180): 512 sub-sampled correspondences of a 64x64
     crop, per-object tensor bounds = crop box -/+ 30 output pixels, z_min = 0.01, relative_delta = 0.1."""

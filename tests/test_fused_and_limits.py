@@ -168,6 +168,40 @@ def test_numerics_check_reports_what_the_reference_raises(backend):
             F.amis_forward(F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6), po, cov, 32, 2, seed=1)
 
 
+def test_check_numerics_attribute_raises_at_the_call(backend):
+    """`solver.check_numerics = True` / `layer.check_numerics = True`: the reference's error convention without an environment
+    variable -- torch.linalg.solve / torch.inverse raise inside LMSolver.solve (levenberg_marquardt.py:15-19,178-181), so the
+    RuntimeError comes out of the call that produced the singular system (one synchronisation), for the solver called on its
+    own, through EProPnP6DoF.forward and through monte_carlo_forward; healthy inputs pass and nothing is left pending."""
+    import warnings
+    from epropnp import functional as F
+    from epropnp.epropnp import EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver
+    B, N = 5, 40
+    prob = orc.make_problem(B, N, 6, seed=18)
+    p, cam, cf = make_layer_objects(prob, backend)
+    bad = p['x3d'].clone()
+    bad[3, 5, 1] = float('nan')
+    assert LMSolver.check_numerics is False and EProPnP6DoF.check_numerics is False          # opt-in
+    solver = LMSolver(dof=6, num_iter=3)
+    solver.check_numerics = True
+    solver.solve(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], with_pose_cov=True)
+    with pytest.raises(RuntimeError, match='object 3'):
+        solver.solve(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])
+    layer = EProPnP6DoF(mc_samples=32, num_iter=2, solver=LMSolver(dof=6, num_iter=3))
+    layer.check_numerics = True
+    layer(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])
+    with pytest.raises(RuntimeError, match='singular or not finite'):
+        layer(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'])
+    out = layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], force_init_solve=False)
+    assert bool(torch.isfinite(out[4]).all())
+    with pytest.raises(RuntimeError, match='object 3'):
+        layer.monte_carlo_forward(bad, p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], force_init_solve=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        F.flush_status()                  # the checked calls reported into their own status word: nothing pending
+
+
 def test_lm_and_normal_equations_beyond_the_resident_limit(backend):
     """N = 8300 > 8192 points per object: the LM solve and the normal-equation sweep stream the points instead of
     refusing (the reference accepts any N)."""
@@ -294,6 +328,40 @@ def _delta_fold_case(dev, monkeypatch, dof, B, N, S, K, bounds, normalize, nspli
     o = layer.monte_carlo_forward(*leaves, cam, cf, pose_init=p['pose_init'], force_init_solve=False, noise=noise)
     monte_carlo_pose_loss(o[4], o[5]).sum().backward()
     assert ((leaves[2].grad.cpu() - gw_b).abs() / scale).max().item() > 1e-4
+
+
+def test_delta_computed_without_grad_is_a_constant(backend, monkeypatch):
+    """AdaptiveHuberPnPCost.set_param(x2d, w2d) under torch.no_grad(): delta is a constant, the reference sends no gradient
+    through it.  A later monte_carlo_forward with grad enabled on the SAME w2d must not fold d delta / d w2d into grad_w2d:
+    same gradients as with an explicitly detached w2d in set_param."""
+    from epropnp import functional as F
+    from epropnp.cost_fun import AdaptiveHuberPnPCost
+    from epropnp.epropnp import EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver
+    from epropnp.losses import monte_carlo_pose_loss
+    B, N, S, K = 4, 80, 32, 2
+    prob = orc.make_problem(B, N, 6, seed=15)
+    noise = pack_noise(orc.make_noise(B, S, K, 6, seed=16), 6).to(backend)
+    p, cam, _ = make_layer_objects(prob, backend, relative_delta=0.5)
+    layer = EProPnP6DoF(mc_samples=S, num_iter=K, solver=LMSolver(dof=6, num_iter=3))
+    seen, real = [], F.PnPProblem.fold_delta
+    monkeypatch.setattr(F.PnPProblem, 'fold_delta', lambda self, *a: (seen.append(True), real(self, *a))[1])
+    grads = []
+    for mode in ('no_grad', 'detached'):
+        cf = AdaptiveHuberPnPCost(relative_delta=0.5)
+        leaves = [p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d')]
+        if mode == 'no_grad':
+            with torch.no_grad():
+                cf.set_param(leaves[1], leaves[2])
+        else:
+            cf.set_param(leaves[1].detach(), leaves[2].detach())
+        assert not cf.delta.requires_grad
+        o = layer.monte_carlo_forward(*leaves, cam, cf, pose_init=p['pose_init'], force_init_solve=False, noise=noise)
+        monte_carlo_pose_loss(o[4], o[5]).sum().backward()
+        grads.append([t.grad.detach().cpu() for t in leaves])
+    assert seen == []
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('dof,B,N,S,K,bounds,normalize', [(6, 5, 96, 32, 2, None, False), (4, 4, 70, 48, 3, 'tensor', True)])

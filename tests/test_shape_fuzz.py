@@ -136,10 +136,33 @@ def test_sampler_state_beyond_lds(backend, poisoned_empty):
     _check(backend, 6, 1, 24, 4800, 8, None, True, 0.1, 777)
 
 
+@pytest.mark.parametrize('dof,S,K', [(6, 8192, 4), (4, 3700, 1)])
+def test_samples_per_iteration_beyond_lds(backend, poisoned_empty, dof, S, K):
+    """More samples PER ITERATION than one LDS pose table holds (48 B per sample: ~3000 beside the point chunks; the reference
+    has no limit, epropnp.py:55-59): an iteration's samples go through the table in tiles -- draw, sweep, costs to the global
+    scratch, per tile.  EProPnP6DoF(mc_samples=8192, num_iter=4) used to be EINVAL."""
+    _check(backend, dof, 1, 24, S, K, None, True, 0.1, 99 + S)
+    # production mode (on-device Philox instead of injected draws: the base noise is then drawn inline, there is no room for
+    # the ahead-of-time buffer): log-weights against the oracle's cost + mixture density at the kernel's own samples
+    from epropnp import functional as F
+    prob = orc.make_problem(1, 24, dof, seed=5)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 5, with_pose_cov=True)
+    samples, logw, props = (t.cpu() for t in F.amis_forward(hp, pose_opt, pose_cov, S, K, seed=3, with_proposals=True))
+    assert bool(torch.isfinite(samples).all())
+    cost = orc.evaluate(prob['x3d'].double(), prob['x2d'].double(), prob['w2d'].double(), samples.double(),
+                        orc.Cam(prob['cam_mats'].double(), 0.1), prob['delta'].double(), want_cost=True)[1]
+    expect = -cost.float() - _mixture_logq(samples, props, dof, K)
+    assert (logw - expect).abs().max().item() <= 2e-4 * max(1.0, expect.abs().max().item())
+    assert len(torch.unique(samples[:, 0, 0])) > S // 2                  # fresh draws for every sample of every tile
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('dof,B,N,S,K', [(6, 2, 64, 2048, 4), (4, 2, 100, 2400, 3), (6, 1, 40, 1024, 1), (6, 2, 33, 2400, 4),
                                          (4, 3, 512, 1536, 2), (6, 3, 700, 2048, 4), (6, 2, 50, 3200, 16),
-                                         (6, 2, 64, 4096, 4), (6, 3, 300, 6000, 4), (4, 2, 100, 4000, 4), (6, 1, 2100, 3000, 2)])
+                                         (6, 2, 64, 4096, 4), (6, 3, 300, 6000, 4), (4, 2, 100, 4000, 4), (6, 1, 2100, 3000, 2),
+                                         (6, 2, 1100, 16384, 4), (4, 2, 200, 12000, 2), (6, 1, 40, 9000, 1)])
 def test_many_samples_gpu(poisoned_empty, dof, B, N, S, K):
     """... up to and beyond the LDS limit of the sampler state (6-DoF: 40 S + 96 S / K bytes + 2 KiB <= 160 KiB; past it
     the state moves to a global scratch buffer)."""
