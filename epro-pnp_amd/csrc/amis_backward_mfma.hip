@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
                                                                      const float* __restrict__ g_init, int P16,
                                                                      float* __restrict__ gx3d, float* __restrict__ gx2d,
                                                                      float* __restrict__ gw2d, float* __restrict__ gdelta,
-                                                                     int nsplit, float drop_eps) {
+                                                                     int nsplit, float drop_eps, int gw_rows) {
   constexpr int PL = PoseLen<DOF>::value;
   // nsplit > 1 (few objects): an object's point chunks are dealt to nsplit workgroups (v = b * nsplit + part), each with
   // its own copy of the pose table; per-point gradients are disjoint, grad_delta comes out as nsplit partials per object
@@ -57,6 +57,11 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   int* idx = reinterpret_cast<int*>(wraw + P16);        // [P16]      sample index of compacted pose c
   float* red = reinterpret_cast<float*>(idx + P16);     // [80]       reductions, lane counts, active count
   float* hist = red + 80;                               // [kDropHistFloats] weight histogram of the drop threshold
+  // [gw_rows][2] this object's grad_w2d, parked until the threshold's gradient (one number per object, known only after the
+  // last chunk) can be added on the way out: the fold below then costs no second pass over grad_w2d in global memory
+  float* gwl = hist + kDropHistFloats;
+  const bool fold = (p.delta_stats != nullptr) && (nsplit == 1);
+  const bool park = fold && (gw_rows >= p.N);
 
   float Kc[9], delta;
   Bounds bd;
@@ -201,13 +206,20 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
           const float s2 = fmaf(rx, rx, ry * ry);
           const float rs = fast_rsqrt(fmaxf(s2, 1e-30f));
 #endif
+#ifdef PNP_BWD_OLD_COEF
           const float rho = s2 * rs;
           const float mm = sat_mul(rho, one_v);                // min(rho, delta) / delta
           const float coef = aw[r] * mm * rs;                  // a * min(1, delta / rho)
-          // d huber / d delta = max(rho - delta, 0) (/ delta).  The compiler contracts rho - mm with rho = s2 * rs into
-          // fma(s2, rs, -mm): for an inlier that is the rounding error of the product (<= ulp(rho) / 2), not exactly 0 as in
-          // the reference -- noise at the 1e-7 level of sum |a| rho; an un-fused subtract costs 2 % of this kernel
           gd = fmaf(aw[r], rho - mm, gd);
+#else
+          // Huber weight min(1, delta / rho) = min(1, rs) straight from the reciprocal norm (rho * rs = 1): ONE clamped
+          // multiply where rho, min(rho, 1) and their product with rs took three.  d huber / d delta = max(rho - delta, 0)
+          // (/ delta) = rho (1 - c1): exactly 0 for an inlier (c1 = 1), as in the reference.
+          const float c1 = sat_mul(rs, one_v);
+          const float coef = aw[r] * c1;
+          const float rho = s2 * rs;
+          gd = fmaf(aw[r], fmaf(-rho, c1, rho), gd);
+#endif
           const float crx = coef * rx, cry = coef * ry;
           // d/dw = crx * (px - u) = crx * rx / w and d/du = -crx * w: the per-point factors are applied once at the end
           A2x[i] = fmaf(crx, rx, A2x[i]);
@@ -252,7 +264,9 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
           const size_t o = (size_t)b * p.N + n;
           if (col < 3) gx3d[o * 3 + col] = D1[r];
           if (col < 2) gx2d[o * 2 + col] = D2[r];
-          else if (col < 4) gw2d[o * 2 + (col - 2)] = D2[r];
+          else if (col < 4) {
+            if (park) gwl[n * 2 + (col - 2)] = D2[r]; else gw2d[o * 2 + (col - 2)] = D2[r];
+          }
         }
       }
     }
@@ -263,11 +277,15 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   // delta = mean(w2d) * std * rel came from THIS w2d (Problem.delta_stats): its gradient reaches w2d as one number per
   // object, added here to what this workgroup has just written instead of by three launches of the caller's autograd.
   // (With the object split over workgroups the sum of the parts is not known here: delta_path_kernel, amis_kernels.hip.)
-  if (p.delta_stats != nullptr && nsplit == 1) {
+  if (fold) {
     const float add = (one[0] * p.delta_stats[(size_t)b * 4 + 1]) * (p.delta_relative / (2.0f * (float)p.N));
-    __syncthreads();        // this workgroup's gw2d stores are visible to all of its threads behind the barrier
+    __syncthreads();        // this workgroup's gw2d values (LDS or global) are visible to all of its threads behind the barrier
     float* row = gw2d + (size_t)b * p.N * 2;
-    for (int i = tid; i < 2 * p.N; i += T) row[i] += add;
+    if (park) {
+      for (int i = tid; i < 2 * p.N; i += T) row[i] = gwl[i] + add;       // the only pass over grad_w2d, coalesced
+    } else {                // (no LDS left for the rows: read back what was just written)
+      for (int i = tid; i < 2 * p.N; i += T) row[i] += add;
+    }
   }
 }
 
@@ -288,8 +306,15 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
   const Problem d = to_device_problem(prob);
   const int P = mc_samples + ((pose_init && grad_cost_init) ? 1 : 0);
   const int P16 = ((P + 15) / 16) * 16 + 16;
-  const size_t smem = sizeof(float) * (15 * (size_t)P16 + 80 + kDropHistFloats);
+  size_t smem = sizeof(float) * (15 * (size_t)P16 + 80 + kDropHistFloats);
   if (smem > 160 * 1024) return 1;
+  // grad_w2d rows parked in LDS while the threshold's gradient is folded in (kernel comment): when the fold applies and the
+  // rows fit next to three workgroups' pose tables per CU
+  int gw_rows = 0;
+  if (prob->delta_stats != nullptr && nsplit == 1 && 3 * (smem + sizeof(float) * 2 * (size_t)d.N) <= 160 * 1024) {
+    gw_rows = d.N;
+    smem += sizeof(float) * 2 * (size_t)d.N;
+  }
   // 4 waves x NPT <= 4 point tiles of 16 per chunk (<= 164 VGPRs: 3 workgroups per CU); larger N loops over chunks of
   // 256 points against the LDS-resident pose table.  Measured at C2: 4x4 (2 chunks) 1.07 ms, 4x8 1.11, 8x4 1.22.
   // Few objects (fewer than two waves per SIMD otherwise): 8 waves, one chunk of 512 points (B = 32 / 256: -7..9 %).
@@ -305,12 +330,9 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     return dispatch_bwd_npt(npt, [&](auto NPT) -> int {
       auto kern = amis_backward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
-#ifndef EPROPNP_EMU
-      if (smem > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
+      allow_dynamic_lds((const void*)kern, smem);
       PNP_LAUNCH(kern, grid, block, smem, st, d, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init, P16,
-                 grad_x3d, grad_x2d, grad_w2d, grad_delta, nsplit, backward_drop_eps());
+                 grad_x3d, grad_x2d, grad_w2d, grad_delta, nsplit, backward_drop_eps(), gw_rows);
       return 0;
     });
   });
