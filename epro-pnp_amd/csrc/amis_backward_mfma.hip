@@ -21,16 +21,6 @@
 
 namespace pnp {
 
-#ifndef EPROPNP_EMU
-typedef float bwd_floatx4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bwd_floatx4 bwd_mfma(float a, float b, bwd_floatx4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-#else
-typedef floatx4_emu bwd_floatx4;
-__device__ __forceinline__ bwd_floatx4 bwd_mfma(float a, float b, bwd_floatx4 c) { return emu::mfma_16x16x4(a, b, c); }
-#endif
-
 #ifndef PNP_BWD_MINW
 #define PNP_BWD_MINW 3
 #endif
@@ -163,7 +153,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
       A1x[i] = A1y[i] = A2x[i] = A2y[i] = 0.f;
       gXv[i] = gYv[i] = gZv[i] = 0.f;
     }
-    const bwd_floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < ntile; ++t) {
       const float* arow = ptab + 12 * (t * 16 + col) + kk;
       const float ax = arow[0], ay = arow[4], az = arow[8];
@@ -177,9 +167,9 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
       }
 #pragma unroll
       for (int i = 0; i < NPT; ++i) {
-        const bwd_floatx4 hx = bwd_mfma(ax, rB[i], zero);
-        const bwd_floatx4 hy = bwd_mfma(ay, rB[i], zero);
-        const bwd_floatx4 hz = bwd_mfma(az, rB[i], zero);
+        const floatx4 hx = mfma_16x16x4(ax, rB[i], zero);
+        const floatx4 hy = mfma_16x16x4(ay, rB[i], zero);
+        const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
         const float4 w4 = rW[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -246,16 +236,16 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
     // ---- outputs of this chunk: sums over the 4 pose groups of a point via MFMAs against indicator columns ----
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-      bwd_floatx4 D1 = zero;
-      D1 = bwd_mfma(gXv[i] * hs.delta_sq, ind0, D1);
-      D1 = bwd_mfma(gYv[i] * hs.delta_sq, ind1, D1);
-      D1 = bwd_mfma(gZv[i] * hs.delta_sq, ind2, D1);
+      floatx4 D1 = zero;
+      D1 = mfma_16x16x4(gXv[i] * hs.delta_sq, ind0, D1);
+      D1 = mfma_16x16x4(gYv[i] * hs.delta_sq, ind1, D1);
+      D1 = mfma_16x16x4(gZv[i] * hs.delta_sq, ind2, D1);
       const float4 w4 = rW[i];
-      bwd_floatx4 D2 = zero;
-      D2 = bwd_mfma(-w4.x * A1x[i] * hs.delta_sq, ind0, D2);                            // d/du
-      D2 = bwd_mfma(-w4.y * A1y[i] * hs.delta_sq, ind1, D2);                            // d/dv
-      D2 = bwd_mfma((w4.x != 0.f) ? A2x[i] * hs.delta / w4.x : 0.f, ind2, D2);          // d/dwu
-      D2 = bwd_mfma((w4.y != 0.f) ? A2y[i] * hs.delta / w4.y : 0.f, ind3, D2);          // d/dwv
+      floatx4 D2 = zero;
+      D2 = mfma_16x16x4(-w4.x * A1x[i] * hs.delta_sq, ind0, D2);                            // d/du
+      D2 = mfma_16x16x4(-w4.y * A1y[i] * hs.delta_sq, ind1, D2);                            // d/dv
+      D2 = mfma_16x16x4((w4.x != 0.f) ? A2x[i] * hs.delta / w4.x : 0.f, ind2, D2);          // d/dwu
+      D2 = mfma_16x16x4((w4.y != 0.f) ? A2y[i] * hs.delta / w4.y : 0.f, ind3, D2);          // d/dwv
       const int nb = c0 + (wv + W * i) * 16 + g4;     // D rows: points nb + r; column = lane & 15
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

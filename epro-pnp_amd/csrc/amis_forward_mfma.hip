@@ -17,20 +17,6 @@
 
 namespace pnp {
 
-#ifndef EPROPNP_EMU
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-#else
-typedef floatx4_emu floatx4;
-#endif
-
-__device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
-#ifndef EPROPNP_EMU
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#else
-  return emu::mfma_16x16x4(a, b, c);
-#endif
-}
-
 #ifdef PNP_TUNING
 // tuning builds: shader-clock cycles per phase (initial fit+load | draw | sweep | weights | refit | store), summed over
 // workgroups by thread 0 of each; read back through epropnp_tuning_phase_cycles (c_api.hip).
@@ -47,18 +33,10 @@ __device__ unsigned long long g_fwd_phase[8];
 #define PNP_PHASE(i)
 #endif
 
-// Two point-poses at a time, written on 2-vectors so that the multiplies / FMAs become v_pk_mul_f32 / v_pk_fma_f32.
-// Packed ops run at the scalar flop rate on gfx950, but the transcendental ops between them (rcp, sqrt) then cost
-// ~3 ns instead of ~5.6 ns per wave (tools/ubench: "2 trans : 6 pk_fma" vs "2 trans : 6 fma") -- a fifth of this loop.
-#ifndef EPROPNP_EMU
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-#else
-typedef float f32x2 __attribute__((vector_size(8)));
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
-  return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
-}
-#endif
+// Two point-poses at a time, written on 2-vectors (wave_ops.h: f32x2, fma2) so that the multiplies / FMAs become
+// v_pk_mul_f32 / v_pk_fma_f32.  Packed ops run at the scalar flop rate on gfx950, but the transcendental ops between them
+// (rcp, sqrt) then cost ~3 ns instead of ~5.6 ns per wave (tools/ubench: "2 trans : 6 pk_fma" vs "2 trans : 6 fma") -- a
+// fifth of this loop.
 
 // Huber costs of the 4 poses a lane holds for one point (MFMA outputs hx, hy, hz) added to acc2 = {poses 0,1}, {2,3}
 // The weights in w4 (and those folded into hx, hy) are pre-divided by the object's Huber threshold delta, so the

@@ -263,11 +263,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
         n0 = rn[0]; n1 = rn[1]; n2 = rn[2]; n3 = rn[3];
       }
       const float a = r3.x;
-#ifndef EPROPNP_EMU
-      if (__builtin_amdgcn_readfirstlane(__float_as_int(a)) == 0) continue;   // exact zero weight (wave-uniform)
-#else
-      if (a == 0.f) continue;
-#endif
+      if (uniform_is_zero(a)) continue;       // exact zero weight (wave-uniform)
       const float kr[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
       const float kt[3] = {r2.y, r2.z, r2.w};
 #pragma unroll
@@ -383,10 +379,7 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   const dim3 grid(padded_object_grid(d.B)), block(64 * WS * WP);
   dispatch_shape(prob->dof, ppl, has_bounds(prob), WS * WP, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     auto kern = amis_forward_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>;
-#ifndef EPROPNP_EMU
-    if (smem > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
+    allow_dynamic_lds((const void*)kern, smem);
     PNP_LAUNCH(kern, grid, block, smem, st, d, k, pose_opt, pose_cov, noise, pose_samples, logweights, proposals);
     return 0;
   });

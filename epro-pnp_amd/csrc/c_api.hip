@@ -17,7 +17,6 @@ char* last_error_buffer() {
 }
 
 // ---- per-stage HIP-event timing ------------------------------------------------------------------------------------
-#ifndef EPROPNP_EMU
 namespace {
 struct StageRec { const char* stage; hipEvent_t e0, e1; bool closed; };
 std::mutex g_prof_mu;
@@ -54,10 +53,6 @@ void profile_end(hipStream_t st) {
   for (size_t i = g_prof.size(); i-- > 0;)
     if (!g_prof[i].closed) { (void)hipEventRecord(g_prof[i].e1, st); g_prof[i].closed = true; break; }
 }
-#else
-bool profile_begin(const char*, hipStream_t) { return false; }
-void profile_end(hipStream_t) {}
-#endif
 }  // namespace pnp
 
 namespace pnp {
@@ -77,12 +72,9 @@ int32_t* default_status_word() {
   }
   if (g_status_mode == 0) return nullptr;
   int dev = 0;
-#ifndef EPROPNP_EMU
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-#endif
   int32_t* w = __atomic_load_n(&g_status_words[dev], __ATOMIC_ACQUIRE);
   if (w != nullptr) return w;
-#ifndef EPROPNP_EMU
   // may be the first call of a process that is already capturing a graph: a host allocation is not a stream operation,
   // relax the thread's capture mode around it
   hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
@@ -92,18 +84,11 @@ int32_t* default_status_word() {
   (void)hipThreadExchangeStreamCaptureMode(&mode);
   if (rc != hipSuccess) { (void)hipGetLastError(); g_status_mode = 0; return nullptr; }
   w = (int32_t*)mem;
-#else
-  w = (int32_t*)malloc(2 * sizeof(int32_t));
-#endif
   w[0] = 0;
   w[1] = INT32_MAX;
   int32_t* expected = nullptr;
   if (!__atomic_compare_exchange_n(&g_status_words[dev], &expected, w, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
-#ifndef EPROPNP_EMU
     (void)hipHostFree(w);
-#else
-    free(w);
-#endif
     w = expected;
   }
   return w;
@@ -327,21 +312,15 @@ int epropnp_prepare_dense_backward(const float* noc_map, const float* dim, const
 }
 
 int epropnp_profile_enable(int on) {
-#ifndef EPROPNP_EMU
   std::lock_guard<std::mutex> lk(pnp::g_prof_mu);
   if (on) pnp::fill_pool(8192);        // 4096 stage launches before anything is created inside a timed region
   pnp::g_prof_on = on != 0;
-#else
-  (void)on;
-#endif
   return EPROPNP_OK;
 }
 
 int epropnp_profile_reset(void) {
-#ifndef EPROPNP_EMU
   std::lock_guard<std::mutex> lk(pnp::g_prof_mu);
   pnp::drop_records();
-#endif
   return EPROPNP_OK;
 }
 
@@ -349,7 +328,6 @@ int epropnp_profile_read(const char* stage, float* mean_ms, int32_t* count) {
   if (!stage || !mean_ms || !count) return pnp::fail(EPROPNP_EINVAL, "profile_read: NULL argument");
   *mean_ms = 0.f;
   *count = 0;
-#ifndef EPROPNP_EMU
   std::lock_guard<std::mutex> lk(pnp::g_prof_mu);
   double sum = 0.0;
   for (auto& r : pnp::g_prof) {
@@ -361,7 +339,6 @@ int epropnp_profile_read(const char* stage, float* mean_ms, int32_t* count) {
     ++*count;
   }
   if (*count > 0) *mean_ms = (float)(sum / *count);
-#endif
   return EPROPNP_OK;
 }
 

@@ -354,12 +354,7 @@ __global__ __launch_bounds__(1024) void mc_loss_reduce_kernel(const float* __res
   if (threadIdx.x == 0) {
     float n = (nf != nullptr) ? nf[0] : 1.0f;
     if (nf != nullptr && nf_in != nullptr) {
-#ifndef EPROPNP_EMU
-      n = __fadd_rn(__fmul_rn(n, one_minus_m), __fmul_rn(m, nf_in[0]));
-#else
-      const volatile float a = n * one_minus_m, c2 = m * nf_in[0];
-      n = a + c2;
-#endif
+      n = add_unfused(mul_unfused(n, one_minus_m), mul_unfused(m, nf_in[0]));       // the reference's two roundings
       nf[0] = n;
     }
     const float c = scale / n;
@@ -625,16 +620,7 @@ struct PrepLayout {
 
 // begin + index * unit with TWO roundings, as the reference's separate torch mul and add (HIP's __fmul_rn is a plain `*`
 // that -ffp-contract=fast fuses with the add)
-__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
-#ifndef EPROPNP_EMU
-#pragma clang fp contract(off)
-  const float m = a * b;
-  return c + m;
-#else
-  volatile float m = a * b;
-  return c + m;
-#endif
-}
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) { return add_unfused(c, mul_unfused(a, b)); }
 
 __device__ __forceinline__ float2 prep_ld2(const float* src, int b, int n, int N, const PrepLayout& L) {
   if (L.inds == nullptr) return reinterpret_cast<const float2*>(src)[(size_t)b * N + n];
@@ -850,14 +836,9 @@ int launch_prepare_dense_backward(const float* noc_map, const float* dim, const 
     return fail(EPROPNP_EINVAL, "prepare_dense_backward: bad argument");
   const PrepLayout L = {inds, H * W, W};
   const size_t plane = (size_t)H * W * sizeof(float);
-#ifndef EPROPNP_EMU
   if (launch_fill_u32(glogit_map, 0u, (size_t)B * 2 * plane / 4, st) != EPROPNP_OK) return fail(EPROPNP_ELAUNCH, "prepare_dense_backward: memset");
   if (gx3d != nullptr && launch_fill_u32(gnoc_map, 0u, (size_t)B * 3 * plane / 4, st) != EPROPNP_OK)
     return fail(EPROPNP_ELAUNCH, "prepare_dense_backward: memset");
-#else
-  memset(glogit_map, 0, (size_t)B * 2 * plane);
-  if (gx3d != nullptr) memset(gnoc_map, 0, (size_t)B * 3 * plane);
-#endif
   PNP_LAUNCH(prepare_backward_kernel, dim3(padded_object_grid(B)), dim3(prepare_threads(N)), 0, st, noc_map, dim, logit_map,
              scale, L, stats, gx3d, gw2d, B, N, mode, gnoc_map, gdim, glogit_map, gscale);
   return check_launch("prepare_backward_kernel (dense)");

@@ -24,6 +24,31 @@ namespace pnp {
 // fast reciprocal / rsqrt for the VALU-bound AMIS sweeps (1 ulp hardware approximations);
 // the LM path uses IEEE division and sqrtf.
 // ---------------------------------------------------------------------------------------------------
+// a product / a sum that the compiler must NOT contract into an fma with its neighbours (results pinned to the reference's
+// separately rounded operations: the running norm_factor, the pixel grid of the dense pre-processing).  Contraction needs the
+// `contract` flag on BOTH operations; the pragma keeps it off the one formed here (HIP's __fmul_rn / __fadd_rn are plain
+// operators that -ffp-contract=fast still fuses).
+PNP_FN float mul_unfused(float a, float b) {
+#ifndef EPROPNP_EMU
+#pragma clang fp contract(off)
+  const float m = a * b;
+  return m;
+#else
+  volatile float m = a * b;
+  return m;
+#endif
+}
+PNP_FN float add_unfused(float a, float b) {
+#ifndef EPROPNP_EMU
+#pragma clang fp contract(off)
+  const float m = a + b;
+  return m;
+#else
+  volatile float m = a + b;
+  return m;
+#endif
+}
+
 PNP_FN float fast_rcp(float x) {
 #ifndef EPROPNP_EMU
   return __builtin_amdgcn_rcpf(x);

@@ -332,21 +332,19 @@ __global__ __launch_bounds__(256) void rslm_reduce_kernel(const float* __restric
 // out the two-or-three-workgroups-per-CU quantisation (600 x 64: 71 -> 63 us); beyond that the per-workgroup staging of the
 // points costs more than the balance gains.  EPROPNP_RSLM_PARTS=<n> overrides.
 static int rslm_parts(int B, int P) {
-  int best = (B <= 256) ? 4 : (B <= 768 ? 2 : 1);
+  const int cus = device_cu_count();         // (256 on an MI355X; the thresholds scale with a partitioned device)
+  int best = (B <= cus) ? 4 : (B <= 3 * cus ? 2 : 1);
+  if (cus < 16) best = 1;                    // nothing to balance over (the tests' one-CU CPU emulation)
   while (best > 1 && P % (kRslmRows * best) != 0) best >>= 1;
   { int ov[1]; if (env_ints("EPROPNP_RSLM_PARTS", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4) && P % (kRslmRows * ov[0]) == 0) best = ov[0]; }
   return best;
 }
 
 unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int P) {
-#ifdef EPROPNP_EMU
-  return 0;
-#else
   if (prob == nullptr || prob->num_obj <= 0 || P < 1) return 0;
   const int q = rslm_parts(prob->num_obj, P);
   const int PL = prob->dof == 6 ? 7 : 4;
   return q > 1 ? sizeof(float) * (unsigned long long)q * prob->num_obj * (PL + 1) : 0;
-#endif
 }
 
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
@@ -371,12 +369,9 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
   k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps; k.split_timeout = 0;
   const int Np = (d.N + 3) & ~3;
   const size_t smem = sizeof(float) * ((size_t)(7 + kRslmRows) * Np + 128);
-  int parts = 1;
-#ifndef EPROPNP_EMU
-  parts = rslm_parts(d.B, P);
+  int parts = rslm_parts(d.B, P);
   const int PLh = prob->dof == 6 ? 7 : 4;
   if (parts > 1 && (scratch == nullptr || scratch_bytes < sizeof(float) * (size_t)parts * d.B * (PLh + 1))) parts = 1;
-#endif
   const dim3 grid(padded_object_grid(d.B * parts)), block(256);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     PNP_LAUNCH((rslm_solve_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, smem, st, d, k, P, n_pts, seed,

@@ -157,6 +157,29 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
   return ab < cd ? ab : cd;
 }
 
+// ---- matrix core and packed-pair primitives (the AMIS sweeps) ------------------------------------------------------
+// v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) B(4x16) + C, exact f32 (a k-ordered fmaf chain).  Lane l holds A[l&15][l>>4],
+// B[l>>4][l&15] and D[4*(l>>4)+r][l&15], r = 0..3.
+#ifndef EPROPNP_EMU
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// two point-poses at a time on 2-vectors, so that the multiplies / FMAs become v_pk_mul_f32 / v_pk_fma_f32
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// exact-zero test of a wave-uniform float without a vector compare
+__device__ __forceinline__ bool uniform_is_zero(float a) { return __builtin_amdgcn_readfirstlane(__float_as_int(a)) == 0; }
+#else
+typedef floatx4_emu floatx4;
+typedef float f32x2 __attribute__((vector_size(8)));
+__device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) { return emu::mfma_16x16x4(a, b, c); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
+  return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+}
+__device__ __forceinline__ bool uniform_is_zero(float a) { return a == 0.f; }
+#endif
+
 // ---- words exchanged between the workgroups of ONE launch (the split-over-workgroups variants of the AMIS forward and
 // the LM solve) ------------------------------------------------------------------------------------------------------
 // A slot is pre-filled with kXwgEmpty by the launcher; its producer overwrites it with the payload (never kXwgEmpty: NaNs

@@ -47,6 +47,19 @@ inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 1; return 0; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
 inline hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
 inline hipError_t hipFreeAsync(void* p, hipStream_t) { std::free(p); return 0; }
+// host-mapped memory of the default status word: plain host memory here; graph-capture modes do not exist
+enum { hipHostMallocMapped = 1, hipHostMallocCoherent = 2 };
+typedef int hipStreamCaptureMode;
+enum { hipStreamCaptureModeRelaxed = 2 };
+inline hipError_t hipThreadExchangeStreamCaptureMode(hipStreamCaptureMode*) { return 0; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return 0; }
+// events (per-stage timing inside the library): recorded, never timed -- every stage reads 0 ms
+typedef int hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 
 namespace emu {
 

@@ -382,7 +382,10 @@ def check_c3_dense(dev, B, N, S, K, L, rslm):
         run = lambda q, dt=None: orc.run_mc(q, noise, 6, S, K, L, relative_delta=0.1, dtype=dt, **kw)
     base = run(prob)
     o64 = {k: v.float() for k, v in run(prob, torch.float64).items()}
-    spread = orc.rounding_spread(run, prob, base, trials=4, extra=[o64])
+    # (8 perturbed runs: the yardstick is a MAXIMUM over samples of the reference's own rounding sensitivity, and at this shape
+    # -- z_min 0.01, relative_delta 0.1, 4096 points -- a third of the objects have gradients that the fp32 reference itself
+    # only knows to 1e-3 ... 0.7 relative, see the tie-break record; four samples under-estimate such a maximum)
+    spread = orc.rounding_spread(run, prob, base, trials=8, extra=[o64])
     compare_with_oracle(name, got, base, spread, B, o64)
     if rslm:
         assert_within_spread((got['pose_opt_plus'] - base['pose_opt_plus']).abs().max(-1).values, spread['pose_opt_plus'],
