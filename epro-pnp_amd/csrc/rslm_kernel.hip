@@ -45,8 +45,17 @@ int tuning_rslm_phase_cycles(unsigned long long* out, int reset) {
 #define PNP_RSLM_PHASE(i)
 #endif
 
+// PNP_RSLM_MINW4: waves per SIMD the 4-DoF instantiation is compiled for (0: whatever its registers allow -- 115 VGPRs, 4 waves)
+#ifndef PNP_RSLM_MINW4
+#define PNP_RSLM_MINW4 0
+#endif
 template <int DOF, bool BOUNDS>
-__global__ __launch_bounds__(256) void rslm_solve_kernel(Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
+#if PNP_RSLM_MINW4
+__global__ __launch_bounds__(256, (DOF == 4 ? PNP_RSLM_MINW4 : 3)) void rslm_solve_kernel(
+#else
+__global__ __launch_bounds__(256) void rslm_solve_kernel(
+#endif
+Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
                                                           unsigned long long offset_in,
                                                           const unsigned long long* __restrict__ offset_dev,
                                                           const long long* __restrict__ inds,
