@@ -227,6 +227,12 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
         const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
         huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, one_v, bd, acc2);
       }
+      // the four poses' sums over this row's 16 points: lane col < 4 ends up with pose g4 + col (wave_ops.h: row_sum16_of4)
+#ifndef PNP_FWD_ROWSUM_OLD
+      const float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
+      const float tot = row_sum16_of4(acc);
+      if (col < 4) cpart[wv * s16 + t * 16 + g4 + col] = tot * delta_sq;
+#else       // tuning variant: four full row sums (16 DPP adds), lane 0 of the row stores
       float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
 #pragma unroll
         for (int r = 0; r < 4; ++r) cpart[wv * s16 + t * 16 + g4 + r] = acc[r] * delta_sq;
       }
+#endif
     }
   };
   PNP_PHASE(0);
@@ -291,15 +298,11 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
           huber_cost_4<BOUNDS>(hx, hy, hz, w4, zmin_v, one_v, bd, acc2);
           hx = hxn; hy = hyn; hz = hzn; w4 = wn;
         }
-        float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
-        if (col == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int pose = t * 16 + g4 + r;
-            cpart[pose] = (ch == 0) ? acc[r] * delta_sq : fmaf(acc[r], delta_sq, cpart[pose]);
-          }
+        const float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
+        const float tot = row_sum16_of4(acc);
+        if (col < 4) {
+          const int pose = t * 16 + g4 + col;
+          cpart[pose] = (ch == 0) ? tot * delta_sq : fmaf(tot, delta_sq, cpart[pose]);
         }
       }
     }
