@@ -4,8 +4,11 @@
 //     sum_j a_j * cost(pose_j; x3d, x2d, w2d, delta),   a_j = -g_logw[j]  (+ g_init * cost(pose_init))
 // w.r.t. the correspondences, recomputed from the points (the reference replays autograd through evaluate_pnp,
 // epropnp/common.py:67-100, camera.py:21-30,81-93, cost_fun.py:45-61).  What differs is where the arithmetic runs:
-//   * forward projection  h = (K R | K t)(X,Y,Z,1)^T of 16 poses x 16 points: three v_mfma_f32_16x16x4_f32, exactly
-//     as in amis_forward_mfma.hip (A = pose rows from LDS, B = point tile in a register);
+//   * forward projection  h = (K R | K t)(X,Y,Z,1)^T of 16 poses x 16 points: three MFMAs (A = pose rows from LDS, B = point
+//     tile in registers) -- v_mfma_f32_16x16x4_f32 as in amis_forward_mfma.hip, or (BF16, the default for <= 4 resident
+//     point tiles) ONE v_mfma_f32_16x16x32_bf16 per image row on bf16x3-split operands: fp32-level accuracy at 55 % of the
+//     matrix time (wave_ops.h: ProjOp; the points are split once per chunk, the pose rows on the fly, 21 instructions per
+//     pose tile);
 //   * back-projection  g_x3d[n] += sum_j (K R)_j^T g_h[j,n] stays on the VALU (9 FMAs per pair).  It IS expressible as
 //     the same MFMA with the roles swapped (A = the per-pair g_h values, which the forward MFMA leaves in exactly the
 //     lane layout an A operand needs; B = pose rows indexed by output coordinate), and that variant was built and
@@ -24,7 +27,7 @@ namespace pnp {
 #ifndef PNP_BWD_MINW
 #define PNP_BWD_MINW 3
 #endif
-template <int DOF, bool BOUNDS, int NPT>
+template <int DOF, bool BOUNDS, int NPT, bool BF16 = false>
 __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backward_mfma_kernel(Problem p, const float* __restrict__ pose_samples,
                                                                      const float* __restrict__ g_logw, int S,
                                                                      const float* __restrict__ pose_init,
@@ -33,6 +36,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
                                                                      float* __restrict__ gw2d, float* __restrict__ gdelta,
                                                                      int nsplit, float drop_eps, int gw_rows) {
   constexpr int PL = PoseLen<DOF>::value;
+  typedef ProjOp<BF16> Proj;      // the projection MFMA: fp32 16x16x4, or the bf16x3 split on 16x16x32 (wave_ops.h)
   // nsplit > 1 (few objects): an object's point chunks are dealt to nsplit workgroups (v = b * nsplit + part), each with
   // its own copy of the pose table; per-point gradients are disjoint, grad_delta comes out as nsplit partials per object
   const int v = object_of_block(p.B * nsplit);
@@ -140,14 +144,14 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   const int chunk_pts = W * NPT * 16;
   for (int c0 = part * chunk_pts; c0 < p.N; c0 += nsplit * chunk_pts) {
     // this wave's point tiles q = wv + W * i of the chunk; lane = (point column, k)
-    float rB[NPT];
+    typename Proj::T rB[NPT];
     float4 rW[NPT];
     float A1x[NPT], A1y[NPT], A2x[NPT], A2y[NPT];
     float gXv[NPT], gYv[NPT], gZv[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const Point q = load_point(p, b, c0 + (wv + W * i) * 16 + col);      // zero weight beyond N
-      rB[i] = (kk == 0) ? q.X : (kk == 1) ? q.Y : (kk == 2) ? q.Z : 1.0f;
+      rB[i] = Proj::b((kk == 0) ? q.X : (kk == 1) ? q.Y : (kk == 2) ? q.Z : 1.0f);
       const float wu = q.wu * hs.inv_delta, wv = q.wv * hs.inv_delta;
       rW[i] = make_float4(wu, wv, -q.u * wu, -q.v * wv);
       A1x[i] = A1y[i] = A2x[i] = A2y[i] = 0.f;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < ntile; ++t) {
       const float* arow = ptab + 12 * (t * 16 + col) + kk;
-      const float ax = arow[0], ay = arow[4], az = arow[8];
+      const typename Proj::T ax = Proj::a(arow[0]), ay = Proj::a(arow[4]), az = Proj::a(arow[8]);
       const float4 a4 = *reinterpret_cast<const float4*>(wtab + t * 16 + g4);
       const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
       float4 krx[4], kry[4], krz[4];     // this lane's 4 poses: rows of (K R | K t), for the back-projection
@@ -167,9 +171,9 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
       }
 #pragma unroll
       for (int i = 0; i < NPT; ++i) {
-        const floatx4 hx = mfma_16x16x4(ax, rB[i], zero);
-        const floatx4 hy = mfma_16x16x4(ay, rB[i], zero);
-        const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
+        const floatx4 hx = Proj::mma(ax, rB[i], zero);
+        const floatx4 hy = Proj::mma(ay, rB[i], zero);
+        const floatx4 hz = Proj::mma(az, rB[i], zero);
         const float4 w4 = rW[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -316,14 +320,25 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
     while (npt < 4 && waves * npt * nsplit < ptiles) npt *= 2;
   }
   { int ov[2]; if (env_ints("EPROPNP_BWD_MFMA", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8)) { waves = ov[0]; npt = ov[1]; } }
+  // Projection on the bf16 matrix path (kernel comment) wherever the split operands fit the register budget of three waves per
+  // SIMD (<= 4 resident point tiles: 4 VGPRs per tile instead of 1).  C2 backward 0.954 -> 0.899 ms, bounded 1.111 -> 1.037 ms,
+  // Det shape neutral (profiles/r04_bwd_bf16_projection.txt).  EPROPNP_BWD_PROJ=f32 | bf16 forces either.
+  bool bf16 = npt <= 4;
+  if (const char* e = getenv("EPROPNP_BWD_PROJ")) bf16 = (e[0] == 'f') ? false : (e[0] == 'b' ? npt <= 4 : bf16);
   const dim3 grid(padded_object_grid(d.B * nsplit)), block(64 * waves);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
-    return dispatch_bwd_npt(npt, [&](auto NPT) -> int {
-      auto kern = amis_backward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
+    auto launch = [&](auto kern) -> int {
       allow_dynamic_lds((const void*)kern, smem);
       PNP_LAUNCH(kern, grid, block, smem, st, d, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init, P16,
                  grad_x3d, grad_x2d, grad_w2d, grad_delta, nsplit, backward_drop_eps(), gw_rows);
       return 0;
+    };
+    if (bf16)
+      return (npt == 1)   ? launch(amis_backward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, 1, true>)
+             : (npt == 2) ? launch(amis_backward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, 2, true>)
+                          : launch(amis_backward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, 4, true>);
+    return dispatch_bwd_npt(npt, [&](auto NPT) -> int {
+      return launch(amis_backward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>);
     });
   });
   return check_launch("amis_backward_mfma_kernel");

@@ -208,6 +208,71 @@ __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
 __device__ __forceinline__ bool uniform_is_zero(float a) { return a == 0.f; }
 #endif
 
+// ---- bf16x3-split projection: v_mfma_f32_16x16x32_bf16 --------------------------------------------------------------------
+// An fp32 product sum over k = 0..3 as ONE 32-deep bf16 MFMA: each fp32 operand is the sum of three bf16 pieces (split by
+// TRUNCATION, so the pieces sum to the value exactly), and the 8 slots of a real k carry the products
+//   a1b1 a2b1 | a1b2 a2b2 | a1b3 a2b3 | a3b1 a3b2      (a3b3 ~ 2^-32 of the term is dropped)
+// -- fp32-level accuracy (tools/ubench/bf16_split_mfma.hip: 1.4e-7 against 1.2e-7 relative for the fp32 MFMA) at 55 % of the
+// fp32 MFMA's time (4 passes instead of 8).  Lane l holds slots 8 (l >> 4) .. +7 of row / column l & 15 as 4 dwords (element 2i =
+// low half of dword i); D as mfma_16x16x4.  The operands are plain vector VALUES and the MFMA is the compiler's builtin: its
+// hazard recogniser keeps the distances this instruction needs on gfx950 (8 wait states before a VALU read of a result, 1
+// behind a VALU-written source: the ISA of a probe shows `s_nop 7` / `s_nop 0`, the distances tools/ubench/mfma_bf16_hazard.hip
+// measured).  Do NOT route an operand or a result through an inline asm: an asm that takes a result in-out hides the MFMA ->
+// VALU dependence from the recogniser (the asm "redefines" the register), which is what made the round-3 attempts at this
+// projection wrong and run-to-run different (profiles/r04_bwd_bf16_projection.txt).
+#ifndef EPROPNP_EMU
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx4 mfma_16x16x32_bf16(u32x4 a, u32x4 b, floatx4 c) {
+  typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
+}
+// {hi16(lo_src), hi16(hi_src)} as one v_perm_b32
+__device__ __forceinline__ unsigned bf16_pack_hi(unsigned lo_src, unsigned hi_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }
+#else
+typedef emu::u32x4_emu u32x4;
+__device__ __forceinline__ floatx4 mfma_16x16x32_bf16(u32x4 a, u32x4 b, floatx4 c) { return emu::mfma_16x16x32_bf16(a, b, c); }
+__device__ __forceinline__ unsigned bf16_pack_hi(unsigned lo_src, unsigned hi_src) { return (lo_src >> 16) | (hi_src & 0xffff0000u); }
+#endif
+__device__ __forceinline__ void bf16_split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {      // pieces in the HIGH halves
+  unsigned u;
+  __builtin_memcpy(&u, &x, 4);
+  p1 = u & 0xffff0000u;
+  float f1;
+  __builtin_memcpy(&f1, &p1, 4);
+  const float r1 = x - f1;                       // exact: the low 16 mantissa bits
+  __builtin_memcpy(&u, &r1, 4);
+  p2 = u & 0xffff0000u;
+  float f2;
+  __builtin_memcpy(&f2, &p2, 4);
+  const float r2 = r1 - f2;                      // exact, <= 8 significant bits left: a bf16 value
+  __builtin_memcpy(&p3, &r2, 4);
+}
+__device__ __forceinline__ u32x4 bf16_split_a(float a) {      // (a1,a2) (a1,a2) (a1,a2) (a3,a3)
+  unsigned a1, a2, a3;
+  bf16_split3(a, a1, a2, a3);
+  const unsigned w0 = bf16_pack_hi(a1, a2);
+  return u32x4{w0, w0, w0, bf16_pack_hi(a3, a3)};
+}
+__device__ __forceinline__ u32x4 bf16_split_b(float b) {      // (b1,b1) (b2,b2) (b3,b3) (b1,b2)
+  unsigned b1, b2, b3;
+  bf16_split3(b, b1, b2, b3);
+  return u32x4{bf16_pack_hi(b1, b1), bf16_pack_hi(b2, b2), bf16_pack_hi(b3, b3), bf16_pack_hi(b1, b2)};
+}
+// operand type / split / product of the two projection flavours, so that a kernel is written once
+template <bool BF16> struct ProjOp;
+template <> struct ProjOp<false> {
+  typedef float T;
+  static __device__ __forceinline__ T a(float x) { return x; }
+  static __device__ __forceinline__ T b(float x) { return x; }
+  static __device__ __forceinline__ floatx4 mma(T x, T y, floatx4 c) { return mfma_16x16x4(x, y, c); }
+};
+template <> struct ProjOp<true> {
+  typedef u32x4 T;
+  static __device__ __forceinline__ T a(float x) { return bf16_split_a(x); }
+  static __device__ __forceinline__ T b(float x) { return bf16_split_b(x); }
+  static __device__ __forceinline__ floatx4 mma(T x, T y, floatx4 c) { return mfma_16x16x32_bf16(x, y, c); }
+};
+
 // ---- words exchanged between the workgroups of ONE launch (the split-over-workgroups variants of the AMIS forward and
 // the LM solve) ------------------------------------------------------------------------------------------------------
 // A slot is pre-filled with kXwgEmpty by the launcher; its producer overwrites it with the payload (never kXwgEmpty: NaNs

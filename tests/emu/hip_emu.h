@@ -261,4 +261,40 @@ inline floatx4_emu mfma_16x16x4(float a, float b, floatx4_emu c) {
     for (int k = 0; k < 4; ++k) d[r] = fmaf(av[r][k], bv[k], d[r]);
   return d;
 }
+
+// v_mfma_f32_16x16x32_bf16: D(16x16) = A(16x32) B(32x16) + C.  Lane l holds the 8 bf16 A[l&15][8*(l>>4) .. +7] and
+// B[8*(l>>4) .. +7][l&15] as 4 dwords each (element 2i = low half of dword i); D layout as mfma_16x16x4.  Products of bf16
+// pairs are exact in fp32; the 32-term sum is accumulated in double and rounded once (the hardware's order is not specified).
+typedef unsigned u32x4_emu __attribute__((vector_size(16)));
+inline floatx4_emu mfma_16x16x32_bf16(u32x4_emu a, u32x4_emu b, floatx4_emu c) {
+  Block& blk_ = blk();
+  unsigned t = blk_.fibers[blk_.cur].tid.x;
+  int w = t / 64, lane = t % 64;
+  unsigned av[64][4], bv[64][4];
+  for (int half = 0; half < 2; ++half) {       // two dwords per exchange round (w_buf holds 64 bits per lane)
+    blk_.w_buf[w][lane] = (uint64_t)a[2 * half] | ((uint64_t)a[2 * half + 1] << 32);
+    wave_sync();
+    for (int l = 0; l < 64; ++l) { av[l][2 * half] = (unsigned)blk_.w_buf[w][l]; av[l][2 * half + 1] = (unsigned)(blk_.w_buf[w][l] >> 32); }
+    wave_sync();
+    blk_.w_buf[w][lane] = (uint64_t)b[2 * half] | ((uint64_t)b[2 * half + 1] << 32);
+    wave_sync();
+    for (int l = 0; l < 64; ++l) { bv[l][2 * half] = (unsigned)blk_.w_buf[w][l]; bv[l][2 * half + 1] = (unsigned)(blk_.w_buf[w][l] >> 32); }
+    wave_sync();
+  }
+  auto elem = [](const unsigned (&v)[4], int e) {
+    const unsigned bits = ((e & 1) ? (v[e >> 1] >> 16) : (v[e >> 1] & 0xffffu)) << 16;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+  };
+  floatx4_emu d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (lane >> 4) + r, col = lane & 15;
+    double acc = d[r];
+    for (int g = 0; g < 4; ++g)
+      for (int e = 0; e < 8; ++e) acc += (double)elem(av[g * 16 + row], e) * (double)elem(bv[g * 16 + col], e);
+    d[r] = (float)acc;
+  }
+  return d;
+}
 }  // namespace emu

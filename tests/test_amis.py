@@ -248,6 +248,44 @@ def test_backward_without_pose_init(backend, monkeypatch, impl, nsplit):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7 * float(b.abs().max()))
 
 
+@pytest.mark.parametrize('dof,bounds,B,N,S,shape', [(6, None, 3, 300, 70, None), (4, 'tight', 5, 128, 33, None), (6, 'tight', 2, 512, 40, None),
+                                                    (6, None, 4, 40, 200, '4,1'), (4, None, 3, 700, 64, '4,2')])
+def test_backward_bf16_split_projection_against_the_fp32_matrix_path(backend, monkeypatch, dof, bounds, B, N, S, shape):
+    """The MFMA backward projects on v_mfma_f32_16x16x32_bf16 with every fp32 operand split into three bf16 pieces (default for
+    <= 4 resident point tiles); EPROPNP_BWD_PROJ=f32 keeps the fp32 MFMA.  Same gradients to fp32-level rounding (8 of the 9 cross
+    products per real k are carried: ~1.4e-7 per projection), poses behind the camera and zero / negligible weights included,
+    and run-to-run the same bits."""
+    from epropnp import functional as F
+    monkeypatch.setenv('EPROPNP_BWD_IMPL', 'mfma')
+    if shape:
+        monkeypatch.setenv('EPROPNP_BWD_MFMA', shape)
+    prob = orc.make_problem(B, N, dof, seed=41, bounds=bounds)
+    g = torch.Generator().manual_seed(8)
+    poses = prob['pose_gt'].unsqueeze(0).repeat(S, 1, 1)
+    poses[..., :3] += 0.2 * torch.randn(S, B, 3, generator=g)
+    if dof == 6:
+        q = poses[..., 3:] + 0.1 * torch.randn(S, B, 4, generator=g)
+        poses[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+    else:
+        poses[..., 3] += 0.3 * torch.randn(S, B, generator=g)
+    poses[0, 0, 2] = -1.0
+    poses[1, :, :3] *= 300.0                       # far away: large (K t) entries against small rotation entries
+    g_logw, g_init = torch.randn(S, B, generator=g), torch.randn(B, generator=g)
+    g_logw[3] = 0.0
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    args = (hp, poses.to(backend), g_logw.to(backend), p['pose_init'], g_init.to(backend))
+    monkeypatch.setenv('EPROPNP_BWD_PROJ', 'bf16')
+    split = F.amis_backward(*args)
+    again = F.amis_backward(*args)
+    monkeypatch.setenv('EPROPNP_BWD_PROJ', 'f32')
+    full = F.amis_backward(*args)
+    for a, b, c in zip(split, again, full):
+        assert torch.equal(a, b)
+        assert _rel(a.cpu(), c.cpu()) <= 2e-5, _rel(a.cpu(), c.cpu())
+    assert not all(torch.equal(a, c) for a, c in zip(split, full))       # the switch does select another kernel
+
+
 @pytest.mark.parametrize('dof,bounds,N,S', [(6, None, 300, 70), (4, 'tight', 128, 33), (6, 'tight', 512, 40)])
 def test_backward_split_over_workgroups(backend, dof, bounds, N, S):
     """Few objects: the point chunks of an object dealt to several workgroups (epropnp_amis_backward_split).  Per-point
