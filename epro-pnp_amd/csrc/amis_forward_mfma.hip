@@ -95,10 +95,15 @@ struct MfmaShape {
 // floats per object -- lives in a global scratch buffer instead of LDS, for mc_samples beyond what 160 KiB hold
 // (the reference has no such limit).  Same code: the arrays are reached through pointers either way, every hand-over
 // between threads goes through a workgroup barrier, and a workgroup's global accesses share one L1.
-template <int DOF, bool BOUNDS, int NPT, bool SPILL = false, bool SPLIT = false>
+// BF16 (register mode only): the projection on v_mfma_f32_16x16x32_bf16 with bf16x3-split operands (wave_ops.h: ProjOp) -- 55 % of the
+// fp32 MFMA's time at fp32-level accuracy.  A split B operand takes 4 VGPRs per resident point tile and a register tuple per image
+// row cannot double as the weighted operand, so the weights are NOT folded into the B operands here (two more multiplies per
+// point-pose) and the 6-DoF kernel is compiled for three waves per SIMD instead of four (152 VGPRs): still -9 % at C2
+// (profiles/r04_fwd_bf16_projection.txt).
+template <int DOF, bool BOUNDS, int NPT, bool SPILL = false, bool SPLIT = false, bool BF16 = false>
 // (SPLIT grids are sized for one workgroup per CU: two waves per SIMD -- 256 VGPRs -- leave room for a second such launch and
 // for the part-recomputation path's second copy of the sweep without spilling)
-__global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MINW : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
+__global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 : PNP_FWD_MINW) : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
                                                                   const float* __restrict__ noise,
@@ -137,7 +142,10 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
 #endif
   PNP_DYN_SMEM(float, smem);
   constexpr bool kRegs = NPT > 0;
-  constexpr bool kFold = kRegs && !BOUNDS;
+  static_assert(!BF16 || NPT > 0, "the split projection is a register-mode variant");
+  constexpr bool kBf = BF16;
+  typedef ProjOp<kBf> Proj;
+  constexpr bool kFold = kRegs && !BOUNDS && !kBf;
   const int WPs = kRegs ? (G > 1 ? G : W) : 1;      // point slices whose partial costs are summed in amis_weights
   // split: W per-wave rows of the part in the registers + G gathered rows (one per part) + the missing-parts word
   const int cpart_rows = kRegs ? (SPLIT ? W + G : W) : 1;
@@ -189,17 +197,18 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
     }
   };
   // register mode: this wave's point tiles q = wv + W * i of part `pt`, lane = (point column, k)
-  float rB[kRegs ? NPT : 1];
+  typename Proj::T rB[kRegs ? NPT : 1];
   float4 rW[kRegs ? NPT : 1];
   auto load_tiles = [&](int pt) {
 #pragma unroll
     for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
       const Point q = load_point(p, b, ((pt * W + wv) + G * W * i) * 16 + (lane & 15));      // zero weight beyond N
       const int k4 = lane >> 4;
-      rB[i] = (k4 == 0) ? q.X : (k4 == 1) ? q.Y : (k4 == 2) ? q.Z : 1.0f;
+      const float bval = (k4 == 0) ? q.X : (k4 == 1) ? q.Y : (k4 == 2) ? q.Z : 1.0f;
+      rB[i] = Proj::b(bval);
       // without a projection clamp the weights are folded into the B operands of the x and y rows (same 5 VGPRs)
       const float wu = q.wu * inv_delta, wv = q.wv * inv_delta;
-      rW[i] = kFold ? make_float4(rB[i] * wu, rB[i] * wv, -q.u * wu, -q.v * wv) : make_float4(wu, wv, -q.u * wu, -q.v * wv);
+      rW[i] = kFold ? make_float4(bval * wu, bval * wv, -q.u * wu, -q.v * wv) : make_float4(wu, wv, -q.u * wu, -q.v * wv);
     }
   };
   if (kRegs) {
@@ -218,13 +227,20 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? PNP_FWD_MI
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < (s16 >> 4); ++t) {
       const float* arow = ptab + 12 * (t * 16 + col) + kk;
-      const float ax = arow[0], ay = arow[4], az = arow[8];
+      const typename Proj::T ax = Proj::a(arow[0]), ay = Proj::a(arow[4]), az = Proj::a(arow[8]);
       f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
       for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
-        const floatx4 hx = mfma_16x16x4(ax, kFold ? rW[i].x : rB[i], zero);
-        const floatx4 hy = mfma_16x16x4(ay, kFold ? rW[i].y : rB[i], zero);
-        const floatx4 hz = mfma_16x16x4(az, rB[i], zero);
+        floatx4 hx, hy, hz;
+        if constexpr (kFold) {
+          hx = mfma_16x16x4(ax, rW[i].x, zero);
+          hy = mfma_16x16x4(ay, rW[i].y, zero);
+          hz = mfma_16x16x4(az, rB[i], zero);
+        } else {
+          hx = Proj::mma(ax, rB[i], zero);
+          hy = Proj::mma(ay, rB[i], zero);
+          hz = Proj::mma(az, rB[i], zero);
+        }
         huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, one_v, bd, acc2);
       }
       // the four poses' sums over this row's 16 points: lane col < 4 ends up with pose g4 + col (wave_ops.h: row_sum16_of4)
@@ -536,6 +552,9 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
                   "(stream capture?)", S, sizeof(float) * (size_t)(PL + 3) * S * d.B);
     }
   }
+  // projection flavour (kernel comment): bf16x3 split in register mode with <= 8 resident point tiles per wave; EPROPNP_FWD_PROJ=f32 | bf16
+  bool bf16 = npt >= 1 && npt <= 8;
+  if (const char* e = getenv("EPROPNP_FWD_PROJ")) bf16 = (e[0] == 'f') ? false : bf16;
   const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
   if (spill != nullptr) {
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
@@ -575,11 +594,14 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   if (G > 1) {
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       auto go = [&](auto NPT) -> int {
-        auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value, false, true>;
-        allow_dynamic_lds((const void*)kern, smem);
-        PNP_LAUNCH(kern, grid_split, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
-                   (float*)nullptr, G, xch);
-        return 0;
+        auto run = [&](auto kern) -> int {
+          allow_dynamic_lds((const void*)kern, smem);
+          PNP_LAUNCH(kern, grid_split, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
+                     (float*)nullptr, G, xch);
+          return 0;
+        };
+        if (bf16) return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value, false, true, true>);
+        return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value, false, true>);
       };
       switch (npt) {
         case 1: return go(ic<1>{});
@@ -591,11 +613,16 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   } else {
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       return dispatch_npt(npt, [&](auto NPT) -> int {
-        auto kern = amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>;
-        allow_dynamic_lds((const void*)kern, smem);
-        PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
-                   (float*)nullptr, 1, (float*)nullptr);
-        return 0;
+        auto run = [&](auto kern) -> int {
+          allow_dynamic_lds((const void*)kern, smem);
+          PNP_LAUNCH(kern, grid, block, smem, st, d, k, sh, pose_opt, pose_cov, noise, pose_samples, logweights, proposals,
+                     (float*)nullptr, 1, (float*)nullptr);
+          return 0;
+        };
+        if constexpr (decltype(NPT)::value >= 1 && decltype(NPT)::value <= 8) {
+          if (bf16) return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value, false, false, true>);
+        }
+        return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>);
       });
     });
   }
