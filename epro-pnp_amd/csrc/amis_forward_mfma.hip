@@ -552,8 +552,9 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
                   "(stream capture?)", S, sizeof(float) * (size_t)(PL + 3) * S * d.B);
     }
   }
-  // projection flavour (kernel comment): bf16x3 split in register mode with <= 8 resident point tiles per wave; EPROPNP_FWD_PROJ=f32 | bf16
-  bool bf16 = npt >= 1 && npt <= 8;
+  // projection flavour (kernel comment): the bf16x3 split wherever the points are register-resident (C2 -9.8 %, 4096 x 1024 and the
+  // C5 shard -16 %, profiles/r04_fwd_bf16_projection.txt); EPROPNP_FWD_PROJ=f32 keeps the fp32 MFMA
+  bool bf16 = npt >= 1;
   if (const char* e = getenv("EPROPNP_FWD_PROJ")) bf16 = (e[0] == 'f') ? false : bf16;
   const dim3 grid(padded_object_grid(d.B)), block(64 * waves);
   if (spill != nullptr) {
@@ -619,7 +620,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
                      (float*)nullptr, 1, (float*)nullptr);
           return 0;
         };
-        if constexpr (decltype(NPT)::value >= 1 && decltype(NPT)::value <= 8) {
+        if constexpr (decltype(NPT)::value >= 1) {
           if (bf16) return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value, false, false, true>);
         }
         return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value>);
