@@ -600,6 +600,12 @@ def main(argv=None, device=None, backend='nccl'):
             'value': round(value, 1), 'unit': 'instances/s', 'n_gpus': world, 'ranks': ranks, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': cfg['scaling'],
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'device_spinup_steps': SPINUP_STEPS,
+            # how the fp32 arithmetic is carried out where it is not plain fp32 instructions ("Round 4")
+            'dtype_note': ('fp32 throughout; the pose x point projection of the two AMIS kernels is evaluated on v_mfma_f32_16x16x32_bf16 with each '
+                           'fp32 operand split into three bf16 pieces that sum to it exactly (8 of the 9 cross products carried, fp32 accumulation: '
+                           '1.4e-7 relative against 1.2e-7 for the fp32 MFMA); EPROPNP_FWD_PROJ=f32 EPROPNP_BWD_PROJ=f32 select the fp32 MFMA: '
+                           + ('fp32 MFMA selected' if os.environ.get('EPROPNP_FWD_PROJ', '')[:1] == 'f' and os.environ.get('EPROPNP_BWD_PROJ', '')[:1] == 'f'
+                              else 'split projection (default)')),
             'launch': 'eager' if launch == 'eager' else 'hipGraph replay of the whole rank step, RCCL exchange included (captured once; fresh samples per replay)',
             'launch_note': launch_note,
             'kernel_ms_source': 'HIP events inside the library over the timed region' if prof_in_region else f'HIP events inside the library over {prof_steps} eager steps before the timed region',
