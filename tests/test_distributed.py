@@ -197,6 +197,9 @@ def test_bench_det_route_switch_and_clean_teardown(route):
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '3', '--warmup', '1', '--config', 'C4',
            '--route', route, '--no-cpu-baseline', '--no-hipgraph']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    if r.returncode != 0:       # one retry for a rendezvous that did not come up (seen once on a box that took 75 s to receive the tree)
+        sys.stderr.write('bench.py self-launch failed once, retrying:\n' + r.stderr[-1500:] + '\n')
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     want = 'rccl ncclAllGather' if route == 'direct' else 'torch.distributed.all_gather_into_tensor'
