@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__
       if (n < N) {
         const float2 wi = w[n];
         const float wm = 0.5f * (wi.x + wi.y);
-        if (packed) ukey[n] = race_key(r.v[q], wm, n);
+        if (packed) ukey[n] = race_key(r.v[q], race_inv_weight(wm), n);
         else key[n] = (wm > 0.f) ? fabsf(logf(u01(r.v[q]))) / wm : INFINITY;
       }
     }

@@ -17,7 +17,7 @@
 
 namespace pnp {
 
-constexpr int kRslmMaxPts = 512;    // LDS: 28 B (points) + 16 x 4 B (keys of the 16 proposals in flight) per point
+constexpr int kRslmMaxPts = 512;    // LDS: 32 B (point + reciprocal weight) + 16 x 4 B (keys of the 16 proposals in flight) per point
 constexpr int kRslmRows = 16;       // DPP rows per workgroup
 
 PNP_FN float row_min16(float x) { return -row_max16(-x); }
@@ -83,6 +83,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
   float* sW = sU + 2 * Np;          // [N][2]
   float* key = sW + 2 * Np;         // [16][Np]
   float* red = key + kRslmRows * Np;   // [128]
+  float* sIw = red + 128;           // [N] reciprocal mean weight of a point (race_inv_weight): one multiply per key, 64 proposals
 
   float K[9], delta;
   Bounds bd;
@@ -92,6 +93,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
     sX[3 * n] = q.X; sX[3 * n + 1] = q.Y; sX[3 * n + 2] = q.Z;
     sU[2 * n] = q.u; sU[2 * n + 1] = q.v;
     sW[2 * n] = q.wu; sW[2 * n + 1] = q.wv;
+    sIw[n] = race_inv_weight(0.5f * (q.wu + q.wv));
   }
   __syncthreads();
 
@@ -169,7 +171,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = 4 * n4 + q;
-          if (n < N) ukey[n] = race_key(r.v[q], 0.5f * (sW[2 * n] + sW[2 * n + 1]), n);
+          if (n < N) ukey[n] = race_key(r.v[q], sIw[n], n);
         }
       }
       wave_lds_fence();
@@ -377,7 +379,7 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
   k.min_rel_decrease = lm->min_relative_decrease; k.radius0 = lm->initial_trust_region_radius;
   k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps; k.split_timeout = 0;
   const int Np = (d.N + 3) & ~3;
-  const size_t smem = sizeof(float) * ((size_t)(7 + kRslmRows) * Np + 128);
+  const size_t smem = sizeof(float) * ((size_t)(8 + kRslmRows) * Np + 128);
   int parts = rslm_parts(d.B, P);
   const int PLh = prob->dof == 6 ? 7 : 4;
   if (parts > 1 && (scratch == nullptr || scratch_bytes < sizeof(float) * (size_t)parts * d.B * (PLh + 1))) parts = 1;
