@@ -417,12 +417,13 @@ def main(argv=None, device=None, backend='nccl'):
     if not on_gpu:
         launch = 'eager'
     launch_note = None
-    # Per-kernel stage times: HIP events around every kernel stage inside the library.  In the GPU-bound configurations
-    # they sit in the timed region itself (they cost nothing there: 1.76 ms per C2 step with or without); in the
-    # launch-bound Det step their ~20 event records per step would slow the host-bound eager step by 40 % and cannot sit in a
-    # graph at all, so there the stage times come from `prof_steps` eager steps just before the timed region.
-    prof_in_region = launch == 'eager' and args.config not in LAUNCH_BOUND
-    prof_steps = args.steps if prof_in_region else (10 if on_gpu else 1)
+    # Per-kernel stage times: HIP events around every kernel stage inside the library, over `prof_steps` eager steps just BEFORE
+    # the timed region.  Inside it they are not free: ~16 event records per step cost the GPU-bound C2 step 3 % (round 4, same
+    # box: 2.522 M instances/s with the events in the timed region, 2.605 M with them in front of it -- they used to disappear
+    # in a 1.76 ms step; profiles/r04_bench_event_overhead.txt), they slow the host-bound eager Det step by 40 %, and they cannot
+    # sit in a hipGraph at all.  BENCH_PROF_IN_REGION=1 puts them back into the timed region of an eager GPU-bound run.
+    prof_in_region = (launch == 'eager' and args.config not in LAUNCH_BOUND and os.environ.get('BENCH_PROF_IN_REGION', '0') == '1')
+    prof_steps = args.steps if prof_in_region else ((10 if args.config in LAUNCH_BOUND else 20) if on_gpu else 1)
     if not prof_in_region:
         fence()
         _hip.profile(enable=True, reset=True)
