@@ -220,7 +220,11 @@ uint64_t epropnp_lm_solve_split_bytes(const epropnp_problem* prob, const epropnp
  *   pose_opt (B,pose_len), pose_cov (B,dof,dof) from the solver
  *   noise: NULL (on-device Philox) or (B,K,S/K,epropnp_noise_stride(dof)) injected base draws
  *   -> pose_samples (S,B,pose_len), logweights (S,B)
- *   -> proposals (optional, may be NULL): (B,K,40) fitted proposal parameters, for diagnostics/tests. */
+ *   -> proposals (optional, may be NULL): (B,K,40) fitted proposal parameters, for diagnostics/tests.
+ * Arithmetic: fp32.  The pose x point projection of the cost sweep (camera.py:21-30) runs on v_mfma_f32_16x16x32_bf16 with each
+ * fp32 operand split into three bf16 pieces that sum to it exactly (8 of the 9 cross products, fp32 accumulation: 1.4e-7
+ * relative, the fp32 MFMA's 1.2e-7) wherever the points are register-resident; environment EPROPNP_FWD_PROJ=f32 selects
+ * v_mfma_f32_16x16x4_f32 (and EPROPNP_BWD_PROJ=f32 does so for epropnp_amis_backward). */
 int epropnp_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
                          const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
                          float* proposals, void* stream);
