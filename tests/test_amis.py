@@ -409,6 +409,17 @@ def test_forward_kernel_variants_agree(backend, monkeypatch):
     s3, w3 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     assert (s1 - s3).abs().max().item() < 5e-4
     assert (torch.logsumexp(w1, 0) - torch.logsumexp(w3, 0)).abs().max().item() < 1e-3
+    # the projection on the fp32 MFMA instead of the bf16x3 split (register mode): the first iteration's samples do not depend on
+    # the sweep at all and its log-weights only through the costs -- fp32-level agreement; later iterations through the refit
+    monkeypatch.delenv('EPROPNP_FWD_MFMA')
+    monkeypatch.setenv('EPROPNP_FWD_PROJ', 'f32')
+    s4, w4 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+    monkeypatch.delenv('EPROPNP_FWD_PROJ')
+    s = S // K
+    assert torch.equal(s1[:s], s4[:s])
+    assert not torch.equal(w1, w4)                                  # (the switch does select another kernel)
+    assert (s1 - s4).abs().max().item() < 5e-4
+    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w4, 0)).abs().max().item() < 1e-3
 
 
 @pytest.mark.gpu
