@@ -1,17 +1,24 @@
 // amis_forward_mfma.hip -- AMIS forward with the pose x point projection on the matrix cores.
 //
 // Same algorithm and LDS-resident sampler state as amis_forward_kernel (amis_kernels.hip); only the cost sweep
-// differs.  The projection h = (K R | K t) (X,Y,Z,1)^T of 16 poses x 16 points is ONE v_mfma_f32_16x16x4_f32 per
-// image row (x, y, z): exact f32 (a k-ordered fmaf chain).  The fp32 MFMA has the VALU's FMA rate and does not overlap
-// with it (tools/ubench/mfma_valu_overlap.hip), so what it buys is not a second pipe but issue slots and registers:
-// three instructions per 16 x 16 tile instead of 9 FMAs per lane and row, operands that are 5 VGPRs per resident point
-// tile.  What stays on the VALU is the perspective divide, the weighted residual and the Huber kernel
-// (2 transcendentals + ~10 simple ops per point-pose).
-//   A operand (16 poses x 4): lane l holds row[pose l&15][k = l>>4]       <- LDS pose table, x | y | z rows
-//   B operand (4 x 16 points): lane l holds (X,Y,Z,1)[k = l>>4] of point l&15 <- LDS point table
+// differs.  The projection h = (K R | K t) (X,Y,Z,1)^T of 16 poses x 16 points is ONE matrix instruction per image row
+// (x, y, z):
+//   * register mode (an object's points resident in the waves' registers: the default up to 2048 points per part), BF16:
+//     v_mfma_f32_16x16x32_bf16 on operands split into three bf16 pieces each (wave_ops.h: ProjOp<true>; fp32-level accuracy,
+//     7.8 ns per instruction and SIMD).  The pose rows are split on the fly, the point tiles once; a split operand is a 4-VGPR
+//     tuple per image row, so the weights stay out of the B operands (two more multiplies per point-pose);
+//   * otherwise v_mfma_f32_16x16x4_f32 (exact f32, a k-ordered fmaf chain; 14.3 ns): the LDS-streamed mode, and register mode
+//     under EPROPNP_FWD_PROJ=f32 -- there, without a projection clamp, the weights are folded into the B operands of the x and
+//     y rows (5 VGPRs per resident tile).  The fp32 MFMA has the VALU's FMA rate and does not overlap with it
+//     (tools/ubench/mfma_valu_overlap.hip): what it buys is issue slots and registers, not a second pipe.
+// What stays on the VALU is the perspective divide, the weighted residual and the Huber kernel (2 transcendentals + ~10
+// simple ops per point-pose).
+//   A operand (16 poses x k): lane l holds row[pose l&15][k-slice l>>4]   <- LDS pose table, x | y | z rows of (K R | K t)
+//   B operand (k x 16 points): lane l holds (X,Y,Z,1)[l>>4] of point l&15  <- registers (register mode) / LDS point table
 //   D (16 x 16): lane l holds poses 4*(l>>4)+r, r = 0..3, at point l&15   -> 4 point-poses per lane per tile
-// Points are no longer register-resident (no N limit; chunks of <= kChunk points stream through LDS), waves split
-// the pose tiles, and a pose's cost is the DPP row-sum over the 16 lanes that hold its 16 points.
+// Register mode: the workgroup's waves split the POINTS and sweep every pose tile; a pose's cost is the row sum over the 16
+// lanes that hold its 16 points, the waves' partial costs meet in LDS.  LDS-streamed mode (any N): waves split the pose tiles,
+// chunks of <= kChunk points stream through LDS.
 #include "amis_common.h"
 #include "dispatch.h"
 
