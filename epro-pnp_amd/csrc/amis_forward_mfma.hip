@@ -90,6 +90,7 @@ struct MfmaShape {
   int s16;       // rows of the LDS pose table: the samples of an iteration rounded up to 16 -- or, in the SPILL variant, of
                  // one TILE of an iteration's samples when a whole iteration does not fit LDS (draw -> sweep per tile)
   int ahead;     // 1: LDS holds the [s][8] buffer for base noise drawn ahead of the proposal fit (0: drawn inline)
+  int chunks;    // register mode, > 1: the object's point tiles go through the waves' registers in `chunks` groups per iteration
 };
 
 // NPT > 0: the workgroup's waves split the POINTS, each wave keeps its NPT point tiles (B operand + residual
@@ -107,7 +108,7 @@ struct MfmaShape {
 // row cannot double as the weighted operand, so the weights are NOT folded into the B operands here (two more multiplies per
 // point-pose) and the 6-DoF kernel is compiled for three waves per SIMD instead of four (152 VGPRs): still -9 % at C2
 // (profiles/r04_fwd_bf16_projection.txt).
-template <int DOF, bool BOUNDS, int NPT, bool SPILL = false, bool SPLIT = false, bool BF16 = false>
+template <int DOF, bool BOUNDS, int NPT, bool SPILL = false, bool SPLIT = false, bool BF16 = false, bool CHUNKED = false>
 // (SPLIT grids are sized for one workgroup per CU: two waves per SIMD -- 256 VGPRs -- leave room for a second such launch and
 // for the part-recomputation path's second copy of the sweep without spilling)
 __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 : PNP_FWD_MINW) : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   // (a template parameter: the one-workgroup-per-object instantiations carry none of this -- the scalar registers it keeps
   // live spilled two VGPRs of the C2 kernel otherwise)
   const int G = SPLIT ? nsplit : 1;
+  static_assert(!CHUNKED || (NPT > 0 && !SPLIT && !SPILL), "chunks are a register-mode variant of the one-workgroup kernel");
+  // chunked register mode (launcher comment); a template parameter: the loop around load_tiles / sweep_regs costs the other
+  // instantiations their register allocation (C2 kernel: 83 instead of 7 spilled VGPRs with a run-time chunk count)
+  const int CH = CHUNKED ? sh.chunks : 1;
+  const int GT = SPLIT ? G : CH;                  // groups the point tiles are dealt to: workgroups of the object, or chunks in time
   int b, part = 0;
   if (SPLIT) {
     const int g = (int)blockIdx.x, per = (p.B + 7) >> 3, idx = g >> 3;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   auto load_tiles = [&](int pt) {
 #pragma unroll
     for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
-      const Point q = load_point(p, b, ((pt * W + wv) + G * W * i) * 16 + (lane & 15));      // zero weight beyond N
+      const Point q = load_point(p, b, ((pt * W + wv) + GT * W * i) * 16 + (lane & 15));      // zero weight beyond N
       const int k4 = lane >> 4;
       const float bval = (k4 == 0) ? q.X : (k4 == 1) ? q.Y : (k4 == 2) ? q.Z : 1.0f;
       rB[i] = Proj::b(bval);
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
     }
   };
   if (kRegs) {
-    load_tiles(part);
+    if constexpr (!CHUNKED) load_tiles(part);
   } else if (nchunk == 1) {
     load_chunk(0);
   }
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   // register mode: every pose tile of the iteration against the point tiles in this wave's registers -> cpart[wv][pose]
   // (issuing the next pose tile's first MFMAs ahead of the current tile's VALU work, to fill the wait states at the
   // head of this loop, was measured: 0.655 vs 0.641 ms at C2 -- the hand-off copies cost more than the s_nops)
-  auto sweep_regs = [&]() {
+  auto sweep_regs = [&](bool accumulate = false) {      // accumulate: a later chunk of the same iteration adds to the wave's row
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < (s16 >> 4); ++t) {
       const float* arow = ptab + 12 * (t * 16 + col) + kk;
@@ -254,7 +260,11 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
 #ifndef PNP_FWD_ROWSUM_OLD
       const float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
       const float tot = row_sum16_of4(acc);
-      if (col < 4) cpart[wv * s16 + t * 16 + g4 + col] = tot * delta_sq;
+      if (col < 4) {
+        float* dst = cpart + wv * s16 + t * 16 + g4 + col;
+        if constexpr (CHUNKED) *dst = accumulate ? fmaf(tot, delta_sq, *dst) : tot * delta_sq;
+        else *dst = tot * delta_sq;
+      }
 #else       // tuning variant: four full row sums (16 DPP adds), lane 0 of the row stores
       float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
 #pragma unroll
@@ -291,7 +301,14 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
     } else
 #endif
     if (kRegs) {
-      sweep_regs();
+      if constexpr (!CHUNKED) {
+        sweep_regs();
+      } else {        // the point tiles in CH groups through the registers: load, split, sweep every pose tile, next group
+        for (int c = 0; c < CH; ++c) {
+          load_tiles(c);
+          sweep_regs(c > 0);
+        }
+      }
     } else
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * NC;
@@ -519,6 +536,17 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       if (o <= 8) { G = g; waves = 4; npt = o; sh.chunk = 0; }
     }
   }
+  // Many points per object in register mode (> 48 tiles: 16 resident tiles per wave or 8-wave workgroups, i.e. 256 VGPRs and one
+  // or two workgroups per CU, whose serial sampler phases nothing hides): 4 waves x 8 resident tiles instead, the object's tiles
+  // going through the registers in chunks of 32 per iteration -- three workgroups per CU again.  The points are re-read per
+  // chunk and iteration (from L2 / HBM: 28 B per point against ~100 ns of arithmetic per 16 of them and pose tile).
+  sh.chunks = 1;
+  { const char* e = getenv("EPROPNP_FWD_PROJ"); if (e && e[0] == 'f') sh.chunks = 0; }      // (the chunked instantiation is the split projection)
+  if (sh.chunks == 1 && G == 1 && npt > 8 && ptiles > 48 && !getenv("EPROPNP_FWD_NO_CHUNKS") && !getenv("EPROPNP_FWD_MFMA")) {
+    waves = 4; npt = 8;
+    sh.chunks = (ptiles + 31) / 32;
+  }
+  if (sh.chunks < 1) sh.chunks = 1;
   AmisParams k;
   k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
@@ -539,7 +567,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
     // buffer do not fit either, the noise is drawn inline and, if need be, the iteration's samples go through the table in
     // tiles (draw -> sweep -> costs to the scratch, per tile): no limit on mc_samples / num_iter (the reference has none,
     // epropnp.py:55-59)
-    waves = 8; npt = 0; G = 1;
+    waves = 8; npt = 0; G = 1; sh.chunks = 1;
     sh.chunk = ((d.N + 15) / 16) * 16;
     if (sh.chunk > kChunk) sh.chunk = kChunk;
     const int tiles = sh.s16 / 16;
@@ -627,6 +655,10 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
                      (float*)nullptr, 1, (float*)nullptr);
           return 0;
         };
+        if constexpr (decltype(NPT)::value == 8) {
+          if (sh.chunks > 1 || (bf16 && getenv("EPROPNP_FWD_CHUNKED") != nullptr))      // (the knob: the chunked instantiation with one chunk)
+            return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, 8, false, false, true, true>);
+        }
         if constexpr (decltype(NPT)::value >= 1) {
           if (bf16) return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, decltype(NPT)::value, false, false, true>);
         }

@@ -85,7 +85,8 @@ def _mixture_logq(samples, props, dof, K):
 
 
 @pytest.mark.parametrize('dof,S,K,N', [(6, 64, 4, 96), (4, 64, 4, 96), (6, 60, 3, 70), (6, 200, 2, 130), (4, 100, 1, 33),
-                                       (6, 320, 2, 600), (6, 48, 2, 1300), (6, 32, 2, 2300), (6, 32, 2, 512), (4, 32, 2, 2040)])
+                                       (6, 320, 2, 600), (6, 48, 2, 1300), (6, 32, 2, 2300), (6, 32, 2, 512), (4, 32, 2, 2040),
+                                       (6, 32, 2, 800), (6, 40, 2, 2048)])
 def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
     """Tight check that does not depend on the (ill-conditioned) proposal fit: recompute cost and proposal mixture
     density with the oracle AT THE KERNEL'S OWN samples and fitted proposals; log-weights must agree to 1e-4."""
@@ -104,6 +105,31 @@ def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
     mix = _mixture_logq(samples, props, dof, K)
     expect = -cost - mix
     assert (logw - expect).abs().max().item() <= 2e-4 * max(1.0, expect.abs().max().item())
+
+
+@pytest.mark.parametrize('N,bounds', [(800, None), (1100, 'tight'), (2048, None)])
+def test_forward_point_tiles_in_chunks_through_the_registers(backend, monkeypatch, N, bounds):
+    """Beyond 48 point tiles per object the register-mode forward keeps 8 tiles per wave and takes the object's tiles through the
+    registers in chunks of 32 per iteration (instead of 16 resident tiles per wave / 8-wave workgroups); EPROPNP_FWD_NO_CHUNKS
+    keeps the old shapes.  Same samples in the first iteration (they do not depend on the sweep), costs to summation order."""
+    from epropnp import functional as F
+    B, S, K, dof = 2, 64, 2, 6
+    prob = orc.make_problem(B, N, dof, seed=51, bounds=bounds)
+    noise = pack_noise(orc.make_noise(B, S, K, dof, seed=52), dof).to(backend)
+    p, cam, cf = make_layer_objects(prob, backend)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
+    pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
+    monkeypatch.delenv('EPROPNP_FWD_NO_CHUNKS', raising=False)
+    s1, w1 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+    again = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+    assert torch.equal(s1, again[0]) and torch.equal(w1, again[1])
+    monkeypatch.setenv('EPROPNP_FWD_NO_CHUNKS', '1')
+    s2, w2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
+    s = S // K
+    assert torch.equal(s1[:s], s2[:s])
+    assert (w1[:s] - w2[:s]).abs().max().item() <= 2e-5 * max(1.0, w2[:s].abs().max().item())
+    assert (s1 - s2).abs().max().item() < 5e-4
+    assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3
 
 
 @pytest.mark.parametrize('impl,N', [('valu', 150), ('mfma', 150), ('mfma', 300), ('mfma', 16), ('valu', 16), ('mfma', 17)])
