@@ -63,7 +63,8 @@ if [[ $PARTS == *c* ]]; then
     i=$((i+1)); rm -rf /tmp/pmc5_$i
     (timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $set -d /tmp/pmc5_$i -o p -- $B 2>&1 | grep -E "rror|ailed" | head -3)
   done
-  [ -f $O/${TAG}_pmc_traffic.json ] || cp /root/repo/profiles/r03_pmc_traffic.json $O/${TAG}_pmc_traffic.json
+  # (without the `p` part in the same call the C2 entry is carried over from the committed profile of this round, not re-measured)
+  [ -f $O/${TAG}_pmc_traffic.json ] || cp /root/repo/profiles/${TAG}_pmc_traffic.json $O/${TAG}_pmc_traffic.json 2>/dev/null || cp /root/repo/profiles/r03_pmc_traffic.json $O/${TAG}_pmc_traffic.json
   python /root/repo/tools/pmc_traffic.py /tmp/pmc5_1 /tmp/pmc5_2 C5:B8192:N2048:S1024:K4:L3 $O/${TAG}_pmc_traffic.json
   rm -rf /tmp/prof5
   (timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof5 -o bench -- $B 2>&1 | tail -1) > $O/${TAG}_bench_C5_under_rocprof.json
