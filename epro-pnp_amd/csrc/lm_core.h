@@ -14,6 +14,18 @@ struct LmParams {
   unsigned split_timeout;   // split over workgroups: shader cycles a part waits for a sibling's partial sums (wave_ops.h)
 };
 
+// Where the LM kernel takes an object's starting pose from when the random-sample initialiser ran split over `parts` workgroups per
+// object (rslm_kernel.hip): the parts' best proposals cand[part][b][1 + pose_len] (cost first) and, optionally, a rival pose with
+// its cost (force_init_solve=True with a given pose_init: the cheaper of the two, levenberg_marquardt.py:124-130).  The winner
+// over the parts is what rslm_reduce_kernel picks (ties: the lowest part = the lowest proposal index); folded into the solve it
+// saves that launch in the one-call forward.  cand == nullptr: the plain pose_init array.
+struct StartSelect {
+  const float* cand;
+  const float* rival_pose;
+  const float* rival_cost;
+  int parts;
+};
+
 // acc (upper-tri JtJ | Jtr | cost)  ->  dense symmetric matrix
 template <int DOF>
 PNP_FN void unpack_h(const float (&acc)[NormalEq<DOF>::NV], float (&H)[DOF][DOF]) {

@@ -25,7 +25,7 @@ template <int DOF, int PPL, bool BOUNDS, int MAXW, bool SPLIT = false>
 __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(Problem p, LmParams lm, const float* __restrict__ pose_init,
                                                                float* __restrict__ pose_opt, float* __restrict__ pose_cov,
                                                                float* __restrict__ cost_out, int* __restrict__ accept_out,
-                                                               int nsplit, float* __restrict__ xch) {
+                                                               int nsplit, float* __restrict__ xch, StartSelect sel) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NH = NormalEq<DOF>::NH, NV = NormalEq<DOF>::NV;
   static_assert(!SPLIT || (MAXW > 0 && MAXW <= 4 && PPL > 0), "the split serves the register-resident <= 4-wave variants");
@@ -63,8 +63,19 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
     pts[k] = load_point(p, b, kRow ? (int)(threadIdx.x & 15u) : (SPLIT ? part * PPL * (int)blockDim.x : 0) + (int)threadIdx.x + k * (int)blockDim.x);
 
   float pose[PL];
+  const float* start = pose_init + (size_t)b * PL;
+  if (sel.cand != nullptr) {       // the split initialiser's winner (lm_core.h: StartSelect); wave-uniform except in the row variant
+    int w = 0;
+    float wc = sel.cand[(size_t)b * (PL + 1)];
+    for (int q = 1; q < sel.parts; ++q) {
+      const float c = sel.cand[((size_t)q * p.B + b) * (PL + 1)];
+      if (c < wc) { wc = c; w = q; }
+    }
+    start = sel.cand + ((size_t)w * p.B + b) * (PL + 1) + 1;
+    if (sel.rival_pose != nullptr && sel.rival_cost[b] < wc) start = sel.rival_pose + (size_t)b * PL;
+  }
 #pragma unroll
-  for (int i = 0; i < PL; ++i) pose[i] = pose_init[(size_t)b * PL + i];
+  for (int i = 0; i < PL; ++i) pose[i] = start[i];
 
   // one sweep: normal equations + cost of all points at pose `ps`
   auto sweep = [&](const float* ps, bool clip, float (&acc)[NV]) {
@@ -207,11 +218,14 @@ unsigned long long lm_split_bytes(const epropnp_problem* prob, const epropnp_lm_
 
 int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
                     float* pose_cov, float* cost, int32_t* accept_mask, void* split_scratch,
-                    unsigned long long split_scratch_bytes, hipStream_t st) {
+                    unsigned long long split_scratch_bytes, hipStream_t st, const StartSelect* select) {
   if (int rc = check_problem(prob)) return rc;
   if (!lm) return fail(EPROPNP_EINVAL, "lm_solve: params NULL");
   if (prob->num_obj == 0) return EPROPNP_OK;
-  if (!pose_init || !pose_opt) return fail(EPROPNP_EINVAL, "lm_solve: NULL pose pointer");
+  StartSelect sel;
+  sel.cand = nullptr; sel.rival_pose = nullptr; sel.rival_cost = nullptr; sel.parts = 0;
+  if (select != nullptr && select->cand != nullptr) sel = *select;
+  if ((!pose_init && sel.cand == nullptr) || !pose_opt) return fail(EPROPNP_EINVAL, "lm_solve: NULL pose pointer");
   if (lm->num_iter < 0 || lm->num_iter > 31 * 1000) return fail(EPROPNP_EINVAL, "lm_solve: bad num_iter");
   const Problem d = to_device_problem(prob);
   LmParams k;
@@ -223,7 +237,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
     const dim3 grid((d.B + 15) / 16), block(256);
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 1, decltype(BND)::value, 0>), grid, block, 0, st, d, k, pose_init,
-                 pose_opt, pose_cov, cost, accept_mask, 1, (float*)nullptr);
+                 pose_opt, pose_cov, cost, accept_mask, 1, (float*)nullptr, sel);
       return 0;
     });
     return check_launch("lm_solve_kernel (row variant)");
@@ -233,7 +247,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 0, decltype(BND)::value, 8>), grid, block,
                  sizeof(float) * NormalEq<decltype(DOF)::value>::NV * 16, st, d, k, pose_init, pose_opt, pose_cov, cost,
-                 accept_mask, 1, (float*)nullptr);
+                 accept_mask, 1, (float*)nullptr, sel);
       return 0;
     });
     return check_launch("lm_solve_kernel (streaming)");
@@ -255,13 +269,13 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
         const size_t smem = sizeof(float) * (4 * kSumTStride<NVc> + 32 + 8 * NVc + 4);
         if (ppl == 4) {
           PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 4, decltype(BND)::value, 4, true>), grid, block, smem, st, d, k,
-                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch);
+                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch, sel);
         } else if (ppl == 2) {
           PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 2, decltype(BND)::value, 4, true>), grid, block, smem, st, d, k,
-                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch);
+                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch, sel);
         } else {
           PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 1, decltype(BND)::value, 4, true>), grid, block, smem, st, d, k,
-                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch);
+                     pose_init, pose_opt, pose_cov, cost, accept_mask, G, (float*)split_scratch, sel);
         }
         return 0;
       });
@@ -279,7 +293,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
                grid, block,
                sizeof(float) * (decltype(MAXW)::value <= 4 ? s.waves * kSumTStride<NormalEq<decltype(DOF)::value>::NV>
                                                            : NormalEq<decltype(DOF)::value>::NV * 16),
-               st, d, k, pose_init, pose_opt, pose_cov, cost, accept_mask, 1, (float*)nullptr);
+               st, d, k, pose_init, pose_opt, pose_cov, cost, accept_mask, 1, (float*)nullptr, sel);
     return 0;
   });
   return check_launch("lm_solve_kernel");

@@ -6,6 +6,7 @@
 // the host -- allocator calls, ctypes marshalling, autograd-node bookkeeping around each of ~10 launches -- against
 // ~0.2 ms of GPU work.  Stream-ordered and free of host synchronisation, so it is hipGraph-capturable like its parts.
 #include "dispatch.h"
+#include "lm_core.h"
 #include "pnp_host.h"
 
 namespace pnp {
@@ -61,14 +62,21 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
     if ((rc = launch_evaluate_cost(&q, pinit, 1, cost_init, st))) return rc;
   }
   const float* start = pinit;
+  StartSelect sel;            // RSLM split over workgroups: its reduce (and the cheaper-of-two selection) runs inside the LM launch
+  sel.cand = nullptr; sel.rival_pose = nullptr; sel.rival_cost = nullptr; sel.parts = 0;
   bool selected = false;      // the cheaper-of-two selection was folded into the RSLM reduce launch
   if (par->init_mode != 0) {  // random-sample initialiser (levenberg_marquardt.py:115-130,283-353)
     StageScope ps("rslm_solve", st);
     if ((rc = launch_rslm_solve(&q, &par->rslm_lm, par->rslm_proposals, par->rslm_points, par->rslm_seed, par->rslm_offset,
                                 (const unsigned long long*)par->rslm_offset_dev, (const long long*)par->rslm_inds,
                                 par->rslm_rot, start_pose, start_cost, par->rslm_scratch, par->rslm_scratch_bytes, st,
-                                par->init_mode == 2 ? pinit : nullptr, par->init_mode == 2 ? cost_init : nullptr, &selected)))
+                                par->init_mode == 2 ? pinit : nullptr, par->init_mode == 2 ? cost_init : nullptr, &selected,
+                                &sel.parts)))
       return rc;
+    if (sel.parts > 1) {      // no reduce launch was made: the LM kernel picks the winner itself
+      sel.cand = (const float*)par->rslm_scratch;
+      if (par->init_mode == 2) { sel.rival_pose = pinit; sel.rival_cost = cost_init; }
+    }
     if (par->init_mode == 2 && !selected) {
       PNP_LAUNCH(select_start_kernel, dim3((B * PL + 255) / 256), dim3(256), 0, st, pinit, cost_init, start_pose, start_cost,
                  B, PL);
@@ -76,7 +84,7 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
     }
     start = start_pose;
   }
-  { StageScope ps("lm_solve", st); if ((rc = launch_lm_solve(&q, &par->lm, start, pose_opt_n, pose_cov, cost, nullptr, par->lm_scratch, par->lm_scratch_bytes, st))) return rc; }
+  { StageScope ps("lm_solve", st); if ((rc = launch_lm_solve(&q, &par->lm, start, pose_opt_n, pose_cov, cost, nullptr, par->lm_scratch, par->lm_scratch_bytes, st, sel.cand ? &sel : nullptr))) return rc; }
   { StageScope ps("amis_forward", st); if ((rc = launch_amis_forward(&q, &par->amis, pose_opt_n, pose_cov, noise, pose_samples_n, logweights, nullptr, st))) return rc; }
   if (par->normalize) {       // pnp_denormalize (common.py:127-136)
     StageScope ps("shift_poses", st);

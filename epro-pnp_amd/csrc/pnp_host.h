@@ -165,7 +165,7 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
                       unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
                       float* pose_out, float* cost_out, void* scratch, unsigned long long scratch_bytes,
                       hipStream_t st, const float* rival_pose = nullptr, const float* rival_cost = nullptr,
-                      bool* rival_taken = nullptr);
+                      bool* rival_taken = nullptr, int* deferred_parts = nullptr);
 unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int num_proposals);
 int launch_shift_poses_pair(const float* pose_a, float* out_a, int Pa, const float* pose_b, float* out_b, int Pb,
                             const float* offset, int B, int dof, float sign, hipStream_t st);
@@ -207,9 +207,10 @@ int launch_mc_loss_reduce_backward(const float* logw, const float* lse, const fl
                                    const float* gout, int S, int B, float* glogw, float* gct, hipStream_t st);
 int launch_mc_loss_backward(const float* logw, const float* lse, const float* loss, const float* g, int S, int B,
                             float* glogw, float* gct, hipStream_t st);
+struct StartSelect;      // lm_core.h
 int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, const float* pose_init, float* pose_opt,
                     float* pose_cov, float* cost, int32_t* accept_mask, void* split_scratch,
-                    unsigned long long split_scratch_bytes, hipStream_t st);
+                    unsigned long long split_scratch_bytes, hipStream_t st, const StartSelect* select = nullptr);
 unsigned long long lm_split_bytes(const epropnp_problem* prob, const epropnp_lm_params* lm);
 int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
                         const float* pose_cov, const float* noise, float* pose_samples, float* logweights,

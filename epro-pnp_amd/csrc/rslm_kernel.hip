@@ -361,7 +361,11 @@ unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int P) {
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
                       unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
                       float* pose_out, float* cost_out, void* scratch, unsigned long long scratch_bytes, hipStream_t st,
-                      const float* rival_pose, const float* rival_cost, bool* rival_taken) {
+                      const float* rival_pose, const float* rival_cost, bool* rival_taken, int* deferred_parts) {
+  // deferred_parts != nullptr: when the proposals are dealt to several workgroups per object the reduce launch is LEFT OUT and
+  // *deferred_parts = parts (> 1) tells the caller to hand `scratch` to the LM launch as its start selection (lm_core.h:
+  // StartSelect); pose_out / cost_out are then not written.  *deferred_parts = 0: pose_out holds the start as usual.
+  if (deferred_parts) *deferred_parts = 0;
   if (rival_taken) *rival_taken = false;
   if (int rc = check_problem(prob)) return rc;
   if (!lm) return fail(EPROPNP_EINVAL, "rslm_solve: params NULL");
@@ -389,6 +393,11 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
                offset, offset_dev, inds, rot, pose_out, cost_out, parts, (float*)scratch);
     return 0;
   });
+  if (parts > 1 && deferred_parts != nullptr) {
+    *deferred_parts = parts;
+    if (rival_taken) *rival_taken = rival_pose != nullptr && rival_cost != nullptr;
+    return check_launch("rslm_solve_kernel");
+  }
   if (parts > 1) {
     if (int rc = check_launch("rslm_solve_kernel")) return rc;
     const dim3 rgrid((d.B + 255) / 256);

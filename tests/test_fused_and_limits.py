@@ -27,6 +27,37 @@ def test_fused_forward_equals_composite(backend, monkeypatch, dof, normalize, rs
     _fused_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bounds, 5, 70, 32, 2, 3)
 
 
+@pytest.mark.parametrize('dof,normalize,force,bounds', [(4, True, True, 'tensor'), (6, False, True, None), (6, True, False, 'tight')])
+def test_rslm_split_winner_is_picked_inside_the_lm_launch(backend, monkeypatch, dof, normalize, force, bounds):
+    """With the initialiser's proposals dealt to several workgroups per object (EPROPNP_RSLM_PARTS, the default at <= 768 objects on
+    the GPU) the one-call forward leaves the reduce launch out: the LM kernel picks the winner over the parts -- and, with
+    force_init_solve on a given pose_init, the cheaper of that and pose_init -- itself (lm_core.h: StartSelect).  Same bits as one
+    workgroup per object, whose start goes through the plain pose array."""
+    B, N, S, K, L = 5, 90, 32, 2, 3
+    prob = orc.make_problem(B, N, dof, seed=61, bounds=bounds)
+    prob['pose_init'][0, :3] += 3.0                        # object 0: a bad pose_init, so the initialiser's start wins there
+    noise = pack_noise(orc.make_noise(B, S, K, dof, seed=62), dof).to(backend)
+    outs = []
+    for parts in ('1', '2', '4'):
+        monkeypatch.setenv('EPROPNP_RSLM_PARTS', parts)
+        p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
+        x3d, x2d, w2d = (p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+        cf.set_param(x2d.detach(), w2d)
+        from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+        from epropnp.levenberg_marquardt import LMSolver, RSLMSolver
+        init = RSLMSolver(dof=dof, num_points=12, num_proposals=64, num_iter=2)
+        layer = (EProPnP6DoF if dof == 6 else EProPnP4DoF)(mc_samples=S, num_iter=K, normalize=normalize, seed=9,
+                                                          solver=LMSolver(dof=dof, num_iter=L, init_solver=init))
+        torch.manual_seed(5)                               # the initialiser's Philox offset comes from torch's generator
+        o = layer.monte_carlo_forward(x3d, x2d, w2d, cam, cf, pose_init=p['pose_init'] if force else None,
+                                      force_init_solve=force, noise=noise)
+        (o[4].logsumexp(0).sum() + (o[5].sum() if o[5] is not None else 0.0)).backward()
+        outs.append([t.detach().clone() for t in (o[0], o[3], o[4], x3d.grad, w2d.grad)])
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def _sweep_cases(n, seed):
     import random
     rng = random.Random(seed)
