@@ -87,63 +87,87 @@ def synth_problem(B, N, device, seed, dof=6, cam='pinhole800'):
                 pose_gt=pose_gt)
 
 
-def cpu_baseline(N, S, K, L, sample_objects, budget_s=25.0):
-    """The oracle (oracle/epropnp_oracle.py) timed on the host cores on `sample_objects` objects of the same
-    workload: monte_carlo_forward + MC loss + backward.  Test/baseline infrastructure -- never the product path.
-    torch-CPU oversubscribes badly on many-core hosts (256 threads on small tensors is ~100x slower than 16),
-    so a few thread counts are tried and the best is reported together with the thread count actually used; BASELINE.md
-    section 3 also asks for the 1-thread and the all-cores figures: both are timed on a smaller sample of the same workload
-    (bounded: one warm-up + one timed run each) and reported beside the headline value."""
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(N, S, K, L, total_objects=1024, chunk=64, one_thread_objects=16):
+    """The oracle (oracle/epropnp_oracle.py) timed on the host cores by BASELINE.md section 3's procedure: `total_objects`
+    (>= 1024 at C2) objects of the same workload -- monte_carlo_forward + MC loss + backward -- in chunks of `chunk` <= 256
+    objects (the reference keeps ~12 MB per object alive for its backward), one warm-up chunk, MEDIAN of 3 passes over all the
+    chunks.  Test / baseline infrastructure -- never the product path.
+    torch-CPU oversubscribes badly on many-core hosts (256 threads on these small ops is ~1000x slower than 16), so the headline
+    `value` is the best of a few thread counts (chosen on one chunk, then the full procedure at that count), and the dict
+    carries the 1-thread figure and the os.cpu_count()-thread figure beside it: the latter on a tiny sample in a bounded
+    subprocess (it reports an upper bound when the run does not finish in time).  `reference_vs_port` quotes the
+    build-container timing of the UNMODIFIED reference next to this oracle (oracle/time_reference_vs_oracle.py)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import epropnp_oracle as orc
     host_cores = os.cpu_count() or 1
-    prob = synth_problem(sample_objects, N, torch.device('cpu'), seed=0)
-    noise = orc.make_noise(sample_objects, S, K, 6, seed=1)
-    best, best_threads, tried = None, None, []
-    t_start = time.perf_counter()
+    chunk = min(chunk, 256, total_objects)
+    prob = synth_problem(total_objects, N, torch.device('cpu'), seed=0)
+    noise = orc.make_noise(total_objects, S, K, 6, seed=1)
+
+    def piece(lo, hi):
+        return ({k: v[lo:hi].contiguous() for k, v in prob.items()}, {k: v[:, :, lo:hi].contiguous() for k, v in noise.items()})
+
+    def one_pass(objects, size):
+        t0 = time.perf_counter()
+        for lo in range(0, objects, size):
+            pp, nn = piece(lo, min(objects, lo + size))
+            orc.run_mc(pp, nn, 6, S, K, L)
+        return time.perf_counter() - t0
+    # thread count: one chunk each (1 warm-up + 2 timed), the best goes through the full procedure
+    tried = []
     for threads in sorted({min(host_cores, t) for t in (8, 16, 32)}):
         torch.set_num_threads(threads)
-        times = []
-        for it in range(6):
-            t0 = time.perf_counter()
-            orc.run_mc(prob, noise, 6, S, K, L)
-            times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_start > budget_s:
-                break
-        t = min(times[1:]) if len(times) > 1 else times[0]
-        tried.append((threads, round(sample_objects / t, 1)))
-        if best is None or t < best:
-            best, best_threads = t, threads
-        if time.perf_counter() - t_start > budget_s:
-            break
-    # 1 thread / every core, on `small` objects of the same workload (a 1-thread run of the full sample would take minutes)
-    small = max(1, min(sample_objects, 8))
-    sp = {k: v[:small].contiguous() for k, v in prob.items()}
-    sn = {k: v[:, :, :small].contiguous() for k, v in noise.items()}
-    extra = {}
-    for label, threads in (('one_thread', 1), ('all_cores', host_cores)):
-        if threads > 64 and os.environ.get('BENCH_CPU_ALL_CORES', '0') != '1':
-            # torch.set_num_threads(os.cpu_count()) on a many-core host spends its time waking threads for ~10^5 small ops: measured
-            # on the 256-core MI355X host 0.06 ... 0.21 instances/s, 30-40 s of wall time whatever the sample (round 4, BENCH_r04 runs;
-            # BENCH_CPU_ALL_CORES=1 measures it again).  Not timed by default: it tripled the duration of the default bench run.
-            extra[label] = {'value': None, 'unit': 'instances/s', 'cores': threads,
-                            'sample': 'not timed by default on > 64 cores (0.06-0.21 instances/s when it was: thread oversubscription); BENCH_CPU_ALL_CORES=1'}
-            continue
-        torch.set_num_threads(threads)
-        ts = []
-        for it in range(2):
-            t0 = time.perf_counter()
-            orc.run_mc(sp, sn, 6, S, K, L)
-            ts.append(time.perf_counter() - t0)
-            if ts[-1] > 15.0:
-                break
-        extra[label] = {'value': round(small / min(ts), 2), 'unit': 'instances/s', 'cores': threads,
-                        'sample': f'{small} objects, best of {len(ts)} run(s)'}
+        ts = [one_pass(chunk, chunk) for _ in range(3)]
+        tried.append((threads, round(chunk / min(ts[1:]), 1)))
+    best_threads = max(tried, key=lambda t: t[1])[0]
     torch.set_num_threads(best_threads)
-    return dict(value=round(sample_objects / best, 2), unit='instances/s', cores=best_threads, kind='port',
-                host_cores=host_cores, tried_threads_inst_per_s=tried, one_thread=extra['one_thread'], all_cores=extra['all_cores'],
-                sample=f'{sample_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd, oracle = PyTorch-CPU restatement '
-                       f'with the reference op structure), best of 5 after 1 warm-up per thread count; larger CPU batches are slower per object (256 objects: 100/s)')
+    one_pass(chunk, chunk)                                       # warm-up at the chosen thread count
+    passes = [one_pass(total_objects, chunk) for _ in range(3)]
+    value = total_objects / _median(passes)
+    # one thread: BASELINE.md's 1-thread figure, same procedure on `one_thread_objects` objects
+    torch.set_num_threads(1)
+    k1 = min(one_thread_objects, total_objects)
+    one_pass(min(4, k1), min(4, k1))
+    t1 = [one_pass(k1, k1) for _ in range(3)]
+    one_thread = {'value': round(k1 / _median(t1), 2), 'unit': 'instances/s', 'cores': 1,
+                  'sample': f'{k1} objects in one chunk, median of 3 after a warm-up'}
+    torch.set_num_threads(best_threads)
+    # every core (torch.set_num_threads(os.cpu_count())): in a subprocess with a wall-clock bound
+    all_cores = {'value': round(value, 2), 'unit': 'instances/s', 'cores': host_cores, 'sample': 'the headline run (best thread count = all cores)'}
+    if host_cores != best_threads:
+        import subprocess
+        n_all, bound_s = 4, float(os.environ.get('BENCH_CPU_ALL_CORES_BOUND_S', '25'))
+        code = (f'import sys, time, json, torch; sys.path[:0] = [{os.path.join(ROOT, "oracle")!r}, {ROOT!r}]\n'
+                f'import bench, epropnp_oracle as orc\n'
+                f'torch.set_num_threads({host_cores})\n'
+                f'p = bench.synth_problem({n_all}, {N}, torch.device("cpu"), seed=0); n = orc.make_noise({n_all}, {S}, {K}, 6, seed=1)\n'
+                f't0 = time.perf_counter(); orc.run_mc(p, n, 6, {S}, {K}, {L}); print(json.dumps(time.perf_counter() - t0))\n')
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=bound_s)
+            t_all = float(r.stdout.strip().splitlines()[-1])
+            all_cores = {'value': round(n_all / t_all, 3), 'unit': 'instances/s', 'cores': host_cores,
+                         'sample': f'{n_all} objects, ONE run without warm-up in a fresh process (thread oversubscription: ~1e5 small ops each waking {host_cores} threads)'}
+        except Exception as e:      # timed out (or failed): an upper bound is what was measured
+            all_cores = {'value': None, 'upper_bound': round(n_all / max(time.perf_counter() - t0, 1e-9), 3), 'unit': 'instances/s', 'cores': host_cores,
+                         'sample': f'{n_all} objects did not finish within {bound_s:.0f} s ({type(e).__name__}); BENCH_CPU_ALL_CORES_BOUND_S raises the bound'}
+    ref = None
+    try:
+        ref = json.load(open(os.path.join(ROOT, 'profiles', 'r05_cpu_reference_vs_oracle.json')))
+        ref['source'] = 'profiles/r05_cpu_reference_vs_oracle.json'
+    except (OSError, ValueError):
+        pass
+    return dict(value=round(value, 2), unit='instances/s', cores=best_threads, kind='port', host_cores=host_cores,
+                procedure=f'BASELINE.md section 3: {total_objects} objects in chunks of {chunk}, 1 warm-up chunk, median of 3 passes',
+                pass_seconds=[round(t, 3) for t in passes], tried_threads_inst_per_s_one_chunk=tried,
+                one_thread=one_thread, all_cores=all_cores, reference_vs_port=ref,
+                sample=f'{total_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd; oracle = PyTorch-CPU restatement with the '
+                       f'reference op structure) in chunks of {chunk} objects on {best_threads} threads; larger CPU chunks are slower per object (256: ~100/s)')
 
 
 def hipgraph_replay():
@@ -208,7 +232,9 @@ def measured_traffic(kernel, shape_key):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json, written by
     tools/pmc_traffic.py from separate --pmc runs; gfx950 corrections applied there) -- None when no profile of this
     exact shape is on file, so a stale number can never be attached to a changed workload."""
-    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):      # newest committed profile of this shape
+    # newest committed profile of this shape.  (r04_pmc_traffic.json is not consulted: its C2 `normal_equations_kernel` entry averages
+    # 121 C2-size with 27 C5-size dispatches -- tools/pmc_traffic.py grouped by kernel name only then; it groups by launch size now.)
+    for name in ('r05_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name))).get(shape_key, {}).get(kernel)
         except (OSError, ValueError):
@@ -263,7 +289,10 @@ def main(argv=None, device=None, backend='nccl'):
     ap.add_argument('--lm-iters', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hipgraph', action='store_true', help='skip the informational hipGraph replay measurement')
-    ap.add_argument('--cpu-sample', type=int, default=64)
+    ap.add_argument('--cpu-sample', type=int, default=1024, help='objects of the workload the cpu_baseline leg times (in chunks of 64)')
+    ap.add_argument('--no-large-sweep', action='store_true',
+                    help="skip `roofline.large` (the C5-size Jacobian sweep): the PMC passes of the C2 workload use it so that every "
+                         "normal_equations_kernel dispatch of the process has the C2 launch size")
     ap.add_argument('--launch', choices=['auto', 'eager', 'graph'], default='auto',
                     help="'graph': the rank's whole step (RCCL exchange included) captured once into a hipGraph; the timed "
                          "region replays it (fresh samples per replay).  'auto' (default): graph for the launch-bound Det "
@@ -509,6 +538,22 @@ def main(argv=None, device=None, backend='nccl'):
         assert torch.equal(gathered['pose_opt'][lo_:hi_], own), 'gathered poses differ from the local ones'
         gathered_bytes = int(gathered['pose_opt'].numel() * 4 + 4)      # (the A/B below re-runs the step WITHOUT the exchange)
 
+    # The same steps with the per-stage HIP events INSIDE the timed window -- rounds 1-3 timed the step that way -- so that the
+    # headline can be compared like for like with BENCH_r01..r03 (~16 event records per step: ~3 % of a 1.5 ms step).
+    events_in_region = None
+    if on_gpu and launch == 'eager' and not prof_in_region and args.config not in LAUNCH_BOUND and world == 1:
+        n_ev = min(args.steps, 100)
+        fence()
+        _hip.profile(enable=True, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(n_ev):
+            step(timed=True)
+        fence()
+        t_ev = time.perf_counter() - t0
+        _hip.profile(enable=False)
+        events_in_region = {'ms_per_step': round(t_ev / n_ev * 1e3, 4), 'value': round(total * n_ev / t_ev, 1), 'unit': 'instances/s',
+                            'steps': n_ev, 'note': 'per-stage HIP events recorded inside this window (the protocol of BENCH_r01..r03)'}
+
     eager_ms = None
     if graph is not None:     # what a caller who just swaps the package gets: the same K steps launched eagerly, same run
         for _ in range(max(args.warmup, 3)):
@@ -585,7 +630,7 @@ def main(argv=None, device=None, backend='nccl'):
         # roofline.large (default C2 line only): the same kernel on the C5-shard sweep, 470 MB per launch -- IC-cold by
         # construction and long enough (~0.1 ms) that launch ramp and tail do not set the figure
         large = None
-        if args.config == 'C2' and default_shape and world == 1:
+        if args.config == 'C2' and default_shape and world == 1 and not args.no_large_sweep:
             LB, LN = LARGE_SWEEP
             lp = synth_problem(LB, LN, dev, seed=77, dof=6)
             l_bytes = LB * (28.0 * LN + 4.0 * (7 + 9 + 1 + 4) + 4.0 * (21 + 6 + 1))
@@ -616,7 +661,9 @@ def main(argv=None, device=None, backend='nccl'):
                               else 'split projection (default)')),
             'launch': 'eager' if launch == 'eager' else 'hipGraph replay of the whole rank step, RCCL exchange included (captured once; fresh samples per replay)',
             'launch_note': launch_note,
-            'kernel_ms_source': 'HIP events inside the library over the timed region' if prof_in_region else f'HIP events inside the library over {prof_steps} eager steps before the timed region',
+            'kernel_ms_source': 'HIP events inside the library over the timed region' if prof_in_region else
+                                (f'HIP events inside the library over {prof_steps} eager steps BEFORE the timed region -- a separate window, and every event pair '
+                                 f'adds ~2.5 us to its stage: the sum of kernel_ms may exceed ms_per_step by ~1 %'),
             'config': {'workload': f'{names[args.config]}: {B} objects/GPU x N={N} points, S={S} MC samples, '
                                    f'K={K} AMIS iters, L={L} LM iters, EProPnP{dof}DoF fwd+bwd'
                                    + (', RSLM(16,64,3) init, normalize=True, Det loss' if args.config == 'C4' else '')
@@ -650,15 +697,20 @@ def main(argv=None, device=None, backend='nccl'):
                                       'credited_bytes_per_launch': lm_bytes,
                                       'credited_achieved': round(lm_gbs, 1), 'credited_frac': round(lm_gbs / HBM_PEAK_GBS, 4)}},
             'roofline_valu': {
-                'amis_forward_mfma_kernel': {'bound': 'valu_fp32', 'achieved': round(fw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
+                'what': ('fp32-EQUIVALENT work per second against the fp32 vector peak: SURVEY 8(d) nominal 40 / 80 flop per point-pose; 24 of them '
+                         'are the projection, which executes as bf16x3-split products on the matrix pipe (v_mfma_f32_16x16x32_bf16), the rest on the VALU -- '
+                         'so `frac` is not a utilisation of the fp32 units (DESIGN.md section 4)'),
+                'amis_forward_mfma_kernel': {'bound': 'fp32-equivalent (projection on bf16 MFMA, the rest on the VALU)', 'achieved': round(fw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
                                         'unit': 'TFLOP/s', 'frac': round(fw_tf / FP32_VECTOR_PEAK_TF, 4),
                                         'flops_per_point_pose': 40, 'launch_ms': round(t_fw, 4)},
-                'amis_backward_mfma_kernel': {'bound': 'valu_fp32', 'achieved': round(bw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
+                'amis_backward_mfma_kernel': {'bound': 'fp32-equivalent (projection on bf16 MFMA, the rest on the VALU)', 'achieved': round(bw_tf, 2), 'peak': FP32_VECTOR_PEAK_TF,
                                          'unit': 'TFLOP/s', 'frac': round(bw_tf / FP32_VECTOR_PEAK_TF, 4),
                                          'flops_per_point_pose': 80, 'launch_ms': round(t_bw, 4)}},
             'kernel_ms': {n: round(v[0] * (v[1] / prof_steps), 4) for n, v in stage_ms.items() if v[1]},   # per step
             'loss': round(loss_val, 5),
         }
+        if events_in_region is not None:
+            out['with_stage_events_in_region'] = events_in_region
         if eager_ms is not None:
             out['eager'] = {'ms_per_step': round(eager_ms, 4), 'value': round(total / (eager_ms * 1e-3), 1), 'unit': 'instances/s',
                             'note': 'the same steps launched eagerly in this run (host-bound: ~20 launches per step)'}
@@ -676,7 +728,8 @@ def main(argv=None, device=None, backend='nccl'):
                                  'gathered_equals_local_bitwise': True,
                                  'replayed_step_check': replay_check}
         if world == 1 and not args.no_cpu_baseline and args.config in ('C2', 'C5'):
-            out['cpu_baseline'] = cpu_baseline(N, S, K, L, args.cpu_sample if args.config == 'C2' else 8)
+            out['cpu_baseline'] = (cpu_baseline(N, S, K, L, args.cpu_sample) if args.config == 'C2'
+                                   else cpu_baseline(N, S, K, L, total_objects=8, chunk=8, one_thread_objects=2))
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
         if world == 1 and not args.no_hipgraph and args.config == 'C2' and default_shape:
             out['hipgraph_replay'] = hipgraph_replay()      # informational: the same step replayed from a hipGraph
