@@ -351,6 +351,30 @@ def case_preprocess():
          w2d=ns2['w2d_scaled'])
 
 
+def case_callers():
+    """tests/golden/callers_{notebook,linemod_train,det_head}.npz: the reference's OWN callers (literal source, read from the
+    checkout at run time by oracle/run_callers.py) executed against the unmodified reference -- losses, pose_opt_plus, the
+    gradients that reach the network outputs.  The GPU box runs the restated slices (oracle/callers_restated.py) on the package
+    against these; here the restatement is pinned to the literal source on the reference itself: identical bits."""
+    import subprocess
+    import tempfile
+    import run_callers as rcall
+    with tempfile.TemporaryDirectory() as tmp:
+        for scenario, fname in rcall.FIXTURES.items():
+            lit = rcall.write_fixture(scenario, os.path.join(OUT, fname), tmp)
+            run = rcall.FIXTURE_RUN[scenario]
+            path = os.path.join(tmp, scenario + '_restated.npz')
+            subprocess.run([sys.executable, os.path.join(HERE, 'run_callers.py'), '--side', 'reference', '--scenario', scenario, '--restated',
+                            '--out', path, '--objects', str(run['objects']), '--steps', str(run['steps'])], check=True, capture_output=True,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
+            res = dict(np.load(path))
+            keys = [k for k in lit if not k.startswith(('spread.', 'meta.'))]
+            assert set(keys) == set(res), (scenario, set(keys) ^ set(res))
+            worst = max(float(np.abs(res[k].astype(lit[k].dtype) - lit[k]).max()) for k in keys)
+            REPORT.append((fname[:-4], 'restated slice vs literal source (on the reference)', worst, 0.0))
+            assert worst == 0.0, (scenario, worst)
+
+
 def main():
     case_evaluate('eval6', 6, 6, 40, None, 10)
     case_evaluate('eval6_clip', 6, 6, 40, 'tight', 11)
@@ -376,6 +400,7 @@ def main():
     case_losses('losses', 8)
     case_preprocess()
     case_signatures('signatures')
+    case_callers()
     w = max(len(n) for n, *_ in REPORT)
     for n, k, d, tol in REPORT:
         print(f'{n:<{w}}  {k:<32} maxdiff {d:.3e}   tol {tol:.1e}')

@@ -120,19 +120,12 @@ def setup_reference(draws):
     return names, torch.device('cpu')
 
 
-def setup_package(draws):
-    sys.path.insert(0, os.path.join(ROOT, 'epro-pnp_amd'))
-    for p in (os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'emu')):
-        sys.path.insert(0, p)
+def patch_package(draws):
+    """The package's classes under the names the scenarios use, with the layer's entry points wrapped so that every call
+    consumes the next seeded draws (AMIS noise through the `noise=` keyword, RSLM sub-samples / rotations through the
+    initialiser's `draw` hook).  Returns (names, restore): `restore()` puts the unwrapped methods back (tests)."""
     from epropnp import builder, camera, common, cost_fun, epropnp, levenberg_marquardt, losses
     assert epropnp.__file__.startswith(ROOT)
-    if torch.cuda.is_available():
-        dev = torch.device('cuda:0')
-    else:
-        import conftest
-        import install as emu
-        emu.install(conftest._emu_lib())
-        dev = torch.device('cpu')
     from helpers import pack_noise
     Base = epropnp.EProPnPBase
 
@@ -158,6 +151,9 @@ def setup_package(draws):
         arm(self, x2d, None)
         return fw0(self, x3d, x2d, *a, **k)
     Base.monte_carlo_forward, Base.forward = mc, fw
+
+    def restore():
+        Base.monte_carlo_forward, Base.forward = mc0, fw0
     names = dict(EProPnP6DoF=epropnp.EProPnP6DoF, EProPnP4DoF=epropnp.EProPnP4DoF, LMSolver=levenberg_marquardt.LMSolver,
                  RSLMSolver=levenberg_marquardt.RSLMSolver, PerspectiveCamera=camera.PerspectiveCamera,
                  AdaptiveHuberPnPCost=cost_fun.AdaptiveHuberPnPCost, evaluate_pnp=common.evaluate_pnp,
@@ -167,7 +163,52 @@ def setup_package(draws):
         type='EProPnP4DoF', mc_samples=512, num_iter=4, normalize=True,
         solver=dict(type='LMSolver', num_iter=10, normalize=True,
                     init_solver=dict(type='RSLMSolver', num_points=16, num_proposals=64, num_iter=3))))
-    return names, dev
+    return names, restore
+
+
+def setup_package(draws):
+    sys.path.insert(0, os.path.join(ROOT, 'epro-pnp_amd'))
+    for p in (os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'emu')):
+        sys.path.insert(0, p)
+    if torch.cuda.is_available():
+        dev = torch.device('cuda:0')
+    else:
+        import conftest
+        import install as emu
+        emu.install(conftest._emu_lib())
+        dev = torch.device('cpu')
+    return patch_package(draws)[0], dev
+
+
+SEEDS = {'notebook': 1000, 'train6dof': 2000, 'det': 3000}
+FIXTURES = {'notebook': 'callers_notebook.npz', 'train6dof': 'callers_linemod_train.npz', 'det': 'callers_det_head.npz'}
+FIXTURE_RUN = {'notebook': dict(objects=4, steps=3), 'train6dof': dict(objects=4, steps=2), 'det': dict(objects=4, steps=2)}
+
+
+def write_fixture(scenario, out_path, tmp_dir):
+    """tests/golden/callers_*.npz: what the UNMODIFIED reference computes when its own caller's literal source is executed
+    (this script, --side reference, in a subprocess: the reference and the package share the import name `epropnp`), stored
+    as float32 -- the GPU box compares the package against these (tests/test_callers_gpu.py).  The notebook fixture also
+    carries `spread.<key>`: how far each output of the reference itself moves under a 2e-7 relative jitter of the network
+    inputs (the yardstick of tests/test_reference_callers.py::test_notebook_cells_run_unchanged)."""
+    import subprocess
+    run = FIXTURE_RUN[scenario]
+
+    def ref(tag, *extra):
+        path = os.path.join(tmp_dir, f'{scenario}_{tag}.npz')
+        cmd = [sys.executable, os.path.abspath(__file__), '--side', 'reference', '--scenario', scenario, '--out', path,
+               '--objects', str(run['objects']), '--steps', str(run['steps'])] + list(extra)
+        subprocess.run(cmd, check=True, capture_output=True, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
+        return dict(np.load(path))
+    res = ref('ref')
+    arrays = {k: (v.astype(np.float64) if k == 'printed' else v.astype(np.float32)) for k, v in res.items()}
+    if scenario == 'notebook':
+        jit = ref('jit', '--jitter', '2e-7')
+        for k in res:
+            arrays['spread.' + k] = np.float64(np.abs(jit[k] - res[k]).max())
+    arrays['meta.objects'], arrays['meta.steps'] = np.int64(run['objects']), np.int64(run['steps'])
+    np.savez_compressed(out_path, **arrays)
+    return arrays
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -346,12 +387,17 @@ def main():
     ap.add_argument('--objects', type=int, default=4)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--jitter', type=float, default=0.0, help='notebook: relative perturbation of the network inputs (yardstick run)')
+    ap.add_argument('--restated', action='store_true', help='run oracle/callers_restated.py (our restatement of the same slices: what the '
+                                                            'GPU box runs) instead of the literal reference source')
     a = ap.parse_args()
     assert os.path.isdir(os.path.join(REF_ROOT, 'epropnp')), 'reference checkout not found (build container only)'
     torch.set_num_threads(4)
-    draws = Draws(seed={'notebook': 1000, 'train6dof': 2000, 'det': 3000}[a.scenario])
+    draws = Draws(seed=SEEDS[a.scenario])
     names, dev = setup_reference(draws) if a.side == 'reference' else setup_package(draws)
     fn = dict(notebook=scenario_notebook, train6dof=scenario_train6dof, det=scenario_det)[a.scenario]
+    if a.restated:
+        import callers_restated
+        fn = callers_restated.SCENARIOS[a.scenario]
     out = fn(names, dev, a.objects, a.steps, a.jitter) if a.scenario == 'notebook' else fn(names, dev, a.objects, a.steps)
     np.savez(a.out, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     print(f'{a.side}/{a.scenario}: {len(out)} arrays, {draws.calls} layer calls -> {a.out}')

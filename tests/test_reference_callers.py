@@ -19,7 +19,17 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'epropnp')),
                                 reason='the reference checkout is only present in the build container')
 
 
+_CACHE = {}
+
+
 def _run(side, scenario, out, *extra):
+    key = (side, scenario) + tuple(extra)
+    if key not in _CACHE:
+        _CACHE[key] = _run_uncached(side, scenario, out, *extra)
+    return _CACHE[key]
+
+
+def _run_uncached(side, scenario, out, *extra):
     cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'run_callers.py'), '--side', side, '--scenario', scenario, '--out', out,
            '--objects', '4'] + list(extra)
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')      # both sides on the CPU (emulation build)
@@ -90,3 +100,22 @@ def test_notebook_cells_run_unchanged(tmp_path):
         assert err <= 10 * spread + 1e-3 * max(np.abs(ref[k]).max(), 1.0), (k, err, spread)
     # what the user sees: the printed losses of every step
     assert _rel(pkg['printed'][:, :4], ref['printed'][:, :4]) <= 2e-3
+
+
+@pytest.mark.parametrize('scenario,steps', [('train6dof', '2'), ('det', '2'), ('notebook', '3')])
+def test_restated_slices_are_the_literal_slices(tmp_path, scenario, steps):
+    """oracle/callers_restated.py is what runs on the GPU box (tests/test_callers_gpu.py) in place of the literal sources, which only
+    exist here: on the same package backend and the same draws the two must agree to the last bit (make_golden.py asserts the same
+    on the reference itself), and the committed fixtures must be what the reference computes today."""
+    extra = () if scenario == 'notebook' else ('--steps', steps)        # (the notebook's default; same cache keys as the tests above)
+    lit = _run('package', scenario, str(tmp_path / 'p.npz'), *extra)
+    res = _run('package', scenario, str(tmp_path / 'q.npz'), *extra, '--restated')
+    assert set(lit) == set(res)
+    for k in lit:
+        assert np.array_equal(lit[k], res[k], equal_nan=True), (scenario, k, float(np.abs(lit[k] - res[k]).max()))
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import run_callers
+    fix = dict(np.load(os.path.join(ROOT, 'tests', 'golden', run_callers.FIXTURES[scenario])))
+    ref = _run('reference', scenario, str(tmp_path / 'r.npz'), *extra)
+    for k in ref:
+        assert np.array_equal(fix[k], ref[k].astype(fix[k].dtype), equal_nan=True), (scenario, k)
