@@ -21,7 +21,7 @@ SOURCES = ['eval_kernels.hip', 'lm_kernel.hip', 'amis_kernels.hip', 'amis_forwar
 _NO_SLP = ['-fno-slp-vectorize']
 FILE_FLAGS = {'lm_kernel.hip': _NO_SLP, 'rslm_kernel.hip': _NO_SLP, 'amis_forward_mfma.hip': _NO_SLP,
               'eval_kernels.hip': _NO_SLP}      # normal_equations 21.6 -> 16.6 us, evaluate_cost 17 -> 13.9 us at C2
-HEADERS = ['pnp_math.h', 'wave_ops.h', 'pnp_sweep.h', 'pnp_host.h', 'dispatch.h', 'amis_common.h', 'lm_core.h']
+HEADERS = ['pnp_math.h', 'wave_ops.h', 'pnp_sweep.h', 'pnp_host.h', 'dispatch.h', 'amis_common.h', 'lm_core.h', 'tuning.h']
 
 
 def _stale(target, deps):
@@ -68,7 +68,7 @@ def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=(),
         if force or _stale(obj, [sp] + deps_common):
             jobs.append(cc + ([] if emu else per_file.get(src, [])) + ['-c', sp, '-o', obj])
     if jobs:
-        with cf.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with cf.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
             for out in ex.map(_run, jobs):
                 if verbose and out.strip():
                     print(out)

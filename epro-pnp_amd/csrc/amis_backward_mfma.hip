@@ -21,12 +21,10 @@
 // EPROPNP_BWD_DROP=0 keeps every non-zero sample), then every wave sweeps all pose tiles for its own points.
 #include "amis_common.h"
 #include "dispatch.h"
+#include "tuning.h"
 
 namespace pnp {
 
-#ifndef PNP_BWD_MINW
-#define PNP_BWD_MINW 3
-#endif
 template <int DOF, bool BOUNDS, int NPT, bool BF16 = false>
 __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backward_mfma_kernel(Problem p, const float* __restrict__ pose_samples,
                                                                      const float* __restrict__ g_logw, int S,
@@ -69,9 +67,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   // the float just below z_min is 1 exactly when h_z >= z_min (compare + two selects issue at half rate, tools/ubench)
   const float front_scale = to_vgpr(0x1p60f);
   const float front_off = to_vgpr(-nextafterf(p.z_min, -1.0f) * 0x1p60f);
-#ifndef PNP_BWD_NO_FOLD
   const float tiny_v = to_vgpr(1e-30f);     // keeps rsq finite at a zero residual; folded into the norm's first fma
-#endif
 
   const bool with_init = (pose_init != nullptr) && (g_init != nullptr);
   const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
@@ -177,14 +173,8 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
         const float4 w4 = rW[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#ifdef PNP_BWD_SELECT_FRONT
-          const bool frontb = hz[r] >= zmin_v;
-          const float front = frontb ? 1.f : 0.f;
-          const float zc = frontb ? hz[r] : zmin_v;
-#else
           const float front = sat_fma(hz[r], front_scale, front_off);
           const float zc = clamp_below(hz[r], zmin_v);
-#endif
           const float rz = fast_rcp(zc);
           const float ppx = hx[r] * rz, ppy = hy[r] * rz;          // un-clamped projection
           float px = ppx, py = ppy;
@@ -193,19 +183,8 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
             py = clamp_lu(py, bd.lby, bd.uby);
           }
           const float rx = fmaf(px, w4.x, w4.z), ry = fmaf(py, w4.y, w4.w);
-#ifndef PNP_BWD_NO_FOLD
           const float s2 = fmaf(rx, rx, fmaf(ry, ry, tiny_v));   // |r|^2 + 1e-30: one v_max less per pair than clamping
           const float rs = fast_rsqrt(s2);
-#else
-          const float s2 = fmaf(rx, rx, ry * ry);
-          const float rs = fast_rsqrt(fmaxf(s2, 1e-30f));
-#endif
-#ifdef PNP_BWD_OLD_COEF
-          const float rho = s2 * rs;
-          const float mm = sat_mul(rho, one_v);                // min(rho, delta) / delta
-          const float coef = aw[r] * mm * rs;                  // a * min(1, delta / rho)
-          gd = fmaf(aw[r], rho - mm, gd);
-#else
           // Huber weight min(1, delta / rho) = min(1, rs) straight from the reciprocal norm (rho * rs = 1): ONE clamped
           // multiply where rho, min(rho, 1) and their product with rs took three.  d huber / d delta = max(rho - delta, 0)
           // (/ delta) = rho (1 - c1): exactly 0 for an inlier (c1 = 1), as in the reference.
@@ -213,7 +192,6 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
           const float coef = aw[r] * c1;
           const float rho = s2 * rs;
           gd = fmaf(aw[r], fmaf(-rho, c1, rho), gd);
-#endif
           const float crx = coef * rx, cry = coef * ry;
           // d/dw = crx * (px - u) = crx * rx / w and d/du = -crx * w: the per-point factors are applied once at the end
           A2x[i] = fmaf(crx, rx, A2x[i]);
@@ -226,11 +204,7 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
             gpy = (py == ppy) ? gpy : 0.f;
           }
           const float ghx = gpx * rz, ghy = gpy * rz;
-#ifdef PNP_BWD_SELECT_FRONT
-          const float ghz = frontb ? fmaf(-ghx, ppx, -(ghy * ppy)) : 0.f;
-#else
           const float ghz = fmaf(-ghx, ppx, -(ghy * ppy)) * front;
-#endif
           gXv[i] = fmaf(krx[r].x, ghx, fmaf(kry[r].x, ghy, fmaf(krz[r].x, ghz, gXv[i])));
           gYv[i] = fmaf(krx[r].y, ghx, fmaf(kry[r].y, ghy, fmaf(krz[r].y, ghz, gYv[i])));
           gZv[i] = fmaf(krx[r].z, ghx, fmaf(kry[r].z, ghy, fmaf(krz[r].z, ghz, gZv[i])));
@@ -319,7 +293,7 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
     waves = 4; npt = 1;
     while (npt < 4 && waves * npt * nsplit < ptiles) npt *= 2;
   }
-  { int ov[2]; if (env_ints("EPROPNP_BWD_MFMA", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8)) { waves = ov[0]; npt = ov[1]; } }
+  { int ov[2]; if (tune_ints("bwd_mfma", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8)) { waves = ov[0]; npt = ov[1]; } }
   // Projection on the bf16 matrix path (kernel comment) wherever the split operands fit the register budget of three waves per
   // SIMD (<= 4 resident point tiles: 4 VGPRs per tile instead of 1).  C2 backward 0.954 -> 0.899 ms, bounded 1.111 -> 1.037 ms,
   // Det shape neutral (profiles/r04_bwd_bf16_projection.txt).  EPROPNP_BWD_PROJ=f32 | bf16 forces either.

@@ -2,44 +2,16 @@
 // proposal fitting, proposal densities, sampling, weight algebra.  See amis_kernels.hip for the reference map.
 #pragma once
 #include "pnp_host.h"
+#include "tuning.h"
 
 namespace pnp {
 
-// precision of the single-lane proposal fits (tuning builds: -DPNP_FIT_T=float measures what fp64 costs there)
-#ifndef PNP_FIT_T
-#define PNP_FIT_T double
-#endif
-typedef PNP_FIT_T fit_t;
-
-
-#ifndef PNP_SWEEP_PIPELINE
-#define PNP_SWEEP_PIPELINE 0
-#endif
-
-// Issue priority of the calling wave while it runs a SERIAL phase of the sampler (the single-wave proposal refit: three waves
-// of the workgroup are parked at a barrier until it is through, while the other workgroups of the CU sweep).  VALU issue on a
-// SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md "two waves per SIMD"): at equal priority the refitting wave
-// gets the slots the sweeping waves leave, and its ~2000 dependent instructions take ~12 us; raised, they take what a lone
-// wave needs and the parked waves return to the sweep sooner.  PNP_FWD_PRIO: the raised level (0 = off; tuning variants).
-#ifndef PNP_FWD_PRIO
-#define PNP_FWD_PRIO 0
-#endif
-__device__ __forceinline__ void serial_phase_priority(bool raised) {
-#ifndef EPROPNP_EMU
-  if (PNP_FWD_PRIO > 0) {
-    if (raised) __builtin_amdgcn_s_setprio(PNP_FWD_PRIO); else __builtin_amdgcn_s_setprio(0);
-  }
-#else
-  (void)raised;
-#endif
-}
+typedef PNP_FIT_T fit_t;      // precision of the single-lane proposal fits (tuning.h)
 
 // min(x, 1) for x >= 0 through the clamp output modifier of a multiply by an opaque 1.0 (v_mul_f32 ... clamp, a full-rate
 // instruction; v_min_f32 issues at half that rate on gfx950, tools/ubench)
 __device__ __forceinline__ float sat_mul(float x, float one_v) {
-#if defined(PNP_FWD_NO_SAT)
-  return fminf(x, one_v);
-#elif !defined(EPROPNP_EMU)
+#ifndef EPROPNP_EMU
   return __builtin_amdgcn_fmed3f(x * one_v, 0.0f, 1.0f);
 #else
   const float y = x * one_v;
@@ -95,10 +67,7 @@ constexpr int kPropStride = 40;   // floats per fitted proposal (layout below)
 //   4-DoF: [16] yaw mode | [17] kappa | [18] log I0(kappa)
 //   [37] 1 if the translation covariance fell back to its default factor, [38] 1 if the ACG shape matrix did
 //   (cholesky_wrapper, epropnp.py:16-33) -- reported through the status word as EPROPNP_ST_CHOL_FALLBACK
-#ifndef PNP_VM_TRIES
-#define PNP_VM_TRIES 16      // tuning builds may lower it to time the rejection loop; the noise layout assumes 16
-#endif
-constexpr int kVmTries = PNP_VM_TRIES;
+constexpr int kVmTries = PNP_VM_TRIES;             // (tuning.h; the injected-noise layout assumes 16)
 constexpr int kRedStride = 68;                      // 64 lanes + 4 floats of padding per parked sample
 constexpr int kWaveRed = 16 * kRedStride + 64;     // per-wave LDS scratch of the transposed cost reduction
 
@@ -114,11 +83,7 @@ struct AmisParams {
   unsigned split_timeout;   // split over workgroups: shader cycles a part waits for a sibling's partial costs (wave_ops.h)
 };
 
-// The fp64 proposal fits run on one lane a handful of times per object; keeping them out of line stops their
-// ~100 live fp64 registers from inflating the allocation of the VALU-bound sweep loops (occupancy).
-#ifndef PNP_FIT_FN
-#define PNP_FIT_FN __device__ __forceinline__
-#endif
+// (PNP_FIT_FN, tuning.h: the fp64 proposal fits run on one lane a handful of times per object)
 
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
@@ -512,21 +477,6 @@ struct AmisCtx {
   int cstride;    // row stride of cpart (s, or s rounded up to 16 for the MFMA kernel)
 };
 
-#ifdef PNP_TUNING_REFIT
-// -DPNP_TUNING -DPNP_TUNING_REFIT builds (the per-phase atomics perturb the kernel): cycles spent by the fitting lane in [moment pass + reductions | ACG fixed-point iterations | final fits]
-__device__ unsigned long long g_refit_phase[4];
-#define PNP_REFIT_PHASE(i)                                                   \
-  do {                                                                       \
-    if (tid == 0) {                                                          \
-      const long long now_ = clock64();                                      \
-      atomicAdd(&g_refit_phase[i], (unsigned long long)(now_ - refit_t0_));  \
-      refit_t0_ = now_;                                                      \
-    }                                                                        \
-  } while (0)
-#else
-#define PNP_REFIT_PHASE(i)
-#endif
-
 // Base draws of sample m of object b: 3 normals + Chi2(3) for the Student-t translation, 4 normals for the ACG
 // rotation (6-DoF).  Philox4x32-10 counter (b, m, offset, q), Box-Muller.  They do not depend on the fitted proposal,
 // which is what lets the otherwise idle waves produce them while one lane runs the fp64 proposal fit.
@@ -612,9 +562,7 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
     ps[0] = rec[0] + rec[3] * y0;
     ps[1] = rec[1] + (rec[4] * y0 + rec[5] * y1);
     ps[2] = rec[2] + (rec[6] * y0 + rec[7] * y1 + rec[8] * y2);
-#ifdef PNP_TUNING_REFIT
-    const long long rot_t0_ = clock64();
-#endif
+    PNP_REFIT_CLOCK(rot_t0_);
     if (DOF == 6) {   // ACG: L_r g / |L_r g|   (distributions.py:42-52)
       const float v0 = rec[16] * g[0];
       const float v1 = rec[17] * g[0] + rec[18] * g[1];
@@ -651,9 +599,7 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
         ps[3] = vm_sample_bounded(rec[16], rec[17], uniforms);
       }
     }
-#ifdef PNP_TUNING_REFIT
-    if (tid == 0) atomicAdd(&g_refit_phase[3], (unsigned long long)(clock64() - rot_t0_));
-#endif
+    PNP_REFIT_ADD(3, rot_t0_);
 #pragma unroll
     for (int i = 0; i < PL; ++i) smp[i * S + m] = ps[i];
     if (pose_samples != nullptr) store_pose<PL>(pose_samples + ((size_t)m * p.B + b) * PL, ps);
@@ -691,19 +637,14 @@ PNP_FN void amis_weights(const AmisCtx& cx, const AmisParams& a, int it, int WP)
         for (int q = 1; q < WP; ++q) c += cpart[q * cx.cstride + (m - it * s)];
         cst[m] = c;
       }
-#ifdef PNP_TUNING
-      if (a.ablate & 4) mix = 0.f; else {
-#endif
-      mix = proposal_logprob<DOF>(prop, ps);
-      for (int j = 1; j <= it; ++j) mix = log_add_exp(mix, proposal_logprob<DOF>(prop + j * kPropStride, ps));
-#ifdef PNP_TUNING
+      if (PNP_ABLATED(a, 4)) {
+        mix = 0.f;
+      } else {
+        mix = proposal_logprob<DOF>(prop, ps);
+        for (int j = 1; j <= it; ++j) mix = log_add_exp(mix, proposal_logprob<DOF>(prop + j * kPropStride, ps));
       }
-#endif
     } else {             // old sample: add the new proposal's density
-#ifdef PNP_TUNING
-      if (a.ablate & 4) mix = 0.f; else
-#endif
-      mix = log_add_exp(mixl[m], proposal_logprob<DOF>(rec, ps));
+      mix = PNP_ABLATED(a, 4) ? 0.f : log_add_exp(mixl[m], proposal_logprob<DOF>(rec, ps));
     }
     mixl[m] = mix;
     lgw[m] = -cst[m] - (mix - log_n);
@@ -734,18 +675,12 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     return;
   }
   const int T = 64, tid = lane_id();
-  serial_phase_priority(true);        // the one wave the other three of the workgroup wait for
-#ifdef PNP_TUNING_REFIT
-  long long refit_t0_ = clock64();
-#endif
-#ifdef PNP_TUNING
-  if (a.ablate & 2) {
+  PNP_REFIT_BEGIN();
+  if (PNP_ABLATED(a, 2)) {
     for (int i = tid; i < kPropStride; i += T) nrec[i] = rec[i];
-    serial_phase_priority(false);
     __syncthreads();
     return;
   }
-#endif
   // One pass over the samples gathers every first/second moment that does not depend on a matrix inverse:
   // Z = sum e, sum e d, sum e d d^T with d = t - (previous mode) as pivot (keeps the E[dd^T] - dd^T cancellation
   // benign), and -- since the ACG fixed point starts from Sigma = I -- the first maximum-likelihood step as well.
@@ -757,10 +692,8 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     float mom[21];
 #pragma unroll
     for (int i = 0; i < 21; ++i) mom[i] = 0.f;
-#ifdef PNP_TUNING
-    if (a.ablate & 8) mom[0] = mom[4] = mom[6] = mom[9] = mom[10] = mom[12] = mom[15] = mom[19] = mom[20] = 1.f;
+    if (PNP_ABLATED(a, 8)) mom[0] = mom[4] = mom[6] = mom[9] = mom[10] = mom[12] = mom[15] = mom[19] = mom[20] = 1.f;
     else
-#endif
     for (int m = tid; m < M; m += T) {
       const float e = fast_exp(lgw[m] - mx);
       const float d0 = smp[m] - p0, d1 = smp[S + m] - p1, d2 = smp[2 * S + m] - p2;
@@ -776,10 +709,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       mom[16] += iw * q3 * q0; mom[17] += iw * q3 * q1; mom[18] += iw * q3 * q2; mom[19] += iw * q3 * q3;
       mom[20] += iw;
     }
-#ifdef PNP_TUNING
-    if (!(a.ablate & 16))
-#endif
-    refit_sum<21>(mom, cx.rred);
+    if (!PNP_ABLATED(a, 16)) refit_sum<21>(mom, cx.rred);
     const float invZ = 1.0f / mom[0];
     const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
     const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;
@@ -909,7 +839,6 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       for (int i = 19; i < 37; ++i) nrec[i] = 0.f;
     }
   }
-  serial_phase_priority(false);
   __syncthreads();
 }
 

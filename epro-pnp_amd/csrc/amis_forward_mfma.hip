@@ -24,21 +24,8 @@
 
 namespace pnp {
 
-#ifdef PNP_TUNING
-// tuning builds: shader-clock cycles per phase (initial fit+load | draw | sweep | weights | refit | store), summed over
-// workgroups by thread 0 of each; read back through epropnp_tuning_phase_cycles (c_api.hip).
-__device__ unsigned long long g_fwd_phase[8];
-#define PNP_PHASE(i)                                                        \
-  do {       /* accumulated in registers, flushed once at the end: per-phase atomics on one address serialise */ \
-    if (tid == 0) {                                                         \
-      const long long now_ = clock64();                                     \
-      phase_acc_[i] += (unsigned long long)(now_ - phase_t0_);              \
-      phase_t0_ = now_;                                                     \
-    }                                                                       \
-  } while (0)
-#else
-#define PNP_PHASE(i)
-#endif
+// (tuning builds count shader-clock cycles per phase -- initial fit + load | draw | sweep | weights | refit | store --: PNP_PHASE,
+// tuning.h; read back through epropnp_tuning_phase_cycles)
 
 // Two point-poses at a time, written on 2-vectors (wave_ops.h: f32x2, fma2) so that the multiplies / FMAs become
 // v_pk_mul_f32 / v_pk_fma_f32.  Packed ops run at the scalar flop rate on gfx950, but the transcendental ops between them
@@ -96,9 +83,6 @@ struct MfmaShape {
 // NPT > 0: the workgroup's waves split the POINTS, each wave keeps its NPT point tiles (B operand + residual
 // constants, 5 VGPRs per tile) in registers for the whole kernel and sweeps every pose tile; per-wave partial costs
 // meet in LDS.  NPT == 0: waves split the pose tiles and points stream through LDS in chunks (any N).
-#ifndef PNP_FWD_MINW
-#define PNP_FWD_MINW 4
-#endif
 // SPILL (NPT == 0 only): the per-sample sampler state -- samples, costs, mixture densities, log-weights, (pose_len + 3) S
 // floats per object -- lives in a global scratch buffer instead of LDS, for mc_samples beyond what 160 KiB hold
 // (the reference has no such limit).  Same code: the arrays are reached through pointers either way, every hand-over
@@ -149,10 +133,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), W = T >> 6;
   const int S = a.S, K = a.K, s = S / K, s16 = sh.s16, NC = sh.chunk;
 
-#ifdef PNP_TUNING
-  long long phase_t0_ = clock64();
-  unsigned long long phase_acc_[6] = {0, 0, 0, 0, 0, 0};
-#endif
+  PNP_PHASES_BEGIN(6);
   PNP_DYN_SMEM(float, smem);
   constexpr bool kRegs = NPT > 0;
   static_assert(!BF16 || NPT > 0, "the split projection is a register-mode variant");
@@ -196,9 +177,6 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
     for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last pose tile
   if (tid < (DOF == 6 ? 2 : 1))      // 6-DoF: lane 1 fits the translation factor inside lane 0's rotation fit
     initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop, tid);
-#ifdef PNP_TUNING_DOUBLE_INIT    // what one initial fit costs: a second one, on the neighbour's data, into a slot the first refit overwrites
-  if (tid < (DOF == 6 ? 2 : 1) && K > 1) initial_fit<DOF>(pose_opt + (size_t)((b + 1) % p.B) * PL, pose_cov + (size_t)((b + 1) % p.B) * DOF * DOF, a.eps, a.dispersion, prop + kPropStride, tid);
-#endif
   const int nchunk = kRegs ? 1 : (p.N + NC - 1) / NC;
   auto load_chunk = [&](int c0) {
     const int cnt = min(NC, ((p.N - c0 + 15) >> 4) << 4);
@@ -257,7 +235,6 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
         huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, one_v, bd, acc2);
       }
       // the four poses' sums over this row's 16 points: lane col < 4 ends up with pose g4 + col (wave_ops.h: row_sum16_of4)
-#ifndef PNP_FWD_ROWSUM_OLD
       const float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
       const float tot = row_sum16_of4(acc);
       if (col < 4) {
@@ -265,15 +242,6 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
         if constexpr (CHUNKED) *dst = accumulate ? fmaf(tot, delta_sq, *dst) : tot * delta_sq;
         else *dst = tot * delta_sq;
       }
-#else       // tuning variant: four full row sums (16 DPP adds), lane 0 of the row stores
-      float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = row_sum16(acc[r]);
-      if (col == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cpart[wv * s16 + t * 16 + g4 + r] = acc[r] * delta_sq;
-      }
-#endif
     }
   };
   PNP_PHASE(0);
@@ -284,23 +252,15 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
       if (n0 > 0) __syncthreads();              // the previous tile's costs have left cpart, its poses are done with
       for (int i = tid; i < 12 * (cnt16 - cnt); i += T) ptab[12 * cnt + i] = 0.f;
     }
-#ifdef PNP_TUNING
-    if (!(a.ablate & 32) || it == 0)      // bit5: the sweep re-uses the first iteration's pose table (what the sweep alone costs)
-#endif
-    amis_draw<DOF>(cx, p, a, it, Kc, noise, part == 0 ? pose_samples : nullptr, n0, tiled ? cnt : -1);
-#ifdef PNP_FWD_PRIO_ALL
-    serial_phase_priority(false);
-#endif
+    if (!PNP_ABLATED(a, 32) || it == 0)   // (tuning, bit5: the sweep re-uses the first iteration's pose table)
+      amis_draw<DOF>(cx, p, a, it, Kc, noise, part == 0 ? pose_samples : nullptr, n0, tiled ? cnt : -1);
     __syncthreads();
     PNP_PHASE(1);
 
     // ---------------- cost sweep: 16 x 16 (pose, point) tiles on the matrix pipe ----------------
-#ifdef PNP_TUNING
-    if (a.ablate & 1) {
+    if (PNP_ABLATED(a, 1)) {
       for (int n = tid; n < s; n += T) cpart[n] = 1.0f;
-    } else
-#endif
-    if (kRegs) {
+    } else if (kRegs) {
       if constexpr (!CHUNKED) {
         sweep_regs();
       } else {        // the point tiles in CH groups through the registers: load, split, sweep every pose tile, next group
@@ -396,9 +356,6 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
       }
     }
     PNP_PHASE(2);
-#ifdef PNP_FWD_PRIO_ALL      // tuning variant: every phase between two sweeps (weights, refit, draw) runs prioritised
-    serial_phase_priority(true);
-#endif
 
     if (tiled) __syncthreads();
     amis_weights<DOF>(cx, a, it, tiled ? 0 : WPs);
@@ -423,34 +380,11 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   if (proposals != nullptr && part == 0)
     for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
   PNP_PHASE(5);
-#ifdef PNP_TUNING
-  if (tid == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) atomicAdd(&g_fwd_phase[i], phase_acc_[i]);
-  }
-#endif
+  PNP_PHASES_FLUSH(6);
 }
 
-#ifdef PNP_TUNING
-int tuning_phase_cycles(unsigned long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-#ifdef PNP_TUNING_REFIT
-  if (out) {    // slots 6, 7 are unused by the kernel phases: cycles of the refit's ACG fixed-point iterations | final fp64 fits
-    unsigned long long rf[4];
-    if (hipMemcpyFromSymbol(rf, HIP_SYMBOL(g_refit_phase), sizeof(rf)) != hipSuccess) return -1;
-    out[6] = rf[1];      // ACG fixed-point iterations (fp64 inverse on one lane + sample passes)
-    out[7] = rf[2];      // final fits (translation, rotation) on one lane; the moment pass is phase 4 minus these two
-    const unsigned long long z4[4] = {0, 0, 0, 0};
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_refit_phase), z4, sizeof(z4)) != hipSuccess) return -1;
-  }
-#endif
-  if (reset) {
-    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_phase), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#endif
+// per-phase cycle totals of this file's kernel (tuning builds; -1 otherwise)
+int tuning_phase_cycles(unsigned long long* out, int reset) { return tuning::read_cycles(out, reset, true); }
 
 template <class F>
 static int dispatch_npt(int npt, F&& f) {
@@ -511,7 +445,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   if (prob->dof == 4 && npt == 16) npt = 0;
   // few objects (less than two waves per SIMD otherwise): spread an object over 8 waves (B = 32: 86 vs 93 us)
   if (d.B < 512 && waves == 4 && npt == 8) { waves = 8; npt = 4; }
-  { int ov[2]; if (env_ints("EPROPNP_FWD_MFMA", ov, 2) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && (ov[1] == 0 || ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8 || ov[1] == 12 || ov[1] == 16) && (ov[1] == 0 || ov[0] * ov[1] >= ptiles)) { waves = ov[0]; npt = ov[1]; } }
+  { int ov[2]; if (tune_ints("fwd_mfma", ov, 2) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && (ov[1] == 0 || ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8 || ov[1] == 12 || ov[1] == 16) && (ov[1] == 0 || ov[0] * ov[1] >= ptiles)) { waves = ov[0]; npt = ov[1]; } }
   if (npt == 0) {       // points stream through LDS in chunks; waves split the pose tiles
     sh.chunk = ((d.N + 15) / 16) * 16;
     if (sh.chunk > kChunk) sh.chunk = kChunk;
@@ -542,7 +476,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   // chunk and iteration (from L2 / HBM: 28 B per point against ~100 ns of arithmetic per 16 of them and pose tile).
   sh.chunks = 1;
   { const char* e = getenv("EPROPNP_FWD_PROJ"); if (e && e[0] == 'f') sh.chunks = 0; }      // (the chunked instantiation is the split projection)
-  if (sh.chunks == 1 && G == 1 && npt > 8 && ptiles > 48 && !getenv("EPROPNP_FWD_NO_CHUNKS") && !getenv("EPROPNP_FWD_MFMA")) {
+  if (sh.chunks == 1 && G == 1 && npt > 8 && ptiles > 48 && !tune_flag("fwd_no_chunks") && !tune_flag("fwd_mfma")) {
     waves = 4; npt = 8;
     sh.chunks = (ptiles + 31) / 32;
   }
@@ -551,7 +485,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
   k.split_timeout = split_timeout_cycles();
-  { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
+  { int ab[1]; if (tune_ints("ablate", ab, 1)) k.ablate = ab[0]; }
   sh.ahead = 1;
   auto lds_bytes = [&](bool spilled) {
     return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (size_t)(PL + 3) * S) +
@@ -656,7 +590,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
           return 0;
         };
         if constexpr (decltype(NPT)::value == 8) {
-          if (sh.chunks > 1 || (bf16 && getenv("EPROPNP_FWD_CHUNKED") != nullptr))      // (the knob: the chunked instantiation with one chunk)
+          if (sh.chunks > 1 || (bf16 && tune_flag("fwd_chunked")))      // (the knob: the chunked instantiation with one chunk)
             return run(amis_forward_mfma_kernel<decltype(DOF)::value, decltype(BND)::value, 8, false, false, true, true>);
         }
         if constexpr (decltype(NPT)::value >= 1) {

@@ -79,42 +79,13 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) vo
 
     // ---------------- 2. cost sweep: s poses x this wave's points (lane = point) ----------------
     const int ntile = (s + 63) >> 6;
-#ifdef PNP_TUNING
-    if (a.ablate & 1) {
+    if (PNP_ABLATED(a, 1)) {
       for (int n = tid; n < s; n += T) cpart[n] = 1.0f;
     } else
-#endif
     for (int t = ws; t < ntile; t += WS) {
       const int base = t * 64;
       const int cnt = min(64, s - base);
       float mine = 0.f;
-#if PNP_SWEEP_PIPELINE
-      // two samples per trip (their DPP reduction chains interleave); the next trip's first pose row is fetched
-      // from LDS before the current pair is evaluated, so the ds_read latency hides behind ~400 VALU instructions
-      const float4* row = reinterpret_cast<const float4*>(ptab + 12 * base);   // uniform address: LDS broadcast
-      float4 n0 = row[0], n1 = row[1], n2 = row[2];
-      for (int j = 0; j < cnt; j += 2) {
-        const float4 a0 = n0, a1 = n1, a2 = n2;
-        const float4* rb = reinterpret_cast<const float4*>(ptab + 12 * (base + min(j + 1, cnt - 1)));
-        const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2];
-        const float4* rn = reinterpret_cast<const float4*>(ptab + 12 * (base + min(j + 2, cnt - 1)));
-        n0 = rn[0]; n1 = rn[1]; n2 = rn[2];
-        const float krA[9] = {a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, a2.x, a2.y, a2.z};
-        const float ktA[3] = {a0.w, a1.w, a2.w};
-        const float krB[9] = {b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, b2.x, b2.y, b2.z};
-        const float ktB[3] = {b0.w, b1.w, b2.w};
-        float cA = 0.f, cB = 0.f;
-#pragma unroll
-        for (int k = 0; k < PPL; ++k) {
-          cA += sweep_cost<BOUNDS>(pts[k], krA, ktA, zmin_v, delta_v, bd);
-          cB += sweep_cost<BOUNDS>(pts[k], krB, ktB, zmin_v, delta_v, bd);
-        }
-        cA = wave_sum(cA);
-        cB = wave_sum(cB);
-        mine = (lane == j) ? cA : mine;
-        mine = (lane == j + 1) ? cB : mine;     // j + 1 == cnt (odd tail) only ever matches a lane >= cnt: unused
-      }
-#else
       // Per-lane partial costs of 16 samples are parked in LDS (one ds_write each, no dependent chain in the hot
       // loop) and summed "transposed": lane l adds the 16 partials of sample (l & 15) held by lanes 16q..16q+15
       // (q = l >> 4), then the four quarter sums are combined through a second 64-float exchange.
@@ -144,7 +115,6 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) vo
         mine = ((lane >> 4) == (j0 >> 4)) ? total : mine;   // lanes j0..j0+15 own samples j0..j0+15 of the tile
         wave_lds_fence();                                   // rt / rq are rewritten by the next group
       }
-#endif
       if (base + lane < s) cpart[wp * s + base + lane] = mine;
     }
     __syncthreads();
@@ -337,8 +307,8 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
                 am->mc_samples, am->num_iter);
   if (prob->num_obj == 0) return EPROPNP_OK;
   if (!pose_opt || !pose_cov || !pose_samples || !logweights) return fail(EPROPNP_EINVAL, "amis_forward: NULL pointer");
-  {   // default: projection on the matrix cores (amis_forward_mfma.hip); EPROPNP_FWD_IMPL=valu keeps the VALU sweep
-    const char* impl = getenv("EPROPNP_FWD_IMPL");
+  {   // default: projection on the matrix cores (amis_forward_mfma.hip); EPROPNP_TUNE="fwd_impl=valu" keeps the VALU sweep
+    const char* impl = tune_value("fwd_impl");
     if (!(impl && impl[0] == 'v'))
       return launch_amis_forward_mfma(prob, am, pose_opt, pose_cov, noise, pose_samples, logweights, proposals, st);
   }
@@ -362,7 +332,7 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
     ppl /= 2;
   }
   int ov[3];   // WS, WP, PPL
-  if (env_ints("EPROPNP_FWD_SHAPE", ov, 3) && valid_shape_override(ov[1], ov[2], d.N) && ov[0] >= 1 && ov[0] * ov[1] <= 16 &&
+  if (tune_ints("fwd_shape", ov, 3) && valid_shape_override(ov[1], ov[2], d.N) && ov[0] >= 1 && ov[0] * ov[1] <= 16 &&
       (ov[0] & (ov[0] - 1)) == 0) {
     WS = ov[0]; WP = ov[1]; ppl = ov[2];
   }
@@ -371,7 +341,7 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   k.S = S; k.K = K; k.WP = WP; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev;
   k.ablate = 0;
-  { int ab[1]; if (env_ints("EPROPNP_ABLATE", ab, 1)) k.ablate = ab[0]; }
+  { int ab[1]; if (tune_ints("ablate", ab, 1)) k.ablate = ab[0]; }
   // the float4-viewed arrays (ptab rows, wred) come first so that they are 16-B aligned for any S
   const size_t smem = sizeof(float) * (12 * (size_t)s + (size_t)PL * S + 3 * (size_t)S + (size_t)WP * s +
                                        (size_t)K * kPropStride + 256 + (size_t)WS * WP * kWaveRed);
@@ -436,8 +406,8 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
   if ((mc_samples > 0 && (!pose_samples || !grad_logweights)) || !grad_x3d || !grad_x2d || !grad_w2d || !grad_delta)
     return fail(EPROPNP_EINVAL, "amis_backward: NULL pointer");
   {   // projection on the matrix cores (amis_backward_mfma.hip) unless its LDS pose table does not fit;
-      // EPROPNP_BWD_IMPL=valu forces this file's all-VALU kernel
-    const char* impl = getenv("EPROPNP_BWD_IMPL");
+      // EPROPNP_TUNE="bwd_impl=valu" forces this file's all-VALU kernel
+    const char* impl = tune_value("bwd_impl");
     if (!(impl && impl[0] == 'v')) {
       const int rc = launch_amis_backward_mfma(prob, pose_samples, grad_logweights, mc_samples, pose_init, grad_cost_init,
                                                grad_x3d, grad_x2d, grad_w2d, grad_delta, 1, st);
@@ -451,7 +421,7 @@ int launch_amis_backward(const epropnp_problem* prob, const float* pose_samples,
   // measured on MI355X (profiles/): fewest waves per object wins (per-pose overhead amortised over 8 points/lane)
   Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/4096);
   int ov[2];
-  if (env_ints("EPROPNP_BWD_SHAPE", ov, 2) && valid_shape_override(ov[0], ov[1], d.N)) { s.waves = ov[0]; s.ppl = ov[1]; }
+  if (tune_ints("bwd_shape", ov, 2) && valid_shape_override(ov[0], ov[1], d.N)) { s.waves = ov[0]; s.ppl = ov[1]; }
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((amis_backward_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),

@@ -7,10 +7,8 @@
 #include "pnp_host.h"
 
 namespace pnp {
-#ifdef PNP_TUNING
-int tuning_phase_cycles(unsigned long long* out, int reset);
+int tuning_phase_cycles(unsigned long long* out, int reset);          // amis_forward_mfma.hip / rslm_kernel.hip (tuning.h)
 int tuning_rslm_phase_cycles(unsigned long long* out, int reset);
-#endif
 char* last_error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
@@ -342,10 +340,9 @@ int epropnp_profile_read(const char* stage, float* mean_ms, int32_t* count) {
   return EPROPNP_OK;
 }
 
-#ifdef PNP_TUNING
-// tuning builds only (not part of the ABI): per-phase shader-clock totals of amis_forward_mfma_kernel
+// Not part of the ABI (tools/tune.py): per-phase shader-clock totals of amis_forward_mfma_kernel / rslm_solve_kernel in a tuning
+// build (build.py -D PNP_TUNING); -1 in the product build, whose kernels carry no counters.
 int epropnp_tuning_phase_cycles(unsigned long long* out, int reset) { return pnp::tuning_phase_cycles(out, reset); }
 int epropnp_tuning_rslm_cycles(unsigned long long* out, int reset) { return pnp::tuning_rslm_phase_cycles(out, reset); }
-#endif
 
 }  // extern "C"

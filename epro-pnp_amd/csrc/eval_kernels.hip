@@ -946,7 +946,7 @@ int launch_normal_equations(const epropnp_problem* prob, const float* pose, int 
   //  22.9 us against 21.3 us -- 190 VGPRs halve the occupancy and cost more than the overlap gains.)
   Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/0);
   int ov[2];
-  if (env_ints("EPROPNP_NE_SHAPE", ov, 2) && valid_shape_override(ov[0], ov[1], d.N)) { s.waves = ov[0]; s.ppl = ov[1]; }
+  if (tune_ints("ne_shape", ov, 2) && valid_shape_override(ov[0], ov[1], d.N)) { s.waves = ov[0]; s.ppl = ov[1]; }
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((normal_equations_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),
                grid, dim3(64 * s.waves),

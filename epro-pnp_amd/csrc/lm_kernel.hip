@@ -233,7 +233,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
   k.min_diag = lm->min_lm_diagonal; k.max_diag = lm->max_lm_diagonal;
   k.min_rel_decrease = lm->min_relative_decrease; k.radius0 = lm->initial_trust_region_radius;
   k.radius_max = lm->max_trust_region_radius; k.eps = lm->eps; k.split_timeout = split_timeout_cycles();
-  if (d.N <= 16 && !getenv("EPROPNP_LM_NO_ROWS")) {   // RSLM sub-problems: 16 objects per 256-thread block
+  if (d.N <= 16 && !tune_flag("lm_no_rows")) {   // RSLM sub-problems: 16 objects per 256-thread block
     const dim3 grid((d.B + 15) / 16), block(256);
     dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
       PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, 1, decltype(BND)::value, 0>), grid, block, 0, st, d, k, pose_init,
@@ -286,7 +286,7 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
   // the 1+L dependent sweeps (measured on MI355X at B = 32 / 256 / 600: 1 wave 38 / 30 / 30 us vs 86 / 62 / 41 us)
   Shape s = choose_shape(d.B, d.N, /*max_ppl=*/8, /*want_waves_total=*/0);
   int ov[2];
-  if (env_ints("EPROPNP_LM_SHAPE", ov, 2) && valid_shape_override(ov[0], ov[1], d.N)) { s.waves = ov[0]; s.ppl = ov[1]; }
+  if (tune_ints("lm_shape", ov, 2) && valid_shape_override(ov[0], ov[1], d.N)) { s.waves = ov[0]; s.ppl = ov[1]; }
   const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
   dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
     PNP_LAUNCH((lm_solve_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/epropnp_hip.h"
 #include "pnp_sweep.h"
@@ -73,7 +74,6 @@ inline Shape choose_shape(int B, int N, int max_ppl = 8, int want_waves_total = 
   return s;
 }
 
-// Tuning knob: EPROPNP_<NAME>="a,b,c" overrides a launcher's automatic workgroup shape.
 // a (waves, points-per-lane) override from a tuning variable is taken only if it is one the kernels are instantiated for
 // and covers the object: anything else is ignored (a typo must not change results)
 inline bool valid_shape_override(int waves, int ppl, int N) {
@@ -82,8 +82,7 @@ inline bool valid_shape_override(int waves, int ppl, int N) {
   return w_ok && p_ok && 64L * waves * ppl >= N;
 }
 
-inline bool env_ints(const char* name, int* out, int n) {
-  const char* v = getenv(name);
+inline bool parse_ints(const char* v, int* out, int n) {
   if (!v || !*v) return false;
   for (int i = 0; i < n; ++i) {
     char* end = nullptr;
@@ -93,6 +92,37 @@ inline bool env_ints(const char* name, int* out, int n) {
   }
   return true;
 }
+
+// A user-facing knob EPROPNP_<NAME>="a[,b]" (INTEGRATION.md lists them all: *_PROJ, BWD_DROP, *_SPLIT, ASYNC_STATUS, NO_TORCH_EXT,
+// DELTA_FOLD, LOSS_FUSED, SPLIT_TIMEOUT_CYCLES).
+inline bool env_ints(const char* name, int* out, int n) { return parse_ints(getenv(name), out, n); }
+
+// Everything else that used to be an environment variable of its own -- launch-shape overrides, implementation selectors,
+// phase ablation: what tools/tune.py and the shape tests need, not what a user does -- is ONE string:
+//     EPROPNP_TUNE="lm_shape=1,8;bwd_impl=valu;rslm_composite"
+// `tune_value(key)` returns the text behind "key=" ("" for a bare key), or nullptr when the key is absent.
+inline const char* tune_value(const char* key) {
+  static thread_local char buf[64];
+  const char* s = getenv("EPROPNP_TUNE");
+  if (!s) return nullptr;
+  const size_t kl = strlen(key);
+  while (*s) {
+    const char* end = strchr(s, ';');
+    const size_t len = end ? (size_t)(end - s) : strlen(s);
+    if (len >= kl && strncmp(s, key, kl) == 0 && (len == kl || s[kl] == '=')) {
+      const size_t vl = (len == kl) ? 0 : len - kl - 1;
+      if (vl >= sizeof(buf)) return nullptr;
+      memcpy(buf, s + kl + (len == kl ? 0 : 1), vl);
+      buf[vl] = 0;
+      return buf;
+    }
+    if (!end) break;
+    s = end + 1;
+  }
+  return nullptr;
+}
+inline bool tune_ints(const char* key, int* out, int n) { return parse_ints(tune_value(key), out, n); }
+inline bool tune_flag(const char* key) { return tune_value(key) != nullptr; }
 
 // Compute units of the current device (hipDeviceAttributeMultiprocessorCount, cached): what the workgroup-split variants
 // size their grids against -- a partitioned (CPX) MI355X or another part reports its own count; the CPU emulation of the

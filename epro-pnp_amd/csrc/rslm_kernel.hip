@@ -14,6 +14,7 @@
 #include "dispatch.h"
 #include "lm_core.h"
 #include "pnp_host.h"
+#include "tuning.h"
 
 namespace pnp {
 
@@ -22,39 +23,11 @@ constexpr int kRslmRows = 16;       // DPP rows per workgroup
 
 PNP_FN float row_min16(float x) { return -row_max16(-x); }
 
-#ifdef PNP_TUNING
-// tuning builds: cycles of thread 0 in [staging + centre init | key draw | 16 picks | sub-sample solve | scoring | argmin]
-__device__ unsigned long long g_rslm_phase[8];
-#define PNP_RSLM_PHASE(i)                                                  \
-  do {                                                                     \
-    if (tid == 0) {                                                        \
-      const long long now_ = clock64();                                    \
-      atomicAdd(&g_rslm_phase[i], (unsigned long long)(now_ - rslm_t0_));  \
-      rslm_t0_ = now_;                                                     \
-    }                                                                      \
-  } while (0)
-int tuning_rslm_phase_cycles(unsigned long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rslm_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-  if (reset) {
-    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rslm_phase), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#else
-#define PNP_RSLM_PHASE(i)
-#endif
+// (tuning builds: cycles of thread 0 in [staging + centre init | key draw | 16 picks | sub-sample solve | scoring | argmin] -- PNP_PHASE, tuning.h)
+int tuning_rslm_phase_cycles(unsigned long long* out, int reset) { return tuning::read_cycles(out, reset, false); }
 
-// PNP_RSLM_MINW4: waves per SIMD the 4-DoF instantiation is compiled for (0: whatever its registers allow -- 115 VGPRs, 4 waves)
-#ifndef PNP_RSLM_MINW4
-#define PNP_RSLM_MINW4 0
-#endif
 template <int DOF, bool BOUNDS>
-#if PNP_RSLM_MINW4
-__global__ __launch_bounds__(256, (DOF == 4 ? PNP_RSLM_MINW4 : 3)) void rslm_solve_kernel(
-#else
 __global__ __launch_bounds__(256) void rslm_solve_kernel(
-#endif
 Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
                                                           unsigned long long offset_in,
                                                           const unsigned long long* __restrict__ offset_dev,
@@ -73,9 +46,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
   const int P_lo = (int)(((long long)P * part) / parts), P_hi = (int)(((long long)P * (part + 1)) / parts);
   const int tid = (int)threadIdx.x, l16 = tid & 15, row = tid >> 4, N = p.N;
   const unsigned long long offset = offset_in + (offset_dev ? *offset_dev : 0ull);
-#ifdef PNP_TUNING
-  long long rslm_t0_ = clock64();
-#endif
+  PNP_PHASES_BEGIN(6);
   const int Np = (N + 3) & ~3;
   PNP_DYN_SMEM(float, smem);
   float* sX = smem;                 // [N][3]
@@ -141,7 +112,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
     t0[0] = mean[0] * depth; t0[1] = mean[1] * depth; t0[2] = depth;
   }
 
-  PNP_RSLM_PHASE(0);
+  PNP_PHASE(0);
   float Kv[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) Kv[i] = to_vgpr(K[i]);
@@ -175,7 +146,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
         }
       }
       wave_lds_fence();
-      PNP_RSLM_PHASE(1);
+      PNP_PHASE(1);
       if (N <= 128) {
         unsigned k8[8];
 #pragma unroll
@@ -211,7 +182,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
         }
       }
     }
-    PNP_RSLM_PHASE(2);
+    PNP_PHASE(2);
     Point pt;
     if (my_idx >= 0 && my_idx < N) {
       pt.X = sX[3 * my_idx]; pt.Y = sX[3 * my_idx + 1]; pt.Z = sX[3 * my_idx + 2];
@@ -259,7 +230,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
     int bits = 0;
     int st_bits = 0;      // sub-sample solves may be degenerate by design (16 random points): not reported
     lm_iterate<DOF>(lm, sweep, pose, cur, bits, st_bits);
-    PNP_RSLM_PHASE(3);
+    PNP_PHASE(3);
 
     // ---- score the proposal on the full correspondence set (:343); hardware rcp / sqrt as in the AMIS sweeps: the
     // score only ranks proposals (and is compared with another pose's cost by LMSolver.solve), 1-ulp effects are moot
@@ -277,7 +248,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
       }
       c = row_sum16(c);
     }
-    PNP_RSLM_PHASE(4);
+    PNP_PHASE(4);
     if (active && (j0 == P_lo || c < best_cost)) {
       best_cost = c;
 #pragma unroll
@@ -312,6 +283,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
       if (cost_out) cost_out[b] = wc;
     }
   }
+  PNP_PHASES_FLUSH(6);
 }
 
 // winner over the parts of an object (ties: the lowest part = the lowest proposal index, as the single-workgroup kernel)
@@ -347,7 +319,7 @@ static int rslm_parts(int B, int P) {
   int best = (B <= cus) ? 4 : (B <= 3 * cus ? 2 : 1);
   if (cus < 16) best = 1;                    // nothing to balance over (the tests' one-CU CPU emulation)
   while (best > 1 && P % (kRslmRows * best) != 0) best >>= 1;
-  { int ov[1]; if (env_ints("EPROPNP_RSLM_PARTS", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4) && P % (kRslmRows * ov[0]) == 0) best = ov[0]; }
+  { int ov[1]; if (tune_ints("rslm_parts", ov, 1) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4) && P % (kRslmRows * ov[0]) == 0) best = ov[0]; }
   return best;
 }
 

@@ -19,6 +19,17 @@ _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
 
 
+def tune(key):
+    """EPROPNP_TUNE="key=value;key2;...": the ONE string behind which launch-shape overrides, implementation selectors and
+    phase ablation live (csrc/pnp_host.h: tune_value; tools/tune.py and the shape tests set it, users do not).  Returns the text
+    behind `key=` ('' for a bare key) or None.  Read on every call: tests change the variable at run time."""
+    for item in os.environ.get('EPROPNP_TUNE', '').split(';'):
+        k, _, v = item.partition('=')
+        if k == key:
+            return v
+    return None
+
+
 class Problem(C.Structure):
     _fields_ = [('x3d', C.c_void_p), ('x2d', C.c_void_p), ('w2d', C.c_void_p), ('cam_mats', C.c_void_p),
                 ('lb', C.c_void_p), ('ub', C.c_void_p), ('delta', C.c_void_p), ('z_min', C.c_float),

@@ -216,7 +216,7 @@ class EProPnPBase(torch.nn.Module):
         from . import _hip
         from .levenberg_marquardt import LMSolver, RSLMSolver
         sv = self.solver
-        if type(sv) is not LMSolver or sv.dof != self.dof or x3d.size(0) == 0 or os.environ.get('EPROPNP_NO_FUSED_FORWARD'):
+        if type(sv) is not LMSolver or sv.dof != self.dof or x3d.size(0) == 0 or hip.tune('no_fused_forward') is not None:
             return False
         if set(kwargs) - {'with_pose_opt_plus', 'with_cost', 'fast_mode'}:
             return False
@@ -226,7 +226,7 @@ class EProPnPBase(torch.nn.Module):
         if pose_init is None or force_init_solve:
             init = sv.init_solver
             if type(init) is not RSLMSolver or init.dof != self.dof or init.num_points > 16 \
-                    or not (2 <= x2d.size(1) <= hip.RSLM_MAX_POINTS) or os.environ.get('EPROPNP_RSLM_COMPOSITE'):
+                    or not (2 <= x2d.size(1) <= hip.RSLM_MAX_POINTS) or hip.tune('rslm_composite') is not None:
                 return False
         return True
 

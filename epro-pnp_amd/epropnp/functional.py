@@ -10,6 +10,8 @@ import torch
 
 from . import _hip
 
+tune = _hip.tune        # EPROPNP_TUNE keys (tools / tests only)
+
 
 def _f32c(t, name):
     if t.dtype != torch.float32:
@@ -390,7 +392,7 @@ def backward_split(B, N, S):
     env = os.environ.get('EPROPNP_BWD_SPLIT')
     if env is not None:
         return max(1, int(env))
-    if S > BWD_SPLIT_MAX_SAMPLES or B >= 256 or os.environ.get('EPROPNP_BWD_IMPL', '')[:1] == 'v':
+    if S > BWD_SPLIT_MAX_SAMPLES or B >= 256 or (_hip.tune('bwd_impl') or '')[:1] == 'v':
         return 1
     n = 1
     while n < 8 and 2 * n * B <= 512 and 2 * n * 64 <= N:

@@ -196,7 +196,7 @@ class RSLMSolver(LMSolver):
             P, n = self.num_proposals, self.num_points
             from . import _hip
             if n <= 16 and 2 <= pn <= hip.RSLM_MAX_POINTS and _hip.on_hip_path(x3d, x2d, w2d) \
-                    and not os.environ.get('EPROPNP_RSLM_COMPOSITE'):
+                    and hip.tune('rslm_composite') is None:
                 # one kernel: init translation, sub-sampling, P x B solves, scoring, argmin (csrc/rslm_kernel.hip)
                 prob = hip.problem(x3d, x2d, w2d, camera, cost_fun, self.dof)
                 if getattr(self.draw, '__func__', None) is RSLMSolver.draw:   # default sampler: device Philox

@@ -26,7 +26,11 @@ def _emu_lib():
         spec = importlib.util.spec_from_file_location('epropnp_build', os.path.join(ROOT, 'epro-pnp_amd', 'build.py'))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        _EMU_LIB = mod.build(emu=True)
+        import fcntl
+        os.makedirs(os.path.join(ROOT, 'tests', 'emu', '_build'), exist_ok=True)
+        with open(os.path.join(ROOT, 'tests', 'emu', '_build', '.lock'), 'w') as lock:      # pytest-xdist: one worker builds, the others wait
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            _EMU_LIB = mod.build(emu=True)
     return _EMU_LIB
 
 

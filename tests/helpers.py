@@ -84,3 +84,13 @@ def rel_per_object(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     d = (a - b).abs().reshape(a.shape[0], -1).amax(1)
     return d / b.abs().reshape(b.shape[0], -1).amax(1).clamp(min=1e-30)
+
+
+def set_tune(monkeypatch, **keys):
+    """EPROPNP_TUNE (csrc/pnp_host.h: tune_value, epropnp/_hip.py: tune) from keyword arguments: `bwd_impl='valu'`, `bwd_mfma='4,2'`,
+    a bare flag as `rslm_composite=True`; no keys (or only None / False values) removes the variable."""
+    items = [k if v is True else f'{k}={v}' for k, v in keys.items() if v is not None and v is not False]
+    if items:
+        monkeypatch.setenv('EPROPNP_TUNE', ';'.join(items))
+    else:
+        monkeypatch.delenv('EPROPNP_TUNE', raising=False)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import epropnp_oracle as orc
-from helpers import assert_within_spread, load_golden, make_layer_objects, pack_noise, rel_per_object
+from helpers import assert_within_spread, load_golden, make_layer_objects, pack_noise, rel_per_object, set_tune
 
 POSE_TOL = 1e-4     # north-star tolerance on the pose
 KL_TOL = 1e-3       # north-star tolerance on the Monte-Carlo (KL) loss
@@ -110,7 +110,7 @@ def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
 @pytest.mark.parametrize('N,bounds', [(800, None), (1100, 'tight'), (2048, None)])
 def test_forward_point_tiles_in_chunks_through_the_registers(backend, monkeypatch, N, bounds):
     """Beyond 48 point tiles per object the register-mode forward keeps 8 tiles per wave and takes the object's tiles through the
-    registers in chunks of 32 per iteration (instead of 16 resident tiles per wave / 8-wave workgroups); EPROPNP_FWD_NO_CHUNKS
+    registers in chunks of 32 per iteration (instead of 16 resident tiles per wave / 8-wave workgroups); EPROPNP_TUNE=fwd_no_chunks
     keeps the old shapes.  Same samples in the first iteration (they do not depend on the sweep), costs to summation order."""
     from epropnp import functional as F
     B, S, K, dof = 2, 64, 2, 6
@@ -119,11 +119,11 @@ def test_forward_point_tiles_in_chunks_through_the_registers(backend, monkeypatc
     p, cam, cf = make_layer_objects(prob, backend)
     hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
     pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
-    monkeypatch.delenv('EPROPNP_FWD_NO_CHUNKS', raising=False)
+    set_tune(monkeypatch)
     s1, w1 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     again = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     assert torch.equal(s1, again[0]) and torch.equal(w1, again[1])
-    monkeypatch.setenv('EPROPNP_FWD_NO_CHUNKS', '1')
+    set_tune(monkeypatch, fwd_no_chunks=True)
     s2, w2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     s = S // K
     assert torch.equal(s1[:s], s2[:s])
@@ -138,7 +138,7 @@ def test_backward_matches_autograd_of_oracle_at_fixed_samples(backend, monkeypat
     upstream gradients, samples fixed -> compare with autograd through the oracle's evaluate (which is what the
     reference's autograd replays)."""
     from epropnp import functional as F
-    monkeypatch.setenv('EPROPNP_BWD_IMPL', impl)
+    set_tune(monkeypatch, bwd_impl=impl)
     for dof, bounds in ((6, None), (4, 'tight'), (6, 'tight')):
         B, S = 3, 40
         if N == 17:                               # pose table larger than LDS: the MFMA launcher hands over to the VALU kernel
@@ -258,7 +258,7 @@ def test_backward_without_pose_init(backend, monkeypatch, impl, nsplit):
     of pose_init.  (On the GPU the wave-uniform g_init[b] is a scalar load; it used to sit inside a per-lane conditional,
     where it is executed even when no lane takes the arm, and faulted on the NULL pointer.)"""
     from epropnp import functional as F
-    monkeypatch.setenv('EPROPNP_BWD_IMPL', impl)
+    set_tune(monkeypatch, bwd_impl=impl)
     B, N, S, dof = 3, 150, 48, 6
     prob = orc.make_problem(B, N, dof, seed=29)
     p, cam, cf = make_layer_objects(prob, backend)
@@ -282,9 +282,7 @@ def test_backward_bf16_split_projection_against_the_fp32_matrix_path(backend, mo
     products per real k are carried: ~1.4e-7 per projection), poses behind the camera and zero / negligible weights included,
     and run-to-run the same bits."""
     from epropnp import functional as F
-    monkeypatch.setenv('EPROPNP_BWD_IMPL', 'mfma')
-    if shape:
-        monkeypatch.setenv('EPROPNP_BWD_MFMA', shape)
+    set_tune(monkeypatch, bwd_impl='mfma', bwd_mfma=shape or None)
     prob = orc.make_problem(B, N, dof, seed=41, bounds=bounds)
     g = torch.Generator().manual_seed(8)
     poses = prob['pose_gt'].unsqueeze(0).repeat(S, 1, 1)
@@ -407,7 +405,7 @@ def test_philox_sampler_statistics(backend):
 
 
 def test_forward_kernel_variants_agree(backend, monkeypatch):
-    """EPROPNP_FWD_IMPL=valu selects the register-resident VALU sweep kernel; same samples, same weights."""
+    """EPROPNP_TUNE=fwd_impl=valu selects the register-resident VALU sweep kernel; same samples, same weights."""
     from epropnp import functional as F
     B, N, S, K, dof = 3, 200, 64, 4, 6
     prob = orc.make_problem(B, N, dof, seed=17)
@@ -415,29 +413,29 @@ def test_forward_kernel_variants_agree(backend, monkeypatch):
     p, cam, cf = make_layer_objects(prob, backend)
     hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, dof)
     pose_opt, pose_cov, _ = F.lm_solve(hp, p['pose_init'], 3, with_pose_cov=True)
-    monkeypatch.delenv('EPROPNP_FWD_IMPL', raising=False)
+    set_tune(monkeypatch)
     s1, w1 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
-    monkeypatch.setenv('EPROPNP_FWD_IMPL', 'valu')
+    set_tune(monkeypatch, fwd_impl='valu')
     s2, w2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     assert (s1 - s2).abs().max().item() < 5e-4
     assert (torch.logsumexp(w1, 0) - torch.logsumexp(w2, 0)).abs().max().item() < 1e-3
     # on-device Philox draws: the MFMA kernel pre-generates the base noise into LDS shared with its pose table, the VALU
     # kernel draws inline -- same counters, same samples
-    monkeypatch.delenv('EPROPNP_FWD_IMPL')
+    set_tune(monkeypatch)
     p1, q1 = F.amis_forward(hp, pose_opt, pose_cov, S, K, seed=42, offset=7)
-    monkeypatch.setenv('EPROPNP_FWD_IMPL', 'valu')
+    set_tune(monkeypatch, fwd_impl='valu')
     p2, q2 = F.amis_forward(hp, pose_opt, pose_cov, S, K, seed=42, offset=7)
     assert (p1 - p2).abs().max().item() < 5e-4
     assert (torch.logsumexp(q1, 0) - torch.logsumexp(q2, 0)).abs().max().item() < 1e-3
     # MFMA kernel, LDS-chunk mode (used for N > 2048), forced on this small problem with 2 waves
-    monkeypatch.delenv('EPROPNP_FWD_IMPL')
-    monkeypatch.setenv('EPROPNP_FWD_MFMA', '2,0')
+    set_tune(monkeypatch)
+    set_tune(monkeypatch, fwd_mfma='2,0')
     s3, w3 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     assert (s1 - s3).abs().max().item() < 5e-4
     assert (torch.logsumexp(w1, 0) - torch.logsumexp(w3, 0)).abs().max().item() < 1e-3
     # the projection on the fp32 MFMA instead of the bf16x3 split (register mode): the first iteration's samples do not depend on
     # the sweep at all and its log-weights only through the costs -- fp32-level agreement; later iterations through the refit
-    monkeypatch.delenv('EPROPNP_FWD_MFMA')
+    set_tune(monkeypatch)
     monkeypatch.setenv('EPROPNP_FWD_PROJ', 'f32')
     s4, w4 = F.amis_forward(hp, pose_opt, pose_cov, S, K, noise=noise)
     monkeypatch.delenv('EPROPNP_FWD_PROJ')
@@ -725,7 +723,7 @@ def test_backward_drop_threshold_is_mass_bounded(backend, monkeypatch, impl):
     object's total (csrc/amis_common.h: mass_drop_threshold).  Heavy-tailed softmax weights (most samples negligible):
     the default differs from the exact sum (EPROPNP_BWD_DROP=0) by rounding only, a coarse 1e-3 budget by at most ~1e-3."""
     from epropnp import functional as F
-    monkeypatch.setenv('EPROPNP_BWD_IMPL', impl)
+    set_tune(monkeypatch, bwd_impl=impl)
     B, N, S, dof = 3, 100, 256, 6
     prob = orc.make_problem(B, N, dof, seed=23)
     g = torch.Generator().manual_seed(9)

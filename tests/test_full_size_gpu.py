@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import epropnp_oracle as orc
-from helpers import assert_within_spread, make_layer_objects, pack_noise, rel_per_object
+from helpers import assert_within_spread, make_layer_objects, pack_noise, rel_per_object, set_tune
 
 pytestmark = pytest.mark.gpu
 
@@ -292,7 +292,7 @@ def test_c2_gn_step_fused_vs_composite_and_backward_variants(dev, monkeypatch):
     gi = torch.full((B,), 1.0 / B, device=dev)
     outs = {}
     for impl in ('mfma', 'valu'):
-        monkeypatch.setenv('EPROPNP_BWD_IMPL', impl)
+        set_tune(monkeypatch, bwd_impl=impl)
         outs[impl] = F.amis_backward(hp_all, o[3], g, prob['pose_init'], gi)
         # bit-identical from run to run at full occupancy (an instruction-hazard defect shows up exactly here and as
         # run-to-run differences, while every small-shape test passes: profiles/r03_tune_bwd_bf16_split.txt)
@@ -322,9 +322,9 @@ def test_c4_fused_rslm_vs_composite(dev, monkeypatch):
     rot = torch.rand(P, B, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 6.283185307179586
     solver = RSLMSolver(dof=4, num_points=n, num_proposals=P, num_iter=3)
     solver.draw = lambda w2d: (inds, rot)
-    monkeypatch.setenv('EPROPNP_RSLM_COMPOSITE', '1')
+    set_tune(monkeypatch, rslm_composite=True)
     pose_c, _, cost_c = solver.solve(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf)
-    monkeypatch.delenv('EPROPNP_RSLM_COMPOSITE')
+    set_tune(monkeypatch)
     pose_f, _, cost_f = solver.solve(prob['x3d'], prob['x2d'], prob['w2d'], cam, cf)
     torch.testing.assert_close(cost_f, cost_c, rtol=5e-4, atol=1e-5)
     assert int(((pose_f - pose_c).abs().max(-1).values < 1e-3).sum()) >= B - 6          # rounding-level ties may differ

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import epropnp_oracle as orc
-from helpers import make_layer_objects, pack_noise
+from helpers import make_layer_objects, pack_noise, set_tune
 
 
 def _layer(dof, S, K, L, normalize, rslm):
@@ -22,14 +22,14 @@ def _layer(dof, S, K, L, normalize, rslm):
                                                              (6, False, True, True, None)])
 def test_fused_forward_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bounds):
     """epropnp_monte_carlo_forward enqueues the same kernels the separate calls do: outputs and input gradients are
-    bit-identical to the composite path (EPROPNP_NO_FUSED_FORWARD=1), with and without pnp_normalize, RSLM
+    bit-identical to the composite path (EPROPNP_TUNE=no_fused_forward), with and without pnp_normalize, RSLM
     initialisation (injected draws), pose_opt_plus and projection bounds; force_init_solve picks per object."""
     _fused_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bounds, 5, 70, 32, 2, 3)
 
 
 @pytest.mark.parametrize('dof,normalize,force,bounds', [(4, True, True, 'tensor'), (6, False, True, None), (6, True, False, 'tight')])
 def test_rslm_split_winner_is_picked_inside_the_lm_launch(backend, monkeypatch, dof, normalize, force, bounds):
-    """With the initialiser's proposals dealt to several workgroups per object (EPROPNP_RSLM_PARTS, the default at <= 768 objects on
+    """With the initialiser's proposals dealt to several workgroups per object (EPROPNP_TUNE=rslm_parts=.., the default at <= 768 objects on
     the GPU) the one-call forward leaves the reduce launch out: the LM kernel picks the winner over the parts -- and, with
     force_init_solve on a given pose_init, the cheaper of that and pose_init -- itself (lm_core.h: StartSelect).  Same bits as one
     workgroup per object, whose start goes through the plain pose array."""
@@ -39,7 +39,7 @@ def test_rslm_split_winner_is_picked_inside_the_lm_launch(backend, monkeypatch, 
     noise = pack_noise(orc.make_noise(B, S, K, dof, seed=62), dof).to(backend)
     outs = []
     for parts in ('1', '2', '4'):
-        monkeypatch.setenv('EPROPNP_RSLM_PARTS', parts)
+        set_tune(monkeypatch, rslm_parts=parts)
         p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
         x3d, x2d, w2d = (p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
         cf.set_param(x2d.detach(), w2d)
@@ -94,9 +94,9 @@ def _fused_equals_composite(backend, monkeypatch, dof, normalize, rslm, plus, bo
     outs = []
     for fused in (True, False):
         if fused:
-            monkeypatch.delenv('EPROPNP_NO_FUSED_FORWARD', raising=False)
+            set_tune(monkeypatch)
         else:
-            monkeypatch.setenv('EPROPNP_NO_FUSED_FORWARD', '1')
+            set_tune(monkeypatch, no_fused_forward=True)
         p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
         x3d, x2d, w2d = (p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
         cf.set_param(x2d.detach(), w2d)
@@ -330,7 +330,7 @@ def _delta_fold_case(dev, monkeypatch, dof, B, N, S, K, bounds, normalize, nspli
     if nsplit_env is not None:
         monkeypatch.setenv('EPROPNP_BWD_SPLIT', nsplit_env)
     if impl_env is not None:
-        monkeypatch.setenv('EPROPNP_BWD_IMPL', impl_env)
+        set_tune(monkeypatch, bwd_impl=impl_env)
     from epropnp import functional as F
     seen, real = [], F.PnPProblem.fold_delta
     monkeypatch.setattr(F.PnPProblem, 'fold_delta', lambda self, *a: (seen.append(True), real(self, *a))[1])

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import epropnp_oracle as orc
-from helpers import make_layer_objects
+from helpers import make_layer_objects, set_tune
 
 
 def _solvers(dof, P, n, L, inds, rot):
@@ -31,9 +31,9 @@ def test_fused_matches_composite_on_same_draws(backend, monkeypatch, dof, N, P, 
     else:
         rot = torch.nn.functional.normalize(torch.randn(P, B, 4, generator=g), dim=-1)
     solver = _solvers(dof, P, n, L, inds, rot)
-    monkeypatch.setenv('EPROPNP_RSLM_COMPOSITE', '1')
+    set_tune(monkeypatch, rslm_composite=True)
     pose_c, _, cost_c = solver.solve(d['x3d'], d['x2d'], d['w2d'], cam, cf, fast_mode=fast)
-    monkeypatch.delenv('EPROPNP_RSLM_COMPOSITE')
+    set_tune(monkeypatch)
     pose_f, _, cost_f = solver.solve(d['x3d'], d['x2d'], d['w2d'], cam, cf, fast_mode=fast)
     torch.testing.assert_close(cost_f.cpu(), cost_c.cpu(), rtol=2e-4, atol=1e-5)
     # same winning proposal unless two proposals tie to rounding; then the costs above already agree

@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from helpers import load_golden, make_layer_objects
+from helpers import load_golden, make_layer_objects, set_tune
 
 
 @pytest.mark.parametrize('name', ['eval6', 'eval6_clip', 'eval4_clip'])
@@ -102,9 +102,9 @@ def test_normal_equations_launch_shapes_agree(backend, monkeypatch, dof, bounds,
             shapes.append(f'{w},{ppl}')
     for shape in shapes:
         if shape is None:
-            monkeypatch.delenv('EPROPNP_NE_SHAPE', raising=False)
+            set_tune(monkeypatch)
         else:
-            monkeypatch.setenv('EPROPNP_NE_SHAPE', shape)
+            set_tune(monkeypatch, ne_shape=shape)
         a, b, c = (t.cpu().double() for t in F.normal_equations(hp, p['pose_init']))
         scale = jtj.abs().amax(dim=(-1, -2), keepdim=True)
         assert ((a - jtj).abs() / scale).max() < 2e-5, shape

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of two forward-kernel variants selected by environment variables, on identical Philox counters (run on the GPU box).
 
-    python tools/diag_fwd_variant.py EPROPNP_FWD_MFMA=8,4          # e.g. another launch shape; any KEY=VALUE pairs
+    python tools/diag_fwd_variant.py EPROPNP_TUNE=fwd_mfma=8,4          # e.g. another launch shape; any KEY=VALUE pairs
 
 The first AMIS iteration draws from the same proposal with the same counters in both variants, so its samples must be
 bit-identical and its log-weights differ only by the sweep's arithmetic: the script prints where they differ (by sample

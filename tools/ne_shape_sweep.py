@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """IC-cold timing of normal_equations_kernel (one Jacobian sweep) under workgroup-shape overrides (run on the GPU box).
 
-    python tools/ne_shape_sweep.py [B N]          # driver: one subprocess per EPROPNP_NE_SHAPE=waves,ppl
+    python tools/ne_shape_sweep.py [B N]          # driver: one subprocess per EPROPNP_TUNE=ne_shape=waves,ppl
 """
 import json
 import os
@@ -45,7 +45,7 @@ def main():
     for sh in shapes:
         e = dict(os.environ, NE_B=str(B), NE_N=str(N))
         if sh != 'default':
-            e['EPROPNP_NE_SHAPE'] = sh
+            e['EPROPNP_TUNE'] = 'ne_shape=' + sh
         r = subprocess.run([sys.executable, __file__, '--worker'], env=e, capture_output=True, text=True)
         line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else 'FAILED ' + r.stderr.strip()[-300:]
         print(f'B={B} N={N} shape={sh:8s} {line}', flush=True)

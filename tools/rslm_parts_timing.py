@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """RSLM initialiser (600 x 128 points, 4-DoF, 16 points per proposal, 3 LM iterations): one workgroup per object against the
-proposals of an object dealt to 2 / 4 workgroups (EPROPNP_RSLM_PARTS), kernel time by HIP events.  python tools/rslm_parts_timing.py"""
+proposals of an object dealt to 2 / 4 workgroups (EPROPNP_TUNE=rslm_parts=..), kernel time by HIP events.  python tools/rslm_parts_timing.py"""
 import json
 import os
 import sys
@@ -29,9 +29,9 @@ def main():
         ref = None
         for q in ('1', '2', '4', 'auto'):
             if q == 'auto':
-                os.environ.pop('EPROPNP_RSLM_PARTS', None)
+                os.environ.pop('EPROPNP_TUNE', None)
             else:
-                os.environ['EPROPNP_RSLM_PARTS'] = q
+                os.environ['EPROPNP_TUNE'] = 'rslm_parts=' + q
             for _ in range(3):
                 out = F.rslm_solve(hp, P, 16, 3, seed=1, offset=7)
             ts = []

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """AMIS forward / backward / RSLM / LM kernel times at the Det shape (600 x 128 points, 4-DoF, S = 128, K = 4) under the current
-env (EPROPNP_LIB, EPROPNP_ABLATE ...): median of 8 windows of 10 launches.   python tools/time_fwd4.py [B N S K]"""
+env (EPROPNP_LIB, EPROPNP_TUNE=ablate=.. ...): median of 8 windows of 10 launches.   python tools/time_fwd4.py [B N S K]"""
 import json
 import os
 import sys

@@ -72,10 +72,22 @@ def worker(B, N, S, K, L, reps=8):
 VARIANTS = [
     ('default', {}),
 ]
-# TUNE_VARIANTS="name:KEY=VAL+KEY=VAL;name2:KEY=VAL" adds env variants without editing this file
-for _spec in filter(None, os.environ.get('TUNE_VARIANTS', '').split(';')):
+# TUNE_VARIANTS="name:KEY=VAL+KEY=VAL|name2:KEY=VAL" adds variants without editing this file.  An UPPER-CASE key is an environment
+# variable of its own (the user-facing knobs: EPROPNP_BWD_DROP, EPROPNP_FWD_PROJ ...), a lower-case key goes into the one tuning
+# string the library reads, EPROPNP_TUNE="lm_shape=1,8;bwd_impl=valu;ablate=2" (csrc/pnp_host.h: tune_value):
+#     TUNE_VARIANTS="norefit:ablate=2|valu:bwd_impl=valu+fwd_impl=valu|exact:EPROPNP_BWD_DROP=0" python tools/tune.py
+for _spec in filter(None, os.environ.get('TUNE_VARIANTS', '').split('|')):
     _name, _, _kv = _spec.partition(':')
-    VARIANTS.append((_name, dict(kv.split('=', 1) for kv in _kv.split('+') if kv)))
+    _env, _tune = {}, []
+    for kv in filter(None, _kv.split('+')):
+        k, _, v = kv.partition('=')
+        if k.isupper():
+            _env[k] = v
+        else:
+            _tune.append(kv)
+    if _tune:
+        _env['EPROPNP_TUNE'] = ';'.join(_tune)
+    VARIANTS.append((_name, _env))
 
 
 def main():
