@@ -25,8 +25,18 @@
 
 namespace pnp {
 
+// Register budget: three waves per SIMD (168 VGPRs) -- except the bf16 instantiation with a projection clamp and four resident tiles,
+// which needs ~190 and is compiled for two.  At 168 it spilled 23-29 dwords per lane, two B-operand tuples among them that were
+// reloaded INSIDE the pose-tile loop in front of the MFMAs that read them -- and that build was intermittently wrong on the
+// MI355X (one point tile of one wave off by ~1e-3, about every second process; profiles/r05_bwd_scratch.txt).  The launcher takes
+// this instantiation only where the grid leaves a CU at most two workgroups anyway (the few-object shapes: LineMOD crops) and the
+// fp32 projection (166 VGPRs, nothing spilled) elsewhere.  Rule (tools/kernel_resources.py --check): no scratch access inside
+// a loop of any instantiation a launcher can select.
+template <int DOF, bool BOUNDS, int NPT, bool BF16>
+constexpr int bwd_min_waves() { return (BOUNDS && BF16 && NPT == 4) ? 2 : PNP_BWD_MINW; }
+
 template <int DOF, bool BOUNDS, int NPT, bool BF16 = false>
-__global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backward_mfma_kernel(Problem p, const float* __restrict__ pose_samples,
+__global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) void amis_backward_mfma_kernel(Problem p, const float* __restrict__ pose_samples,
                                                                      const float* __restrict__ g_logw, int S,
                                                                      const float* __restrict__ pose_init,
                                                                      const float* __restrict__ g_init, int P16,
@@ -134,8 +144,6 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
   __syncthreads();
 
   const int col = lane & 15, kk = lane >> 4, g4 = kk * 4;
-  const float ind0 = (col == 0) ? 1.f : 0.f, ind1 = (col == 1) ? 1.f : 0.f, ind2 = (col == 2) ? 1.f : 0.f,
-              ind3 = (col == 3) ? 1.f : 0.f;
   float gd = 0.f;
   const int chunk_pts = W * NPT * 16;
   for (int c0 = part * chunk_pts; c0 < p.N; c0 += nsplit * chunk_pts) {
@@ -196,8 +204,10 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
           // d/dw = crx * (px - u) = crx * rx / w and d/du = -crx * w: the per-point factors are applied once at the end
           A2x[i] = fmaf(crx, rx, A2x[i]);
           A2y[i] = fmaf(cry, ry, A2y[i]);
-          A1x[i] += crx;
-          A1y[i] += cry;
+          // (written as the fused operation the compiler picks under -ffp-contract=fast -- in SOME copies of this loop: a peeled first
+          // chunk kept `A1 += round(coef r)`, and the same point came out 1 ulp apart in the split and the unsplit launch)
+          A1x[i] = fmaf(coef, rx, A1x[i]);
+          A1y[i] = fmaf(coef, ry, A1y[i]);
           float gpx = crx * w4.x, gpy = cry * w4.y;
           if (BOUNDS) {                  // the clamp passes no gradient where it is active: inside [lb, ub] <=> clamp(x) == x
             gpx = (px == ppx) ? gpx : 0.f;
@@ -212,6 +222,13 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
       }
     }
     // ---- outputs of this chunk: sums over the 4 pose groups of a point via MFMAs against indicator columns ----
+    // The lane geometry is re-derived here behind an opaque copy of the lane index: as invariants of the chunk loop the four
+    // indicator columns and the three 64-bit output addresses were hoisted in front of it and stayed live across the pose-tile
+    // loop -- 10 VGPRs, which cost the bf16 instantiation 7 spilled dwords per lane (33 MB of scratch traffic per launch at C2).
+    const int laneE = __float_as_int(to_vgpr(__int_as_float(lane)));
+    const int colE = laneE & 15, g4E = (laneE >> 4) * 4;
+    const float ind0 = (colE == 0) ? 1.f : 0.f, ind1 = (colE == 1) ? 1.f : 0.f, ind2 = (colE == 2) ? 1.f : 0.f,
+                ind3 = (colE == 3) ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       floatx4 D1 = zero;
@@ -224,16 +241,16 @@ __global__ __launch_bounds__(512, (NPT <= 4 ? PNP_BWD_MINW : 2)) void amis_backw
       D2 = mfma_16x16x4(-w4.y * A1y[i] * hs.delta_sq, ind1, D2);                            // d/dv
       D2 = mfma_16x16x4((w4.x != 0.f) ? A2x[i] * hs.delta / w4.x : 0.f, ind2, D2);          // d/dwu
       D2 = mfma_16x16x4((w4.y != 0.f) ? A2y[i] * hs.delta / w4.y : 0.f, ind3, D2);          // d/dwv
-      const int nb = c0 + (wv + W * i) * 16 + g4;     // D rows: points nb + r; column = lane & 15
+      const int nb = c0 + (wv + W * i) * 16 + g4E;    // D rows: points nb + r; column = lane & 15
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb + r;
         if (n < p.N) {
           const size_t o = (size_t)b * p.N + n;
-          if (col < 3) gx3d[o * 3 + col] = D1[r];
-          if (col < 2) gx2d[o * 2 + col] = D2[r];
-          else if (col < 4) {
-            if (park) gwl[n * 2 + (col - 2)] = D2[r]; else gw2d[o * 2 + (col - 2)] = D2[r];
+          if (colE < 3) gx3d[o * 3 + colE] = D1[r];
+          if (colE < 2) gx2d[o * 2 + colE] = D2[r];
+          else if (colE < 4) {
+            if (park) gwl[n * 2 + (colE - 2)] = D2[r]; else gw2d[o * 2 + (colE - 2)] = D2[r];
           }
         }
       }
@@ -262,8 +279,7 @@ static int dispatch_bwd_npt(int npt, F&& f) {
   switch (npt) {
     case 1: return f(ic<1>{});
     case 2: return f(ic<2>{});
-    case 4: return f(ic<4>{});
-    default: return f(ic<8>{});
+    default: return f(ic<4>{});
   }
 }
 
@@ -293,13 +309,16 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
     waves = 4; npt = 1;
     while (npt < 4 && waves * npt * nsplit < ptiles) npt *= 2;
   }
-  { int ov[2]; if (tune_ints("bwd_mfma", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8)) { waves = ov[0]; npt = ov[1]; } }
+  { int ov[2]; if (tune_ints("bwd_mfma", ov, 2) && ov[0] >= 1 && ov[0] <= 8 && (ov[1] == 1 || ov[1] == 2 || ov[1] == 4)) { waves = ov[0]; npt = ov[1]; } }
   // Projection on the bf16 matrix path (kernel comment) wherever the split operands fit the register budget of three waves per
   // SIMD (<= 4 resident point tiles: 4 VGPRs per tile instead of 1).  C2 backward 0.954 -> 0.899 ms, bounded 1.111 -> 1.037 ms,
   // Det shape neutral (profiles/r04_bwd_bf16_projection.txt).  EPROPNP_BWD_PROJ=f32 | bf16 forces either.
-  bool bf16 = npt <= 4;
-  if (const char* e = getenv("EPROPNP_BWD_PROJ")) bf16 = (e[0] == 'f') ? false : (e[0] == 'b' ? npt <= 4 : bf16);
+  // (With a projection clamp and four resident tiles the bf16 instantiation is a two-waves-per-SIMD kernel, see above: taken where
+  // the grid gives a CU no more than two such workgroups.)
   const dim3 grid(padded_object_grid(d.B * nsplit)), block(64 * waves);
+  const bool two_per_simd = has_bounds(prob) && npt == 4;
+  bool bf16 = !two_per_simd || (long)grid.x * waves <= 8L * device_cu_count();
+  if (const char* e = getenv("EPROPNP_BWD_PROJ")) bf16 = (e[0] == 'f') ? false : (e[0] == 'b' ? true : bf16);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     auto launch = [&](auto kern) -> int {
       allow_dynamic_lds((const void*)kern, smem);
