@@ -540,6 +540,9 @@ def main(argv=None, device=None, backend='nccl'):
 
     # The same steps with the per-stage HIP events INSIDE the timed window -- rounds 1-3 timed the step that way -- so that the
     # headline can be compared like for like with BENCH_r01..r03 (~16 event records per step: ~3 % of a 1.5 ms step).
+    STAGES = ('evaluate_cost', 'rslm_solve', 'lm_solve', 'amis_forward', 'amis_backward', 'adaptive_delta', 'mc_loss_forward',
+              'mc_loss_backward', 'center_points', 'shift_poses')
+    stage_ms = {n: _hip.profile_read(n) for n in STAGES} if on_gpu else {}       # (read before the next leg re-uses the recorder)
     events_in_region = None
     if on_gpu and launch == 'eager' and not prof_in_region and args.config not in LAUNCH_BOUND and world == 1:
         n_ev = min(args.steps, 100)
@@ -604,9 +607,6 @@ def main(argv=None, device=None, backend='nccl'):
     if rank == 0 and on_gpu:
         ms = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
-        stage_ms = {n: _hip.profile_read(n) for n in ('evaluate_cost', 'rslm_solve', 'lm_solve', 'amis_forward', 'amis_backward',
-                                                       'adaptive_delta', 'mc_loss_forward', 'mc_loss_backward',
-                                                       'center_points', 'shift_poses')}
         t_lm, t_fw, t_bw, t_ci = (stage_ms[n][0] for n in ('lm_solve', 'amis_forward', 'amis_backward', 'evaluate_cost'))
         assert stage_ms['lm_solve'][1] == prof_steps and stage_ms['amis_backward'][1] == prof_steps, stage_ms
         sweeps = 1 + L

@@ -26,12 +26,14 @@
 namespace pnp {
 
 // Register budget: three waves per SIMD (168 VGPRs) -- except the bf16 instantiation with a projection clamp and four resident tiles,
-// which needs ~190 and is compiled for two.  At 168 it spilled 23-29 dwords per lane, two B-operand tuples among them that were
-// reloaded INSIDE the pose-tile loop in front of the MFMAs that read them -- and that build was intermittently wrong on the
-// MI355X (one point tile of one wave off by ~1e-3, about every second process; profiles/r05_bwd_scratch.txt).  The launcher takes
-// this instantiation only where the grid leaves a CU at most two workgroups anyway (the few-object shapes: LineMOD crops) and the
-// fp32 projection (166 VGPRs, nothing spilled) elsewhere.  Rule (tools/kernel_resources.py --check): no scratch access inside
-// a loop of any instantiation a launcher can select.
+// which needs ~196 and is compiled for two.  At 168 it spilled 23-29 dwords per lane, B-operand tuples among them that were reloaded
+// INSIDE the pose-tile loop -- and every build of this kernel with such reloads, the round-4 one included, has returned wrong
+// gradients for some point tiles whenever two waves shared a SIMD (profiles/r05_bwd_scratch.txt; what the hardware objects to is
+// not established -- the instruction stream is correct by the in-order rules).  The shapes with projection bounds in the
+// reference's callers are the few-object ones (LineMOD crops: two workgroups per CU whatever the budget); a bounded many-object
+// batch pays a third of its occupancy (EPROPNP_BWD_PROJ=f32: 168 VGPRs, three waves per SIMD).
+// Rules: no scratch access inside a loop of this kernel (tools/scratch_audit.py --check), and every instantiation must pass the
+// repeated-launch test at full occupancy (tests/test_determinism_gpu.py) -- a defect of this kind is invisible to a tolerance.
 template <int DOF, bool BOUNDS, int NPT, bool BF16>
 constexpr int bwd_min_waves() { return (BOUNDS && BF16 && NPT == 4) ? 2 : PNP_BWD_MINW; }
 
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
   const int b = v / nsplit, part = v - b * nsplit;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), W = T >> 6;
 
+  PNP_PHASES_BEGIN(6);      // (tuning builds: cycles in [weights | drop threshold | compaction | pose rows | sweep + outputs | tail])
   PNP_DYN_SMEM(float, smem);
   float* ptab = smem;                                   // [P16][12]  x | y | z rows of (K R | K t), compacted
   float* wtab = ptab + 12 * P16;                        // [P16]      weights of the compacted poses
@@ -95,10 +98,12 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
   }
   amax = block_max(amax, red);          // (barriers inside: wraw is visible to every wave afterwards)
   __syncthreads();
+  PNP_PHASE(0);
   const float askip = mass_drop_threshold([&](int m) { return fabsf(wraw[m]); }, S, amax, drop_eps, hist);
   for (int m = tid; m < S; m += T)
     if (fabsf(wraw[m]) <= askip) wraw[m] = 0.f;
   __syncthreads();
+  PNP_PHASE(1);
   if (wv == 0) {     // ordered compaction by one wave: lane l owns the contiguous samples [l*seg, (l+1)*seg)
     const int seg = (P + 63) >> 6;
     const int m0 = lane * seg, m1 = min(P, m0 + seg);
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
     if (lane == 0) lcnt[64] = total;
   }
   __syncthreads();
+  PNP_PHASE(2);
   const int nact = reinterpret_cast<const int*>(red)[64];
   const int ntile = (nact + 15) >> 4;
   for (int c = tid; c < ntile * 16; c += T) {
@@ -142,6 +148,7 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
     }
   }
   __syncthreads();
+  PNP_PHASE(3);
 
   const int col = lane & 15, kk = lane >> 4, g4 = kk * 4;
   float gd = 0.f;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
     // The lane geometry is re-derived here behind an opaque copy of the lane index: as invariants of the chunk loop the four
     // indicator columns and the three 64-bit output addresses were hoisted in front of it and stayed live across the pose-tile
     // loop -- 10 VGPRs, which cost the bf16 instantiation 7 spilled dwords per lane (33 MB of scratch traffic per launch at C2).
-    const int laneE = __float_as_int(to_vgpr(__int_as_float(lane)));
+    const int laneE = (int)f32_bits(to_vgpr(bits_f32((unsigned)lane)));
     const int colE = laneE & 15, g4E = (laneE >> 4) * 4;
     const float ind0 = (colE == 0) ? 1.f : 0.f, ind1 = (colE == 1) ? 1.f : 0.f, ind2 = (colE == 2) ? 1.f : 0.f,
                 ind3 = (colE == 3) ? 1.f : 0.f;
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
       }
     }
   }
+  PNP_PHASE(4);
   float one[1] = {gd * hs.delta};
   block_sum<1>(one, red);
   if (tid == 0) gdelta[v] = one[0];
@@ -272,7 +280,12 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
       for (int i = tid; i < 2 * p.N; i += T) row[i] += add;
     }
   }
+  PNP_PHASE(5);
+  PNP_PHASES_FLUSH(6);
 }
+
+// per-phase cycle totals of this file's kernel (tuning builds; -1 otherwise)
+int tuning_bwd_phase_cycles(unsigned long long* out, int reset) { return tuning::read_cycles(out, reset, false); }
 
 template <class F>
 static int dispatch_bwd_npt(int npt, F&& f) {
@@ -313,11 +326,11 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
   // Projection on the bf16 matrix path (kernel comment) wherever the split operands fit the register budget of three waves per
   // SIMD (<= 4 resident point tiles: 4 VGPRs per tile instead of 1).  C2 backward 0.954 -> 0.899 ms, bounded 1.111 -> 1.037 ms,
   // Det shape neutral (profiles/r04_bwd_bf16_projection.txt).  EPROPNP_BWD_PROJ=f32 | bf16 forces either.
-  // (With a projection clamp and four resident tiles the bf16 instantiation is a two-waves-per-SIMD kernel, see above: taken where
-  // the grid gives a CU no more than two such workgroups.)
+  // (With a projection clamp and four resident tiles the bf16 instantiation is a two-waves-per-SIMD kernel, see above.  It is taken
+  // whatever the grid: which projection arithmetic an object gets must not depend on how many objects share the launch or on how
+  // its points are split over workgroups -- the per-point gradients of the split and the unsplit launch are the same bits.)
   const dim3 grid(padded_object_grid(d.B * nsplit)), block(64 * waves);
-  const bool two_per_simd = has_bounds(prob) && npt == 4;
-  bool bf16 = !two_per_simd || (long)grid.x * waves <= 8L * device_cu_count();
+  bool bf16 = true;
   if (const char* e = getenv("EPROPNP_BWD_PROJ")) bf16 = (e[0] == 'f') ? false : (e[0] == 'b' ? true : bf16);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     auto launch = [&](auto kern) -> int {

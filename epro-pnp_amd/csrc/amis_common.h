@@ -297,20 +297,32 @@ PNP_FIT_FN void initial_fit(const float* pose_opt, const float* cov, float eps, 
 // log-weights times the upstream gradient) span tens of orders of magnitude; the per-pair factor dc/dx is bounded
 // (Huber), so terms whose TOTAL weight is below `eps` of the object's total |weight| move the result by less than eps
 // relative -- at the default eps = 2^-24 that is one fp32 rounding of the sum itself.  The threshold is the largest
-// power-of-two fraction of max|a| for which the dropped mass stays within that budget (64 power-of-two bins, summed in
-// a fixed order: results stay bit-reproducible).  eps = 0 keeps every non-zero sample (exact).  Returns t: drop |a| <= t.
-// `wabs(m)` = |a_m| for m < S (wave-uniform argument); hist: LDS, (waves + 1) * 64 floats.  Ends on a barrier.
-constexpr int kDropHistFloats = 17 * 64;
+// power-of-two fraction of max|a| for which the dropped mass stays within that budget.  eps = 0 keeps every non-zero sample
+// (exact).  Returns t: drop |a| <= t.
+// Round 5: the 64 power-of-two bins hold their mass as 64-bit INTEGERS in units of max|a| * 2^-40, added with LDS atomics --
+// integer sums do not depend on the order of the additions, so every thread bins its own samples and the result stays
+// bit-reproducible; the suffix sums and the cut are taken by one wave, lane = bin.  (Until round 4 every wave walked through a
+// quarter of the samples with all its lanes, one sample per trip, and lane 0 scanned the bins one dependent load at a time:
+// 14 % of the backward's lifetime at 32 x 4096 points, 41 % at 32 x 512, 20 % at the detection shape --
+// profiles/r05_phase_shares.txt.)  A sample below 2^-40 of the maximum counts as mass 0: S such samples are 2^-31 of the
+// budget's unit at S = 512.
+// `wabs(m)` = |a_m| for m < S; hist: LDS, 8-byte aligned, kDropHistFloats floats.  Ends on a barrier.
+constexpr int kDropHistFloats = 2 * 66;
+// NOT inlined, on purpose: inlined into amis_backward_mfma_kernel this function changed the register allocation of the sweep
+// loop behind it (168 VGPRs with B-operand tuples reloaded from scratch inside the loop, where the old threshold code left
+// 164 and no scratch), and that build -- like every build of the kernel with scratch reloads inside its pair loop, the
+// round-4 one included -- returned wrong gradients for 1-2 % of the points whenever two waves shared a SIMD
+// (profiles/r05_bwd_scratch.txt).  Out of line it costs one call per workgroup and leaves the sweep the allocation it had.
 template <class W>
-__device__ __forceinline__ float mass_drop_threshold(W&& wabs, int S, float amax, float eps, float* hist) {
-  const int nw = (int)(blockDim.x >> 6), w = wave_id(), lane = lane_id();
+__device__ __attribute__((noinline)) float mass_drop_threshold(W&& wabs, int S, float amax, float eps, float* hist) {
+  unsigned long long* bins = reinterpret_cast<unsigned long long*>(hist);      // [64] masses, [64] total, [65] threshold (float bits)
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = lane_id();
   const bool usable = (amax > 0.f) && (amax < INFINITY);          // all-zero / non-finite weights: drop nothing
   const float inv = usable ? 1.0f / amax : 0.f;
-  const int per = (S + nw - 1) / nw, m0 = w * per, m1 = min(S, m0 + per);
-  float mass = 0.f;
-  for (int m = m0; m < m1; ++m) {
-    const float a = wabs(m);
-    const float rel = a * inv;
+  if (tid < 64) bins[tid] = 0ull;
+  __syncthreads();
+  for (int m = tid; m < S; m += T) {
+    const float rel = fminf(wabs(m) * inv, 1.0f);                 // (a non-finite weight among finite ones: NaN -> 1.0f)
     // bin k holds 2^-(k+1) < rel <= 2^-k (k = 0..62); bin 63 holds the rest, zeros included
 #ifndef EPROPNP_EMU
     int k = (rel > 0.f) ? (int)(-__builtin_amdgcn_logf(rel)) : 63;
@@ -318,30 +330,22 @@ __device__ __forceinline__ float mass_drop_threshold(W&& wabs, int S, float amax
     int k = (rel > 0.f) ? (int)(-log2f(rel)) : 63;
 #endif
     k = min(max(k, 0), 63);
-    mass += (k == lane) ? a : 0.f;
+    const unsigned long long q = (unsigned long long)(rel * 0x1p40f);
+    if (q != 0ull) atomicAdd(&bins[k], q);
   }
-  hist[w * 64 + lane] = mass;
   __syncthreads();
-  if (w == 0) {
-    float tot = 0.f;
-    for (int k = 0; k < nw; ++k) tot += hist[k * 64 + lane];
-    hist[nw * 64 + lane] = tot;
+  if (tid < 64) {       // wave 0, lane = bin: c = mass of bins lane..63; the cut is the lowest bin whose suffix stays within the budget
+    unsigned long long c = 0ull;
+    for (int j = 63; j >= 0; --j) c += (j >= lane) ? bins[j] : 0ull;
+    if (lane == 0) bins[64] = c;
     wave_lds_fence();
-    if (lane == 0) {
-      float total = 0.f;
-      for (int j = 0; j < 64; ++j) total += hist[nw * 64 + j];
-      const float budget = eps * total;
-      float c = 0.f;
-      int kmin = 64;
-      for (int j = 63; j >= 0; --j) {
-        c += hist[nw * 64 + j];
-        if (c <= budget) kmin = j; else break;
-      }
-      hist[nw * 64] = (usable && kmin < 64) ? ldexpf(amax, -kmin) : 0.f;
-    }
+    const unsigned long long total = bins[64];
+    const unsigned long long budget = (unsigned long long)((double)total * (double)eps);
+    const unsigned kmin = wave_min_u32((c <= budget) ? (unsigned)lane : 64u);
+    if (lane == 0) hist[2 * 65] = (usable && kmin < 64u) ? ldexpf(amax, -(int)kmin) : 0.f;
   }
   __syncthreads();
-  const float t = hist[nw * 64];
+  const float t = hist[2 * 65];
   __syncthreads();
   return t;
 }

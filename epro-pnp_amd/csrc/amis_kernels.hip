@@ -156,7 +156,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
   // pose tiles: 64 poses x {K R (9) | K t (3) | weight | pad} as 4 float4 rows, double buffered
   __shared__ __attribute__((aligned(16))) float tab[2][64][16];
   __shared__ float red[16];
-  __shared__ float hist[kDropHistFloats];
+  __shared__ __attribute__((aligned(8))) float hist[kDropHistFloats];
   const int b = object_of_block(p.B);
   if (b >= p.B) return;
   const int T = (int)blockDim.x, tid = (int)threadIdx.x;

@@ -9,6 +9,7 @@
 namespace pnp {
 int tuning_phase_cycles(unsigned long long* out, int reset);          // amis_forward_mfma.hip / rslm_kernel.hip (tuning.h)
 int tuning_rslm_phase_cycles(unsigned long long* out, int reset);
+int tuning_bwd_phase_cycles(unsigned long long* out, int reset);
 char* last_error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
@@ -344,5 +345,6 @@ int epropnp_profile_read(const char* stage, float* mean_ms, int32_t* count) {
 // build (build.py -D PNP_TUNING); -1 in the product build, whose kernels carry no counters.
 int epropnp_tuning_phase_cycles(unsigned long long* out, int reset) { return pnp::tuning_phase_cycles(out, reset); }
 int epropnp_tuning_rslm_cycles(unsigned long long* out, int reset) { return pnp::tuning_rslm_phase_cycles(out, reset); }
+int epropnp_tuning_bwd_cycles(unsigned long long* out, int reset) { return pnp::tuning_bwd_phase_cycles(out, reset); }
 
 }  // extern "C"
