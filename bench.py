@@ -368,7 +368,11 @@ def main(argv=None, device=None, backend='nccl'):
             init = RSLMSolver(dof=6, num_points=caller['rslm'][0], num_proposals=caller['rslm'][1], num_iter=caller['rslm'][2])
             pose_target = prob['pose_gt']                   # pose_init = the ground truth, force_init_solve=True
         layer = EProPnP6DoF(mc_samples=S, num_iter=K, solver=LMSolver(dof=6, num_iter=L, init_solver=init), seed=1 + rank)
-        loss_mod, force_init, with_plus = None, init is not None, caller['plus']
+        # lib/train.py:182-183: the 6-DoF repo's loss MODULE with `scale.detach().mean()` as its norm_factor input (the notebook,
+        # C1, defines its own loss class in cell 8 -- plain PyTorch statements -- and keeps the functional form below)
+        loss_mod = MonteCarloPoseLoss(momentum=0.01).to(dev) if args.config in ('C3', 'C3-train') else None
+        scale_net = torch.full((B, 2), 2.0, device=dev)               # stand-in for the network's `scale` output
+        force_init, with_plus = init is not None, caller['plus']
     elif args.config == 'C4':
         camera = PerspectiveCamera(z_min=0.1, allowed_border=200)
         camera.set_param(prob['cam_mats'], img_shape=torch.tensor([[480., 640.]], device=dev).expand(B, 2))
@@ -377,6 +381,7 @@ def main(argv=None, device=None, backend='nccl'):
                             solver=LMSolver(dof=4, num_iter=L, init_solver=init))
         loss_mod = MonteCarloPoseLoss(momentum=0.01).to(dev)           # training mode: world-mean of norm_factor
         obj_weight = torch.ones(B, device=dev)                         # `sample_weights` of the Det head
+        scale_det = torch.full((B, 2), 2.0, device=dev)                # its `scale` (n_obj, 2): the weight scale the head predicts
         force_init = True
     else:
         camera = PerspectiveCamera(cam_mats=prob['cam_mats'], z_min=0.1)
@@ -393,11 +398,10 @@ def main(argv=None, device=None, backend='nccl'):
     nf_scale = 1.0 / max(2 * B, 1)
 
     def norm_factor_input():
-        # the Det head's norm_factor input (mean weight scale).  Summed per object first: a (600 x 256) -> () torch.sum is a
-        # multi-block reduction whose semaphores are reset by a hipMemsetAsync, and a captured memset NODE of this ROCm stack
-        # writes garbage once eager launches have run between two replays (tools/ubench/graph_memset_node.py; the r03 C4
-        # line's loss of 17.7 against 1.79 eager was this).  Row sums + one single-block sum need no memset.
-        return w2d.detach().sum(dim=(1, 2)).sum() * nf_scale
+        # the Det head's norm_factor input, deform_pnp_head.py:870, as the head writes it (three ATen launches).  The timed step
+        # hands `scale` and `sample_weights` to the exchange instead, whose pack launch evaluates the same expression
+        # (sharding.ObjectExchange.start); this eager form is what `replayed_step_check` compares the replayed value with.
+        return (scale_det * obj_weight[:, None]).sum() * nf_scale
 
     def step(timed=False):
         for t in (x3d, x2d, w2d):
@@ -406,8 +410,11 @@ def main(argv=None, device=None, backend='nccl'):
         pose_opt, _, plus, _, logw, cost_init = layer.monte_carlo_forward(
             x3d, x2d, w2d, camera, cost_fun, pose_init=pose_target, force_init_solve=force_init,
             **({'with_pose_opt_plus': True} if with_plus else {}))
-        if loss_mod is None:
-            loss = monte_carlo_pose_loss(logw, cost_init).mean()       # Monte-Carlo pose (KL) loss, NaN -> 0
+        if loss_mod is None or caller:
+            if loss_mod is None:
+                loss = monte_carlo_pose_loss(logw, cost_init).mean()   # Monte-Carlo pose (KL) loss, NaN -> 0
+            else:
+                loss = loss_mod(logw, cost_init, scale_net.detach().mean())
             if with_plus:       # derivative regularisation of the callers (lib/train.py:184-193, notebook cell 9)
                 dist_t = (plus[:, :3] - pose_target[:, :3]).norm(dim=-1)
                 loss_t = torch.where(dist_t < 0.05, 0.5 * dist_t.square() / 0.05, dist_t - 0.025).mean()
@@ -422,7 +429,8 @@ def main(argv=None, device=None, backend='nccl'):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        exchange.start(pose_opt, norm_factor_input())
+        # (the head's norm_factor input, deform_pnp_head.py:870, is summed inside the exchange's pack launch: sharding.ObjectExchange.start)
+        exchange.start(pose_opt, sum_of=scale_det, sum_row_weight=obj_weight, sum_scale=nf_scale)
         layer_last_pose['pose_opt'] = pose_opt.detach()
         if timed:
             e1.record()                 # GPU time of the pack kernel + the RCCL kernel in stream order

@@ -79,9 +79,27 @@ struct AmisParams {
   float dispersion;
   unsigned long long seed, offset;
   const unsigned long long* offset_dev;   // optional device-side addend to `offset` (graph replay)
+  unsigned long long* advance;            // optional: counters the last workgroup to retire increments (advance_counters)
+  int* advance_ticket;
+  int advance_count;
   int ablate;          // tuning builds only (-DPNP_TUNING): bit0 skip sweep, bit1 skip proposal refit, bit2 skip densities
   unsigned split_timeout;   // split over workgroups: shader cycles a part waits for a sibling's partial costs (wave_ops.h)
 };
+
+// AmisParams.advance: called once by every workgroup that takes part in the launch (`expected` of them), at its very end.  The last
+// one to arrive increments the caller's counters and returns the ticket to zero; every workgroup read *offset_dev when it started,
+// i.e. before it took its ticket, and the next launch on the stream sees the new values (kernel boundary).  No fences: nothing a
+// workgroup wrote is read by another one here, the ticket is a device-scope atomic, and an agent-scope fence per workgroup --
+// a write-back of the XCD's L2 -- cost the Det forward 13 us of 43 when it was tried (profiles/r05_launch_fusions.txt).
+__device__ __forceinline__ void advance_counters(const AmisParams& a, int expected) {
+  if (a.advance == nullptr) return;
+  if (threadIdx.x == 0) {
+    if (atomicAdd(a.advance_ticket, 1) == expected - 1) {
+      for (int i = 0; i < a.advance_count; ++i) atomicAdd(&a.advance[i], 1ull);
+      atomicExch(a.advance_ticket, 0);
+    }
+  }
+}
 
 // (PNP_FIT_FN, tuning.h: the fp64 proposal fits run on one lane a handful of times per object)
 

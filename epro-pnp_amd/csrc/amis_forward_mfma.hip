@@ -380,6 +380,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   if (proposals != nullptr && part == 0)
     for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
   PNP_PHASE(5);
+  advance_counters(a, p.B * G);       // (every workgroup that passed the `b >= p.B` test above: B objects x G parts)
   PNP_PHASES_FLUSH(6);
 }
 
@@ -484,6 +485,8 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   AmisParams k;
   k.S = S; k.K = K; k.WP = 1; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev; k.ablate = 0;
+  k.advance = (am->advance && am->advance_ticket && am->advance_count > 0) ? (unsigned long long*)am->advance : nullptr;
+  k.advance_ticket = (int*)am->advance_ticket; k.advance_count = am->advance_count;
   k.split_timeout = split_timeout_cycles();
   { int ab[1]; if (tune_ints("ablate", ab, 1)) k.ablate = ab[0]; }
   sh.ahead = 1;
@@ -554,7 +557,8 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       }
       owned = mem;
     }
-    if (launch_fill_u32(mem, 0xffffffffu, xbytes / 4, st) != EPROPNP_OK) {      // (a kernel, not a memset node: pnp_host.h)
+    if (!exchange_prefilled(mem, xbytes) &&
+        launch_fill_u32(mem, 0xffffffffu, xbytes / 4, st) != EPROPNP_OK) {      // (a kernel, not a memset node: pnp_host.h)
       (void)hipGetLastError();
       return fail(EPROPNP_ELAUNCH, "amis_forward: could not fill the split scratch");
     }

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) vo
   }
   if (proposals != nullptr)
     for (int i = tid; i < K * kPropStride; i += T) proposals[(size_t)b * K * kPropStride + i] = prop[i];
+  advance_counters(a, p.B);
 }
 
 // ================================================================================================================
@@ -340,6 +341,8 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   k.split_timeout = 0;
   k.S = S; k.K = K; k.WP = WP; k.eps = am->eps; k.mle_iter = am->acg_mle_iter; k.dispersion = am->acg_dispersion;
   k.seed = am->seed; k.offset = am->offset; k.offset_dev = (const unsigned long long*)am->offset_dev;
+  k.advance = (am->advance && am->advance_ticket && am->advance_count > 0) ? (unsigned long long*)am->advance : nullptr;
+  k.advance_ticket = (int*)am->advance_ticket; k.advance_count = am->advance_count;
   k.ablate = 0;
   { int ab[1]; if (tune_ints("ablate", ab, 1)) k.ablate = ab[0]; }
   // the float4-viewed arrays (ptab rows, wred) come first so that they are 16-B aligned for any S
@@ -359,20 +362,25 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
 // grad_w2d[b, :, :] += (sum over parts of grad_delta[b, part]) * d delta[b] / d w2d  for a Huber threshold that came from
 // AdaptiveHuberPnPCost on this w2d (epropnp_problem.delta_stats): the follow-up launch for the backward variants whose kernel
 // does not know the object's whole grad_delta at its end (object split over workgroups; the all-VALU kernel).
+// (grid: B x ceil(2N / kDeltaPathSpan) workgroups -- one workgroup per object took 10 us for 32 x 4096 points, a launch of 32
+// workgroups on a 256-CU device)
+constexpr int kDeltaPathSpan = 1024;
 __global__ __launch_bounds__(256) void delta_path_kernel(Problem p, const float* __restrict__ gdelta, int nparts,
-                                                          float* __restrict__ gw2d) {
-  const int b = (int)blockIdx.x;
+                                                          float* __restrict__ gw2d, int spans) {
+  const int b = (int)blockIdx.x / spans, sp = (int)blockIdx.x - b * spans;
   float g = 0.f;
   for (int q = 0; q < nparts; ++q) g += gdelta[(size_t)b * nparts + q];
   const float add = (g * p.delta_stats[(size_t)b * 4 + 1]) * (p.delta_relative / (2.0f * (float)p.N));
   float* row = gw2d + (size_t)b * p.N * 2;
-  for (int i = (int)threadIdx.x; i < 2 * p.N; i += (int)blockDim.x) row[i] += add;
+  const int end = min(2 * p.N, (sp + 1) * kDeltaPathSpan);
+  for (int i = sp * kDeltaPathSpan + (int)threadIdx.x; i < end; i += (int)blockDim.x) row[i] += add;
 }
 
 int launch_delta_path(const epropnp_problem* prob, const float* gdelta, int nparts, float* gw2d, hipStream_t st) {
   if (prob->delta_stats == nullptr) return EPROPNP_OK;
   const Problem d = to_device_problem(prob);
-  PNP_LAUNCH(delta_path_kernel, dim3(d.B), dim3(256), 0, st, d, gdelta, nparts, gw2d);
+  const int spans = (2 * d.N + kDeltaPathSpan - 1) / kDeltaPathSpan;
+  PNP_LAUNCH(delta_path_kernel, dim3((unsigned)(d.B * spans)), dim3(256), 0, st, d, gdelta, nparts, gw2d, spans);
   return check_launch("delta_path_kernel");
 }
 

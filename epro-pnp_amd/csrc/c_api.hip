@@ -202,10 +202,18 @@ int epropnp_mc_loss_backward(const float* logweights, const float* lse, const fl
 }
 
 int epropnp_mc_loss_reduce(const float* loss, const float* weight, int32_t num_obj, float scale, float momentum,
-                           const float* norm_factor_in, float* norm_factor, float* out, void* stream) {
+                           const float* norm_factor_in, int32_t norm_factor_in_count, int64_t norm_factor_in_stride,
+                           float* norm_factor, float* out, void* stream) {
   pnp::StageScope prof_("mc_loss_reduce", (hipStream_t)stream);
-  return pnp::launch_mc_loss_reduce(loss, weight, num_obj, scale, momentum, norm_factor_in, norm_factor, out,
-                                    (hipStream_t)stream);
+  return pnp::launch_mc_loss_reduce(loss, weight, num_obj, scale, momentum, norm_factor_in, norm_factor_in_count,
+                                    (long long)norm_factor_in_stride, norm_factor, out, (hipStream_t)stream);
+}
+
+int epropnp_exchange_pack(const float* rows, uint64_t row_floats, const float* scalars, int32_t n_scalars,
+                          const float* sum_src, uint64_t sum_floats, float sum_scale, const float* sum_row_weight,
+                          int32_t sum_row_len, float* send, void* stream) {
+  return pnp::launch_exchange_pack(rows, (size_t)row_floats, scalars, n_scalars, sum_src, (size_t)sum_floats, sum_scale,
+                                   sum_row_weight, sum_row_len, send, (hipStream_t)stream);
 }
 
 int epropnp_mc_loss_reduce_backward(const float* logweights, const float* lse, const float* weight, const float* coef,

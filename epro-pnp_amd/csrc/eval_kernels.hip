@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256) void mc_loss_backward_kernel(const float* __re
 // products, as the reference's mul_ / add_ pair does.
 __global__ __launch_bounds__(1024) void mc_loss_reduce_kernel(const float* __restrict__ loss, const float* __restrict__ weight,
                                                                int B, float scale, float one_minus_m, float m,
-                                                               const float* __restrict__ nf_in, float* __restrict__ nf,
-                                                               float* __restrict__ out) {
+                                                               const float* __restrict__ nf_in, int nf_count, long long nf_stride,
+                                                               float* __restrict__ nf, float* __restrict__ out) {
   __shared__ float red[16];
   float acc = 0.f;
   for (int b = (int)threadIdx.x; b < B; b += (int)blockDim.x) acc += (weight != nullptr) ? loss[b] * weight[b] : loss[b];
@@ -354,7 +354,12 @@ __global__ __launch_bounds__(1024) void mc_loss_reduce_kernel(const float* __res
   if (threadIdx.x == 0) {
     float n = (nf != nullptr) ? nf[0] : 1.0f;
     if (nf != nullptr && nf_in != nullptr) {
-      n = add_unfused(mul_unfused(n, one_minus_m), mul_unfused(m, nf_in[0]));       // the reference's two roundings
+      float in = nf_in[0];
+      if (nf_count > 1) {       // the world mean of the ranks' inputs, read out of the all-gather's receive buffer in rank order
+        for (int r = 1; r < nf_count; ++r) in += nf_in[(size_t)r * (size_t)nf_stride];
+        in /= (float)nf_count;
+      }
+      n = add_unfused(mul_unfused(n, one_minus_m), mul_unfused(m, in));       // the reference's two roundings
       nf[0] = n;
     }
     const float c = scale / n;
@@ -902,14 +907,55 @@ int launch_mc_loss_backward(const float* logw, const float* lse, const float* lo
   return check_launch("mc_loss_backward_kernel");
 }
 
+// ObjectExchange's send buffer in one launch (include/epropnp_hip.h: epropnp_exchange_pack).  Block 0 also produces the scalars:
+// with sum_src the first one is a fixed-order single-workgroup sum (the Det head's norm_factor input).
+__global__ __launch_bounds__(256) void exchange_pack_kernel(const float* __restrict__ rows, size_t row_floats,
+                                                            const float* __restrict__ scalars, int n_scal,
+                                                            const float* __restrict__ sum_src, size_t sum_floats, float sum_scale,
+                                                            const float* __restrict__ row_w, int row_len, float* __restrict__ send) {
+  __shared__ float red[4];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_floats; i += (size_t)gridDim.x * blockDim.x)
+    send[(size_t)n_scal + i] = rows[i];
+  if (blockIdx.x != 0) return;
+  if (sum_src != nullptr) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};       // four independent chains per thread, combined in a fixed order
+    const size_t T = blockDim.x;
+    auto at = [&](size_t j) { return row_w != nullptr ? sum_src[j] * row_w[j / (size_t)row_len] : sum_src[j]; };
+    size_t i = threadIdx.x;
+    for (; i + 3 * T < sum_floats; i += 4 * T) {
+      acc[0] += at(i); acc[1] += at(i + T); acc[2] += at(i + 2 * T); acc[3] += at(i + 3 * T);
+    }
+    for (; i < sum_floats; i += T) acc[0] += at(i);
+    float v[1] = {(acc[0] + acc[1]) + (acc[2] + acc[3])};
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) send[0] = v[0] * sum_scale;
+  }
+  for (int i = (int)threadIdx.x + (sum_src != nullptr ? 1 : 0); i < n_scal; i += (int)blockDim.x) send[i] = scalars[i];
+}
+
+int launch_exchange_pack(const float* rows, size_t row_floats, const float* scalars, int n_scal, const float* sum_src,
+                         size_t sum_floats, float sum_scale, const float* row_w, int row_len, float* send, hipStream_t st) {
+  if (row_w != nullptr && (row_len < 1 || sum_src == nullptr)) return fail(EPROPNP_EINVAL, "exchange_pack: row weights need sum_src and row_len >= 1");
+  if (!send || (row_floats > 0 && !rows) || n_scal < 0) return fail(EPROPNP_EINVAL, "exchange_pack: NULL pointer");
+  if (sum_src != nullptr && n_scal < 1) return fail(EPROPNP_EINVAL, "exchange_pack: a sum needs a scalar slot");
+  if (scalars == nullptr && n_scal > (sum_src != nullptr ? 1 : 0)) return fail(EPROPNP_EINVAL, "exchange_pack: scalars NULL");
+  size_t blocks = (row_floats + 1023) / 1024;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  PNP_LAUNCH(exchange_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, rows, row_floats, scalars, n_scal, sum_src, sum_floats,
+             sum_scale, row_w, row_len, send);
+  return check_launch("exchange_pack_kernel");
+}
+
 int launch_mc_loss_reduce(const float* loss, const float* weight, int B, float scale, float momentum, const float* nf_in,
-                          float* nf, float* out, hipStream_t st) {
+                          int nf_count, long long nf_stride, float* nf, float* out, hipStream_t st) {
   if (B < 0) return fail(EPROPNP_EINVAL, "mc_loss_reduce: negative num_obj");
   if (!out || (B > 0 && !loss)) return fail(EPROPNP_EINVAL, "mc_loss_reduce: NULL pointer");
   if (nf_in != nullptr && nf == nullptr) return fail(EPROPNP_EINVAL, "mc_loss_reduce: norm_factor_in without norm_factor");
+  if (nf_in != nullptr && (nf_count < 1 || (nf_count > 1 && nf_stride < 1))) return fail(EPROPNP_EINVAL, "mc_loss_reduce: bad norm_factor_in count / stride");
   const float one_minus_m = (float)(1.0 - (double)momentum);       // the reference's `1 - self.momentum`, rounded once
   PNP_LAUNCH(mc_loss_reduce_kernel, dim3(1), dim3(B > 4096 ? 1024 : 256), 0, st, loss, weight, B, scale, one_minus_m, momentum,
-             nf_in, nf, out);
+             nf_in, nf_count, nf_stride, nf, out);
   return check_launch("mc_loss_reduce_kernel");
 }
 

@@ -259,7 +259,8 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
     const int per_part = (d.N + G - 1) / G;
     if (G > 1 && split_scratch != nullptr && split_scratch_bytes >= need && per_part <= 1024) {
       const int ppl = per_part > 512 ? 4 : (per_part > 256 ? 2 : 1);
-      if (launch_fill_u32(split_scratch, 0xffffffffu, need / 4, st) != EPROPNP_OK) {      // (a kernel, not a memset node)
+      if (!exchange_prefilled(split_scratch, need) &&
+          launch_fill_u32(split_scratch, 0xffffffffu, need / 4, st) != EPROPNP_OK) {      // (a kernel, not a memset node)
         (void)hipGetLastError();
         return fail(EPROPNP_ELAUNCH, "lm_solve: could not fill the split scratch");
       }

@@ -11,6 +11,16 @@
 
 namespace pnp {
 
+PrefilledRange& prefilled_exchange_range() {
+  static thread_local PrefilledRange r = {nullptr, nullptr};
+  return r;
+}
+namespace {
+struct PrefillScope {      // clears the mark when the host call returns, whichever way
+  ~PrefillScope() { prefilled_exchange_range() = PrefilledRange{nullptr, nullptr}; }
+};
+}  // namespace
+
 // force_init_solve=True with a given pose_init: per object the cheaper of {pose_init, RSLM pose}
 // (levenberg_marquardt.py:124-130: `use_init = cost_init < cost_init_solve`), written over the RSLM pose.
 __global__ __launch_bounds__(256) void select_start_kernel(const float* __restrict__ pose_init,
@@ -47,6 +57,16 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
   epropnp_problem q = *prob;
   const float* pinit = pose_init;
   int rc;
+  // both split kernels' exchange scratch in one contiguous block (LM first): ONE fill launch for the two (32 crops x 4096
+  // points: a launch less in a step of ~12)
+  PrefillScope prefill_scope;
+  if (par->lm_scratch != nullptr && par->amis.split_scratch != nullptr && par->lm_scratch_bytes > 0 && par->amis.split_scratch_bytes > 0 &&
+      (const char*)par->lm_scratch + par->lm_scratch_bytes == (const char*)par->amis.split_scratch &&
+      (par->lm_scratch_bytes % 4) == 0 && (par->amis.split_scratch_bytes % 4) == 0) {
+    const size_t total = (size_t)par->lm_scratch_bytes + (size_t)par->amis.split_scratch_bytes;
+    if ((rc = launch_fill_u32(par->lm_scratch, 0xffffffffu, total / 4, st))) return rc;
+    prefilled_exchange_range() = PrefilledRange{(const char*)par->lm_scratch, (const char*)par->lm_scratch + total};
+  }
   if (par->normalize) {       // pnp_normalize (common.py:103-124)
     {   // centred points and, in the same launch, pose_init in the centred frame
       StageScope ps("center_points", st);
@@ -73,7 +93,7 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
                                 par->init_mode == 2 ? pinit : nullptr, par->init_mode == 2 ? cost_init : nullptr, &selected,
                                 &sel.parts)))
       return rc;
-    if (sel.parts > 1) {      // no reduce launch was made: the LM kernel picks the winner itself
+    if (sel.parts >= 1) {     // no reduce / select launch was made: the LM kernel picks the winner itself
       sel.cand = (const float*)par->rslm_scratch;
       if (par->init_mode == 2) { sel.rival_pose = pinit; sel.rival_cost = cost_init; }
     }

@@ -231,8 +231,20 @@ int launch_mc_loss_forward(const float* logw, const float* ct, int S, int B, flo
 int launch_delta_path(const epropnp_problem* prob, const float* gdelta, int nparts, float* gw2d, hipStream_t st);
 // stream-ordered fill as a kernel (never hipMemsetAsync: eval_kernels.hip, fill_u32_kernel)
 int launch_fill_u32(void* p, unsigned v, size_t words, hipStream_t st);
+// The exchange scratch of the split LM solve and of the split AMIS forward start out as 0xffffffff words ("not yet written").  The
+// one-call forward fills BOTH with one launch when the caller hands them over as one contiguous block (mc_forward.hip) and marks
+// the range here; a launcher whose scratch lies inside the marked range skips its own fill.  Thread-local, valid for the duration
+// of that one host call.
+struct PrefilledRange { const char* lo; const char* hi; };
+PrefilledRange& prefilled_exchange_range();      // mc_forward.hip
+inline bool exchange_prefilled(const void* p, size_t bytes) {
+  const PrefilledRange& r = prefilled_exchange_range();
+  return r.lo != nullptr && (const char*)p >= r.lo && (const char*)p + bytes <= r.hi;
+}
 int launch_mc_loss_reduce(const float* loss, const float* weight, int B, float scale, float momentum, const float* nf_in,
-                          float* nf, float* out, hipStream_t st);
+                          int nf_count, long long nf_stride, float* nf, float* out, hipStream_t st);
+int launch_exchange_pack(const float* rows, size_t row_floats, const float* scalars, int n_scal, const float* sum_src,
+                         size_t sum_floats, float sum_scale, const float* row_w, int row_len, float* send, hipStream_t st);
 int launch_mc_loss_reduce_backward(const float* logw, const float* lse, const float* weight, const float* coef,
                                    const float* gout, int S, int B, float* glogw, float* gct, hipStream_t st);
 int launch_mc_loss_backward(const float* logw, const float* lse, const float* loss, const float* g, int S, int B,

@@ -33,7 +33,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
                                                           const unsigned long long* __restrict__ offset_dev,
                                                           const long long* __restrict__ inds,
                                                           const float* __restrict__ rot, float* __restrict__ pose_out,
-                                                          float* __restrict__ cost_out, int parts, float* __restrict__ cand_out) {
+                                                          float* __restrict__ cost_out, int parts, float* __restrict__ cand_out, int to_cand) {
   constexpr int PL = PoseLen<DOF>::value;
   constexpr int NV = NormalEq<DOF>::NV;
   // parts > 1: the proposals of an object are dealt to `parts` workgroups (v = b * parts + part), each keeps the best of its
@@ -272,7 +272,7 @@ Problem p, LmParams lm, int P, int n_pts, unsigned long long seed,
       const float cr = cand[r * (PL + 1)];
       if (cr < wc) { wc = cr; w = r; }
     }
-    if (parts > 1) {
+    if (parts > 1 || to_cand) {     // (to_cand: one part, but the consumer -- the LM launch's start selection -- reads the candidate layout)
       float* dst = cand_out + ((size_t)part * p.B + b) * (PL + 1);
       dst[0] = wc;
 #pragma unroll
@@ -327,16 +327,18 @@ unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int P) {
   if (prob == nullptr || prob->num_obj <= 0 || P < 1) return 0;
   const int q = rslm_parts(prob->num_obj, P);
   const int PL = prob->dof == 6 ? 7 : 4;
-  return q > 1 ? sizeof(float) * (unsigned long long)q * prob->num_obj * (PL + 1) : 0;
+  // (one part: the candidate record through which the one-call forward hands the start to the LM launch, which then also takes the
+  // cheaper-of-two selection against pose_init -- no select launch)
+  return sizeof(float) * (unsigned long long)q * prob->num_obj * (PL + 1);
 }
 
 int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, int P, int n_pts, unsigned long long seed,
                       unsigned long long offset, const unsigned long long* offset_dev, const long long* inds, const float* rot,
                       float* pose_out, float* cost_out, void* scratch, unsigned long long scratch_bytes, hipStream_t st,
                       const float* rival_pose, const float* rival_cost, bool* rival_taken, int* deferred_parts) {
-  // deferred_parts != nullptr: when the proposals are dealt to several workgroups per object the reduce launch is LEFT OUT and
-  // *deferred_parts = parts (> 1) tells the caller to hand `scratch` to the LM launch as its start selection (lm_core.h:
-  // StartSelect); pose_out / cost_out are then not written.  *deferred_parts = 0: pose_out holds the start as usual.
+  // deferred_parts != nullptr (and a scratch that holds the candidates): the reduce launch is LEFT OUT and *deferred_parts = parts
+  // (>= 1) tells the caller to hand `scratch` to the LM launch as its start selection (lm_core.h: StartSelect); pose_out / cost_out
+  // are then not written.  *deferred_parts = 0: pose_out holds the start as usual.
   if (deferred_parts) *deferred_parts = 0;
   if (rival_taken) *rival_taken = false;
   if (int rc = check_problem(prob)) return rc;
@@ -359,13 +361,14 @@ int launch_rslm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, 
   int parts = rslm_parts(d.B, P);
   const int PLh = prob->dof == 6 ? 7 : 4;
   if (parts > 1 && (scratch == nullptr || scratch_bytes < sizeof(float) * (size_t)parts * d.B * (PLh + 1))) parts = 1;
+  const bool to_cand = deferred_parts != nullptr && scratch != nullptr && scratch_bytes >= sizeof(float) * (size_t)parts * d.B * (PLh + 1);
   const dim3 grid(padded_object_grid(d.B * parts)), block(256);
   dispatch_dof_bounds(prob->dof, has_bounds(prob), [&](auto DOF, auto BND) -> int {
     PNP_LAUNCH((rslm_solve_kernel<decltype(DOF)::value, decltype(BND)::value>), grid, block, smem, st, d, k, P, n_pts, seed,
-               offset, offset_dev, inds, rot, pose_out, cost_out, parts, (float*)scratch);
+               offset, offset_dev, inds, rot, pose_out, cost_out, parts, (float*)scratch, (int)to_cand);
     return 0;
   });
-  if (parts > 1 && deferred_parts != nullptr) {
+  if (to_cand) {
     *deferred_parts = parts;
     if (rival_taken) *rival_taken = rival_pose != nullptr && rival_cost != nullptr;
     return check_launch("rslm_solve_kernel");

@@ -116,7 +116,14 @@ struct McPoseLossReduced : public torch::autograd::Function<McPoseLossReduced> {
     Tensor loss = torch::empty({B}, lw.options()), lse = torch::empty({B}, lw.options()), out = torch::empty({2}, lw.options());
     check(epropnp_mc_loss_forward(fptr(lw), fptr(ct), (int32_t)S, (int32_t)B, fptr(loss), fptr(lse), (void*)stream),
           "epropnp_mc_loss_forward");
-    check(epropnp_mc_loss_reduce(fptr(loss), fptr(w), (int32_t)B, (float)scale, (float)momentum, fptr(nf_in),
+    // nf_in: a scalar, or the (ranks,) STRIDED view of the exchange's receive buffer whose mean the kernel takes itself
+    int32_t nf_count = 1;
+    int64_t nf_stride = 1;
+    if (nf_in.has_value() && nf_in->defined() && nf_in->dim() == 1 && nf_in->numel() > 1) {
+      nf_count = (int32_t)nf_in->numel();
+      nf_stride = nf_in->stride(0);
+    }
+    check(epropnp_mc_loss_reduce(fptr(loss), fptr(w), (int32_t)B, (float)scale, (float)momentum, fptr(nf_in), nf_count, nf_stride,
                                  fptr(norm_factor), fptr(out), (void*)stream), "epropnp_mc_loss_reduce");
     ctx->save_for_backward({lw, lse, out, w});
     ctx->saved_data["stream"] = stream;
@@ -172,7 +179,9 @@ int backward_launch(const epropnp_problem& q, const Tensor& samples, const Tenso
     Tensor parts = torch::empty({B, nsplit}, samples.options());
     const int rc = epropnp_amis_backward_split(&q, fptr(samples), fptr(glw), (int32_t)S, fptr(pin), fptr(gin), (int32_t)nsplit,
                                                fptr(gx3d), fptr(gx2d), fptr(gw2d), fptr(parts), (void*)stream);
-    gdel = parts.sum(1);
+    // (the per-workgroup partials are only added up for a caller that wants d/d delta: with the threshold's gradient folded into
+    // grad_w2d -- q.delta_stats -- nobody does, and the sum would be one more launch of a launch-bound step)
+    if (q.delta_stats == nullptr) gdel = parts.sum(1);
     return rc;
   }
   gdel = torch::empty({B}, samples.options());

@@ -49,7 +49,8 @@ class AmisParams(C.Structure):
     _fields_ = [('mc_samples', C.c_int32), ('num_iter', C.c_int32), ('eps', C.c_float),
                 ('acg_mle_iter', C.c_int32), ('acg_dispersion', C.c_float), ('seed', C.c_uint64),
                 ('offset', C.c_uint64), ('offset_dev', C.c_void_p), ('split_scratch', C.c_void_p),
-                ('split_scratch_bytes', C.c_uint64)]
+                ('split_scratch_bytes', C.c_uint64), ('advance', C.c_void_p), ('advance_ticket', C.c_void_p),
+                ('advance_count', C.c_int32)]
 
 
 class McParams(C.Structure):
@@ -60,7 +61,7 @@ class McParams(C.Structure):
                 ('rslm_scratch_bytes', C.c_uint64), ('lm_scratch', C.c_void_p), ('lm_scratch_bytes', C.c_uint64)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 
@@ -105,7 +106,8 @@ def _declare(lib):
     lib.epropnp_adaptive_delta.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp]
     lib.epropnp_mc_loss_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.epropnp_mc_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
-    lib.epropnp_mc_loss_reduce.argtypes = [vp, vp, i32, C.c_float, C.c_float, vp, vp, vp, vp]
+    lib.epropnp_mc_loss_reduce.argtypes = [vp, vp, i32, C.c_float, C.c_float, vp, i32, C.c_int64, vp, vp, vp]
+    lib.epropnp_exchange_pack.argtypes = [vp, C.c_uint64, vp, i32, vp, C.c_uint64, C.c_float, vp, i32, vp, vp]
     lib.epropnp_mc_loss_reduce_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     for name in ('evaluate_cost', 'normal_equations', 'lm_solve', 'amis_forward', 'amis_backward', 'adaptive_delta',
                  'mc_loss_forward', 'mc_loss_backward', 'rslm_draw', 'gn_step_forward', 'gn_step_backward', 'rslm_solve', 'center_points', 'shift_poses', 'prepare_forward', 'prepare_backward', 'pose_opt_plus_forward', 'pose_opt_plus_backward', 'shift_poses_backward', 'prepare_dense_forward',
@@ -125,7 +127,7 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split',
            'epropnp_monte_carlo_forward', 'epropnp_cost_pose_cam_grad', 'epropnp_async_status',
            'epropnp_async_status_word', 'epropnp_amis_forward_split_bytes', 'epropnp_rslm_solve_scratch_bytes',
-           'epropnp_lm_solve_split_bytes', 'epropnp_mc_loss_reduce', 'epropnp_mc_loss_reduce_backward')
+           'epropnp_lm_solve_split_bytes', 'epropnp_mc_loss_reduce', 'epropnp_mc_loss_reduce_backward', 'epropnp_exchange_pack')
 
 
 def lib():

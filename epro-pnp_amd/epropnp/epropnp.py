@@ -78,13 +78,14 @@ class EProPnPBase(torch.nn.Module):
             self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         # [the sampler's call counter, the RSLM initialiser's]: one tensor, so that a forward that advances both does it with
         # ONE in-stream add (each tiny launch is ~2.5 us of a replayed Det step)
-        self._rng_pair = torch.full((2,), 0, dtype=torch.int64, device=device)
+        # (third word: the ticket with which the sampler's launch advances the counters itself -- epropnp_amis_params.advance)
+        self._rng_pair = torch.full((3,), 0, dtype=torch.int64, device=device)
         self.rng_counter = self._rng_pair[:1]
         init = getattr(self.solver, 'init_solver', None)
         if init is not None and hasattr(init, 'num_proposals'):
             if not hasattr(init, '_draw_seed'):
                 init._draw_seed, init._draw_calls = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
-            init.rng_counter = self._rng_pair[1:]       # its own call counter
+            init.rng_counter = self._rng_pair[1:2]      # its own call counter
         return self
 
     # Extension hooks of the reference (epropnp.py:64-82).  monte_carlo_forward runs the fused sampler and does not call
@@ -239,10 +240,15 @@ class EProPnPBase(torch.nn.Module):
         cfg = self._amis_config(noise)
         par = _hip.McParams()
         par.lm = hip._lm_struct(sv, fast_mode)
-        lm_scratch = hip.lm_split_scratch(prob, par.lm)
-        par.lm_scratch, par.lm_scratch_bytes = _hip.ptr(lm_scratch), 0 if lm_scratch is None else lm_scratch.numel() * 4
-        par.amis, split_scratch = hip._amis_struct(prob, cfg['mc_samples'], cfg['num_iter'], cfg['eps'], cfg['acg_mle_iter'],
-                                                   cfg['acg_dispersion'], cfg['seed'], cfg['offset'], cfg.get('offset_dev'))
+        # exchange scratch of the split LM solve and of the split forward as ONE block (LM first): the library then fills both
+        # with one launch (csrc/mc_forward.hip)
+        lm_words, fw_words = hip.split_scratch_words(prob, par.lm, cfg['mc_samples'], cfg['num_iter'])
+        block = prob.new(lm_words + fw_words) if lm_words + fw_words else None
+        lm_scratch = block[:lm_words] if lm_words else None
+        split_scratch = block[lm_words:] if fw_words else None
+        par.lm_scratch, par.lm_scratch_bytes = _hip.ptr(lm_scratch), lm_words * 4
+        par.amis, _ = hip._amis_struct(prob, cfg['mc_samples'], cfg['num_iter'], cfg['eps'], cfg['acg_mle_iter'],
+                                       cfg['acg_dispersion'], cfg['seed'], cfg['offset'], cfg.get('offset_dev'), scratch=split_scratch)
         par.normalize = int(bool(self.normalize))
         par.init_mode = 1 if pose_init is None else (2 if force_init_solve else 0)
         keep = (split_scratch, lm_scratch)
@@ -278,15 +284,22 @@ class EProPnPBase(torch.nn.Module):
                 and os.environ.get('EPROPNP_DELTA_FOLD', '1') != '0' and src[0]() is delta and src[1]() is w2d and not src[4]:
             fold = (src[2], src[3])
             prob.fold_delta(*fold)          # (every backward built on `prob`, pose_opt_plus below included)
-        pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
-            x3d, x2d, w2d, None if fold else delta, prob, pose_init, par, noise, bool(with_cost))
-        del keep
+        # Device-side call counters (enable_graph_safe_rng) are advanced by the sampler's own launch when its last workgroup
+        # retires (epropnp_amis_params.advance): no add kernel in the step.  Counters that do not sit in the layer's own
+        # [self, initialiser, ticket] triple (an initialiser shared between layers, say) keep the in-stream add.
         bump_init = bool(par.init_mode and inds is None and counter is not None)
         bump_self = self.rng_counter is not None and noise is None
         pair = getattr(self, '_rng_pair', None)
-        if bump_init and bump_self and pair is not None and counter.data_ptr() == pair[1:].data_ptr():
-            pair.add_(1)                          # both counters, one in-stream add: part of a captured graph
-        else:
+        in_kernel = pair is not None and pair.numel() == 3 and (bump_self or bump_init) \
+            and (not bump_init or counter.data_ptr() == pair[1:2].data_ptr())
+        if in_kernel:
+            first = pair[0:1] if bump_self else pair[1:2]
+            par.amis.advance, par.amis.advance_ticket = _hip.ptr(first), _hip.ptr(pair[2:3])
+            par.amis.advance_count = 2 if (bump_self and bump_init) else 1
+        pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
+            x3d, x2d, w2d, None if fold else delta, prob, pose_init, par, noise, bool(with_cost))
+        del keep
+        if not in_kernel:
             if bump_init:
                 counter.add_(1)
             if bump_self:

@@ -357,9 +357,20 @@ def split_scratch(prob, mc_samples, num_iter):
     return prob.new((nbytes + 3) // 4) if nbytes > 0 else None
 
 
-def _amis_struct(prob, S, K, eps, acg_mle_iter, acg_dispersion, seed, offset, offset_dev):
+def split_scratch_words(prob, lm_par, mc_samples, num_iter):
+    """-> (words of the split LM solve's exchange scratch, words of the split forward's), 0 where the library would not split"""
+    lm_bytes = 0 if prob.B > 128 else int(_hip.lib().epropnp_lm_solve_split_bytes(C.byref(prob.c), C.byref(lm_par)))
+    fw_bytes = 0 if prob.B > 64 else int(_hip.lib().epropnp_amis_forward_split_bytes(C.byref(prob.c), int(mc_samples), int(num_iter)))
+    return (lm_bytes + 3) // 4, (fw_bytes + 3) // 4
+
+
+_NO_SCRATCH = object()
+
+
+def _amis_struct(prob, S, K, eps, acg_mle_iter, acg_dispersion, seed, offset, offset_dev, scratch=_NO_SCRATCH):
     """-> (epropnp_amis_params, the scratch tensor to keep alive until the launch is enqueued)"""
-    scratch = split_scratch(prob, S, K)
+    if scratch is _NO_SCRATCH:
+        scratch = split_scratch(prob, S, K)
     return _hip.AmisParams(int(S), int(K), eps, int(acg_mle_iter), acg_dispersion, int(seed), int(offset), _hip.ptr(offset_dev),
                            _hip.ptr(scratch), 0 if scratch is None else scratch.numel() * 4), scratch
 
@@ -655,8 +666,9 @@ class _McPoseLossReduced(torch.autograd.Function):
         out = torch.empty(2, dtype=torch.float32, device=lw.device)
         st = _hip.stream_of(lw)
         _hip.call('epropnp_mc_loss_forward', _hip.ptr(lw), _hip.ptr(ct), S, B, _hip.ptr(loss), _hip.ptr(lse), st)
+        nf_count, nf_stride = (nf_in.numel(), nf_in.stride(0)) if (nf_in is not None and nf_in.dim() == 1 and nf_in.numel() > 1) else (1, 1)
         _hip.call('epropnp_mc_loss_reduce', _hip.ptr(loss), _hip.ptr(weight), B, float(scale), float(momentum),
-                  _hip.ptr(nf_in), _hip.ptr(norm_factor), _hip.ptr(out), st)
+                  _hip.ptr(nf_in), int(nf_count), int(nf_stride), _hip.ptr(norm_factor), _hip.ptr(out), st)
         ctx.save_for_backward(lw, lse, out)
         ctx.weight = weight
         return out[0]
@@ -684,7 +696,15 @@ def mc_pose_loss_reduced(logweights, cost_target, weight=None, scale=1.0, moment
     if cost_target is not None:
         _f32c(cost_target, 'cost_target')
     w = None if weight is None else _f32c(weight, 'weight')
-    nf_in = None if norm_factor_in is None else _f32c(norm_factor_in, 'norm_factor_in')
+    if norm_factor_in is not None and norm_factor_in.dim() == 1 and norm_factor_in.numel() > 1:
+        # one value per rank, strided through the receive buffer of the step's all-gather (sharding.ObjectExchange.scalar_slots):
+        # the reduce kernel averages them itself -- no mean launch, no copy
+        _hip.check_device(norm_factor_in, 'norm_factor_in')
+        if norm_factor_in.dtype != torch.float32:
+            raise TypeError('norm_factor_in must be float32')
+        nf_in = norm_factor_in
+    else:
+        nf_in = None if norm_factor_in is None else _f32c(norm_factor_in, 'norm_factor_in')
     if norm_factor is not None and (norm_factor.dtype != torch.float32 or not norm_factor.is_contiguous()
                                     or norm_factor.device != logweights.device):
         raise ValueError('norm_factor must be a contiguous float32 scalar on the device of the log-weights')
@@ -693,6 +713,29 @@ def mc_pose_loss_reduced(logweights, cost_target, weight=None, scale=1.0, moment
         return ext.mc_pose_loss_reduced(logweights, cost_target, w, float(scale), float(momentum), nf_in, norm_factor,
                                         int(_hip.stream_of(logweights) or 0))
     return _McPoseLossReduced.apply(logweights, cost_target, w, scale, momentum, nf_in, norm_factor)
+
+
+def exchange_pack(send, rows, scalars=None, sum_of=None, sum_scale=1.0, sum_row_weight=None):
+    """send[:n_scalars] = scalars, send[n_scalars : n_scalars + rows.numel()] = rows.flatten() in ONE launch
+    (epropnp_exchange_pack).  With `sum_of` the first scalar is `sum_scale * sum_of.sum()`, computed inside the same launch (fixed
+    order: bit-reproducible) -- `scalars` then only supplies the others, if any.  All tensors fp32 on one HIP device."""
+    rows = _f32c(rows, 'rows')
+    n_scal = 0 if scalars is None else int(scalars.numel())
+    row_len = 1
+    if sum_of is not None:
+        sum_of = _f32c(sum_of, 'sum_of')
+        n_scal = max(n_scal, 1)
+        if sum_row_weight is not None:        # sum_of (rows, ...) with one weight per row
+            sum_row_weight = _f32c(sum_row_weight, 'sum_row_weight')
+            assert sum_row_weight.dim() == 1 and sum_of.shape[0] == sum_row_weight.shape[0]
+            row_len = max(1, sum_of.numel() // max(1, sum_of.shape[0]))
+    if scalars is not None:
+        scalars = _f32c(scalars.reshape(-1), 'scalars')
+    assert send.is_contiguous() and send.dtype == torch.float32 and send.numel() >= n_scal + rows.numel()
+    _hip.call('epropnp_exchange_pack', _hip.ptr(rows), int(rows.numel()), _hip.ptr(scalars), n_scal, _hip.ptr(sum_of),
+              0 if sum_of is None else int(sum_of.numel()), float(sum_scale),
+              _hip.ptr(sum_row_weight) if sum_of is not None else None, int(row_len), _hip.ptr(send), _hip.stream_of(rows))
+    return send
 
 
 def rslm_draw(w2d, num_proposals, num_points, seed, offset):

@@ -43,21 +43,25 @@ class MonteCarloPoseLoss(nn.Module):
                 reduction_override=None):
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
-        nf = None
+        nf = slots = None
+        scale = self._fused_scale(pose_sample_logweights, cost_target, weight, avg_factor, reduction)
         if self.training:
             with torch.no_grad():
                 if hasattr(norm_factor, 'world_mean'):      # sharding.ObjectExchange: the scalar rode in the step's ONE
-                    nf = norm_factor.world_mean().to(self.norm_factor.device)       # collective (no all-reduce here)
+                    if scale is not None and hasattr(norm_factor, 'scalar_slots'):      # collective (no all-reduce here), and the
+                        slots = norm_factor.scalar_slots()                               # fused reduce averages the ranks itself
+                        nf = slots if slots.numel() > 1 else slots.reshape(1)
+                    else:
+                        nf = norm_factor.world_mean().to(self.norm_factor.device)
                 else:
                     nf = _world_mean(torch.as_tensor(norm_factor, dtype=torch.float, device=self.norm_factor.device))
-        scale = self._fused_scale(pose_sample_logweights, cost_target, weight, avg_factor, reduction)
         if scale is not None:
             # the reduced loss as THREE launches (per-object loss, reduce + running estimate + scaling, backward) instead of the
             # ~15 elementwise / reduce launches of the statement below -- a quarter of the Det step when it is replayed from a
             # hipGraph (profiles/r03_det_loss_fused.txt); same value to rounding
             from .functional import mc_pose_loss_reduced
             return mc_pose_loss_reduced(pose_sample_logweights, cost_target, weight, scale, self.momentum,
-                                        None if nf is None else nf.reshape(1), self.norm_factor)
+                                        None if nf is None else (nf if slots is not None else nf.reshape(1)), self.norm_factor)
         if nf is not None:
             with torch.no_grad():
                 self.norm_factor.mul_(1 - self.momentum).add_(self.momentum * nf)

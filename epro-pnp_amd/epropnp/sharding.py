@@ -197,15 +197,36 @@ class ObjectExchange:
     def _active(self):
         return dist.is_initialized() and (self._world() > 1 or self.force) and not self.disabled
 
-    def start(self, local, scalars=None):
-        """local (n_local, ...) per-object outputs of this rank's shard; scalars: tensor / float / sequence of them."""
+    def start(self, local, scalars=None, sum_of=None, sum_scale=1.0, sum_row_weight=None):
+        """local (n_local, ...) per-object outputs of this rank's shard; scalars: tensor / float / sequence of them.
+        sum_of / sum_scale (HIP tensors): the FIRST scalar is `sum_scale * sum_of.sum()`, evaluated inside the pack launch -- the
+        detection head's norm_factor input `(scale * sample_weights[:, None]).sum() / max(2 n, 1)` (deform_pnp_head.py:870) as
+        `sum_of=scale, sum_row_weight=sample_weights, sum_scale=1 / max(2 n, 1)`, without its three ATen launches."""
         world = self._world()
         local = local.detach()
         scal = None
         if scalars is not None:
             scal = torch.as_tensor(scalars, dtype=local.dtype, device=local.device).detach().reshape(-1)
+        from . import _hip
+        fused_pack = local.dtype == torch.float32 and _hip.on_hip_path(local) and (sum_of is None or _hip.on_hip_path(sum_of))
+        if sum_of is not None and not self._active():
+            if fused_pack:          # no collective, but still one launch for the scalar (same arithmetic as with one)
+                from . import functional as F
+                n = max(1, 0 if scal is None else scal.numel())
+                if getattr(self, '_solo', None) is None or self._solo.numel() != n or self._solo.device != local.device:
+                    self._solo = local.new_empty(n)
+                F.exchange_pack(self._solo, local[:0], scal, sum_of.detach(), sum_scale, sum_row_weight)
+                scal = self._solo
+            else:
+                first = (self._weighted(sum_of, sum_row_weight).sum() * sum_scale).reshape(1).to(local.dtype)
+                scal = first if scal is None else torch.cat((first, scal[1:]))
+            sum_of = None
+        elif sum_of is not None and not fused_pack:
+            first = (self._weighted(sum_of, sum_row_weight).sum() * sum_scale).reshape(1).to(local.dtype)
+            scal = first if scal is None else torch.cat((first, scal[1:]))
+            sum_of = None
         self._local, self._scal = local, scal
-        self._n_scal = 0 if scal is None else scal.numel()
+        self._n_scal = (0 if scal is None else scal.numel()) if sum_of is None else max(1, 0 if scal is None else scal.numel())
         if not self._active():
             return self
         chunk = (self.num_obj + world - 1) // world
@@ -217,8 +238,12 @@ class ObjectExchange:
             self._recv = local.new_empty(world * (self._n_scal + chunk * row))
         self._chunk, self._row = chunk, row
         n = local.shape[0] * row
-        parts = ([scal] if scal is not None else []) + [local.reshape(-1)]
-        torch.cat(parts, out=self._send[:self._n_scal + n])                   # one kernel
+        if fused_pack:
+            from . import functional as F
+            F.exchange_pack(self._send, local, scal, None if sum_of is None else sum_of.detach(), sum_scale, sum_row_weight)     # one kernel
+        else:
+            parts = ([scal] if scal is not None else []) + [local.reshape(-1)]
+            torch.cat(parts, out=self._send[:self._n_scal + n])               # one kernel
         if self.direct and local.is_cuda and self._comm is None:
             try:
                 self._comm = RcclComm(self.group)
@@ -234,6 +259,11 @@ class ObjectExchange:
             self.route = f'torch.distributed.all_gather_into_tensor ({dist.get_backend(self.group)})'
         return self
 
+    @staticmethod
+    def _weighted(sum_of, row_weight):
+        t = sum_of.detach()
+        return t if row_weight is None else t * row_weight.detach().reshape((-1,) + (1,) * (t.dim() - 1))
+
     def close(self):
         """Destroy the direct RCCL communicator, if one was set up (idempotent; the exchange falls back to creating a new one
         on the next start())."""
@@ -241,10 +271,18 @@ class ObjectExchange:
             self._comm.close()
             self._comm = None
 
+    def scalar_slots(self):
+        """The FIRST scalar of every rank as a strided (ranks,) view of the receive buffer -- what MonteCarloPoseLoss hands to the
+        fused reduce kernel, which averages the ranks itself (no mean launch); the local scalar when no collective ran."""
+        assert self._n_scal >= 1, 'start() was called without scalars'
+        if not self._active():
+            return self._scal[:1]
+        return self._recv.view(self._world(), -1)[:, 0]
+
     def world_mean(self):
         """Mean over ranks of the scalars handed to start(): shape (n_scalars,), or () for a single scalar (a view of the
         receive buffer: valid until the next start())."""
-        assert self._scal is not None, 'start() was called without scalars'
+        assert self._n_scal >= 1, 'start() was called without scalars'
         if not self._active():
             return self._scal.reshape(()) if self._n_scal == 1 else self._scal
         m = self._recv.view(self._world(), -1)[:, :self._n_scal].mean(0)

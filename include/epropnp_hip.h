@@ -28,7 +28,7 @@ extern "C" {
 #define EPROPNP_ELAUNCH (-2)  /* HIP launch/runtime error                                         */
 #define EPROPNP_ENODEV (-3)   /* no HIP device / not a gfx950 code object                         */
 
-#define EPROPNP_ABI_VERSION 5
+#define EPROPNP_ABI_VERSION 6
 
 /* Correspondences + camera + robust-cost parameters of one batch of objects.
  * Mirrors the state of PerspectiveCamera (epropnp/camera.py:35-62) and HuberPnPCost.delta
@@ -105,6 +105,13 @@ typedef struct epropnp_amis_params {
                                  takes the split only if the buffer holds epropnp_amis_forward_split_bytes() bytes.  The
                                  library fills it on the stream before the launch; contents are undefined afterwards.     */
   uint64_t split_scratch_bytes;
+  uint64_t* advance;          /* optional (NULL: none): `advance_count` consecutive DEVICE uint64 counters that the launch increments
+                                 by one when its LAST workgroup retires -- every workgroup has read `offset_dev` long before.  With
+                                 `offset_dev` (and epropnp_mc_params.rslm_offset_dev) among them a captured step advances its Philox
+                                 counters inside the sampler's own launch: no add kernel per step (round 5; ~2.5 us of a replayed
+                                 step, ~8 us of an eager one).  Needs `advance_ticket`.                                          */
+  int32_t* advance_ticket;    /* DEVICE int32, zero before the first launch; the library returns it to zero                     */
+  int32_t advance_count;
 } epropnp_amis_params;
 
 /* Bytes of `split_scratch` with which epropnp_amis_forward would split the objects of this problem over workgroups
@@ -273,9 +280,25 @@ int epropnp_mc_loss_backward(const float* logweights, const float* lse, const fl
  *   norm_factor[0] <- (1 - momentum) * norm_factor[0] + momentum * norm_factor_in[0]     if norm_factor_in != NULL (training)
  *   out[0] = (sum_b weight[b] * loss[b]) * scale / norm_factor[0],    out[1] = scale / norm_factor[0]  (for the backward)
  * scale = loss_weight / num_obj ('mean'), loss_weight ('sum') or loss_weight / avg_factor.  weight (B,) or NULL (ones),
- * norm_factor (1,) device scalar or NULL (1.0), out (2,).  Fixed summation order: bit-reproducible. */
+ * norm_factor (1,) device scalar or NULL (1.0), out (2,).  Fixed summation order: bit-reproducible.
+ *   norm_factor_in: `norm_factor_in_count` values `norm_factor_in_stride` floats apart, averaged in index order -- the
+ *   world mean of mmdet's reduce_mean read straight out of the receive buffer of the step's one all-gather (count = ranks,
+ *   stride = floats per rank; sharding.ObjectExchange); count 1 for a plain scalar. */
 int epropnp_mc_loss_reduce(const float* loss, const float* weight, int32_t num_obj, float scale, float momentum,
-                           const float* norm_factor_in, float* norm_factor, float* out, void* stream);
+                           const float* norm_factor_in, int32_t norm_factor_in_count, int64_t norm_factor_in_stride,
+                           float* norm_factor, float* out, void* stream);
+
+/* Send buffer of the Det step's one collective (sharding.ObjectExchange), packed by ONE launch:
+ *   send[0 .. n_scalars)            = scalars[i]                       (or, with sum_src != NULL, send[0] = sum_scale * sum(sum_src[0 .. sum_floats)),
+ *                                                                      a fixed-order sum -- the detection head's norm_factor input,
+ *                                                                      deform_pnp_head.py:870 -- and scalars[i] for i >= 1)
+ *   send[n_scalars .. + row_floats) = rows                             (this rank's per-object outputs, flattened)
+ * scalars may be NULL when n_scalars == 0 or (n_scalars == 1 and sum_src != NULL).
+ * sum_row_weight (or NULL): sum_src is a (rows, sum_row_len) array and element [i, c] counts sum_row_weight[i] times -- the head's
+ * `(scale * sample_weights[:, None]).sum() / max(2 n, 1)` in one go. */
+int epropnp_exchange_pack(const float* rows, uint64_t row_floats, const float* scalars, int32_t n_scalars,
+                          const float* sum_src, uint64_t sum_floats, float sum_scale, const float* sum_row_weight,
+                          int32_t sum_row_len, float* send, void* stream);
 /* Its backward through epropnp_mc_loss_forward: with g_b = grad_out[0] * coef[0] * weight[b] (coef = out + 1 of the forward),
  *   grad_logweights[j,b] = g_b * exp(logweights[j,b] - lse[b]),  grad_cost_target[b] = g_b (or NULL)   (0 where the loss was NaN).
  * grad_out and coef are device scalars: nothing is read back, the node is capturable. */

@@ -210,6 +210,9 @@ inline void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> bod
 inline void __syncthreads() { emu::syncthreads(); }
 inline float atomicAdd(float* p, float v) { return emu::atomic_add(p, v); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
+inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }
+inline void __threadfence() {}
 inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }        // one fiber at a time: plain RMW
 inline int atomicMin(int* p, int v) { const int o = *p; *p = v < o ? v : o; return o; }
 

@@ -38,7 +38,7 @@ def test_exports_match_header(lib):
 
 
 def test_abi_version_and_noise_stride(lib):
-    assert lib.epropnp_abi_version() == 5
+    assert lib.epropnp_abi_version() == 6
     assert lib.epropnp_noise_stride(6) == 8 and lib.epropnp_noise_stride(4) == 52 and lib.epropnp_noise_stride(5) == -1
 
 
@@ -113,7 +113,7 @@ def test_c_program_links_and_runs(tmp_path, lib):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
-    assert out.stdout.split() == ['5', '8', '52']
+    assert out.stdout.split() == ['6', '8', '52']
 
 
 def _build_standalone(tmp_path):
