@@ -394,7 +394,10 @@ def main(argv=None, device=None, backend='nccl'):
     coll_events = []
     gathered, layer_last_pose = {}, {}
     # C4: the step's ONE collective (pose outputs + the loss's norm_factor scalar in one payload, sharding.ObjectExchange)
-    exchange = sharding.ObjectExchange(total, force_collective=dist is not None, direct=args.route == 'direct') if strong else None
+    # (BENCH_RCCL_LIB: test hook -- the RCCL library the direct route binds; tests/test_distributed.py runs this step with 8 ranks on
+    # the shared-memory stub of tests/stubs/rccl_stub.c, where no 8-GPU node is at hand)
+    exchange = sharding.ObjectExchange(total, force_collective=dist is not None, direct=args.route == 'direct',
+                                       rccl_lib=os.environ.get('BENCH_RCCL_LIB') or None) if strong else None
     nf_scale = 1.0 / max(2 * B, 1)
 
     def norm_factor_input():

@@ -150,7 +150,9 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   float* cst = smp + PL * S;          // [S]
   float* mixl = cst + S;              // [S]
   float* lgw = mixl + S;              // [S]
-  float* cpart = SPILL ? pW + 4 * NC : lgw + S;                              // [WPs][s16]
+  // (the sampler arrays hold (PL + 3) S floats -- 10 S or 7 S, a multiple of 4 only for even S (6-DoF) / S % 4 == 0 (4-DoF); what
+  // follows them is read as float4 (cpart rows, the refit's rred): the block is rounded up, here and in the launcher's lds_bytes)
+  float* cpart = SPILL ? pW + 4 * NC : smp + (((PL + 3) * S + 3) & ~3);      // [WPs][s16]
   float* gath = cpart + W * s16;             // [G][s16] (SPLIT) the parts' partial costs of the current iteration
   float* prop = cpart + cpart_rows * s16 + (SPLIT ? 4 : 0);    // [K][kPropStride]  (SPLIT: + the missing-parts word)
   float* red = prop + K * kPropStride;   // [256]
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
     }
   };
   PNP_PHASE(0);
+  unsigned gone_parts = 0u;     // (SPLIT) sibling parts that have timed out once
   for (int it = 0; it < K; ++it) {
     for (int n0 = 0; n0 < (SPILL ? s : 1); n0 += (SPILL ? s16 : 1)) {        // (exactly one pass unless `tiled`)
     const int cnt = min(s16, s - n0), cnt16 = (cnt + 15) & ~15;
@@ -328,16 +331,17 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
       }
       if (tid == 0) *missw = 0u;
       __syncthreads();
-      unsigned miss = 0u;
-      for (int i = tid; i < G * s; i += T) {
+      unsigned miss = 0u;      // parts that timed out in an earlier iteration, or for an earlier slot of this thread, are not waited
+      for (int i = tid; i < G * s; i += T) {      // for again: what is there is taken, the rest recomputed below
         const int q = i / s, m = i - q * s;
         if (q == part) continue;
-        const unsigned v = xwg_poll(slot + q * s16 + m, a.split_timeout);
+        const unsigned v = xwg_poll(slot + q * s16 + m, (((miss | gone_parts) >> q) & 1u) ? 0u : a.split_timeout);
         if (v == kXwgEmpty) miss |= 1u << q; else gath[q * s16 + m] = bits_f32(v);
       }
       if (miss) atomicOr(reinterpret_cast<int*>(missw), (int)miss);
       __syncthreads();
       unsigned todo = *missw;                   // the same in every thread
+      gone_parts |= todo;
       if (todo) {
         if (tid == 0) raise_status(p, EPROPNP_ST_SPLIT_TIMEOUT, b);        // informational: this launch ran slower, not wrong
         for (int q = 0; q < G; ++q) {
@@ -491,7 +495,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   { int ab[1]; if (tune_ints("ablate", ab, 1)) k.ablate = ab[0]; }
   sh.ahead = 1;
   auto lds_bytes = [&](bool spilled) {
-    return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (size_t)(PL + 3) * S) +
+    return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (((size_t)(PL + 3) * S + 3) & ~(size_t)3)) +
                             (size_t)(npt ? (G > 1 ? waves + G : waves) : 1) * sh.s16 + (G > 1 ? 4 : 0) + (size_t)K * kPropStride + 256 +
                             kRefitRedFloats +
                             ((s <= 64 * waves || !sh.ahead) ? 0 : 8 * (size_t)s));      // (s <= lanes: the noise shares the pose table)

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
 #pragma unroll
   for (int i = 0; i < PL; ++i) pose[i] = start[i];
 
+  unsigned gone_parts = 0u;      // (SPLIT) sibling parts that have timed out once: later sweeps do not wait for them again
   // one sweep: normal equations + cost of all points at pose `ps`
   auto sweep = [&](const float* ps, bool clip, float (&acc)[NV]) {
     float R[9], t[3];
@@ -127,13 +128,15 @@ __global__ __launch_bounds__(MAXW == 0 ? 256 : MAXW * 64) void lm_solve_kernel(P
         unsigned miss = 0u;
         for (int q = 0; q < G; ++q) {
           if (q == part) continue;
-          const unsigned u = xwg_poll(slot + q * NV + tid, lm.split_timeout);
+          // (a part that was missing in an earlier sweep is not waited for again: whatever is there is taken, the rest recomputed)
+          const unsigned u = xwg_poll(slot + q * NV + tid, ((gone_parts >> q) & 1u) ? 0u : lm.split_timeout);
           if (u == kXwgEmpty) miss |= 1u << q; else xq[q * NV + tid] = bits_f32(u);
         }
         if (miss) atomicOr(reinterpret_cast<int*>(missw), (int)miss);
       }
       __syncthreads();
       const unsigned todo = *missw;                 // the same in every thread
+      gone_parts |= todo;
       if (todo) {
         if (tid == 0) raise_status(p, EPROPNP_ST_SPLIT_TIMEOUT, b);      // informational: slower, not wrong
         for (int q = 0; q < G; ++q) {

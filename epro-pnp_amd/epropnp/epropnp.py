@@ -160,15 +160,19 @@ class EProPnPBase(torch.nn.Module):
                                                          1.0, 0)[0]
             if cam_grad:        # logweights = -cost(samples) - log mixture: d/d cam_mats through the cost of every sample
                 out[4] = out[4] + hip.pose_cam_grad_term(prob, out[3].detach(), None, camera.cam_mats, -1.0, -1)
-                if kwargs.get('with_pose_opt_plus'):
-                    # the reference's pose_opt_plus (LMSolver.gn_step + pose_add under autograd, levenberg_marquardt.py:70-72,
+                if kwargs.get('with_pose_opt_plus') and out[2] is not None:
+                    # The reference's pose_opt_plus (LMSolver.gn_step + pose_add under autograd, levenberg_marquardt.py:70-72,
                     # 243-265) is differentiable w.r.t. camera.cam_mats as well; the fused Gauss-Newton kernels differentiate
-                    # w.r.t. the correspondences only
-                    import warnings
-                    warnings.warn('EProPnP: camera.cam_mats requires grad and with_pose_opt_plus=True -- pose_opt_plus carries no '
-                                  'gradient to the intrinsics here (cost_init and the log-weights do); compute pose_opt_plus with '
-                                  'solver.pose_add(pose_opt, solver.gn_step(...)) on a pose that requires grad to get the PyTorch '
-                                  'composite', RuntimeWarning, stacklevel=2)
+                    # w.r.t. the correspondences only.  In this rare case (no caller of the reference learns intrinsics) the step
+                    # is recomputed at the detached pose_opt with the PyTorch composite, which autograd differentiates w.r.t.
+                    # the correspondences, delta AND the intrinsics -- it replaces the kernels' pose_opt_plus, same value to rounding.
+                    sv = self.solver
+                    x3d_s, pose_s, transform = x3d, out[0].detach(), None
+                    if self.normalize:
+                        transform, x3d_s, pose_s = pnp_normalize(x3d, pose_s, detach_transformation=True)
+                    step = sv.gn_step(x3d_s, x2d, w2d, pose_s, camera, cost_fun, composite=True)
+                    plus = sv.pose_add(pose_s, step, camera)
+                    out[2] = pnp_denormalize(transform, plus) if self.normalize else plus
             return tuple(out)
         if self._fusable(x3d, x2d, w2d, pose_init, force_init_solve, kwargs):
             return self._fused_forward(x3d, x2d, w2d, camera, cost_fun, pose_init, force_init_solve, noise, **kwargs)

@@ -117,11 +117,15 @@ class LMSolver(nn.Module):
                                 with_cost=with_cost, **self._lm_kwargs())
 
     # ------------------------------------------------------------------------------------------------
-    def gn_step(self, x3d, x2d, w2d, pose, camera, cost_fun):
+    def gn_step(self, x3d, x2d, w2d, pose, camera, cost_fun, composite=False):
         """One differentiable Gauss-Newton step at `pose` (used for the derivative-regularisation loss).
-        On HIP tensors: fused forward / backward kernels (csrc/gn_step_kernel.hip); otherwise the PyTorch composite."""
+        On HIP tensors: fused forward / backward kernels (csrc/gn_step_kernel.hip), differentiable w.r.t. the correspondences and
+        cost_fun.delta; otherwise -- a pose that requires grad, `composite=True`, or camera.cam_mats requiring grad -- the PyTorch
+        composite of the reference (levenberg_marquardt.py:243-253), which autograd differentiates w.r.t. everything."""
         from . import _hip
-        if x2d.dim() == 3 and x2d.size(0) > 0 and not pose.requires_grad and _hip.on_hip_path(x3d, x2d, w2d, pose):
+        cam_grad = isinstance(camera.cam_mats, torch.Tensor) and camera.cam_mats.requires_grad and torch.is_grad_enabled()
+        if x2d.dim() == 3 and x2d.size(0) > 0 and not pose.requires_grad and not composite and not cam_grad \
+                and _hip.on_hip_path(x3d, x2d, w2d, pose):
             prob = hip.problem(x3d, x2d, w2d, camera, cost_fun, self.dof)
             delta = cost_fun.delta if isinstance(cost_fun.delta, torch.Tensor) else None
             return hip.gn_step(x3d, x2d, w2d, delta, prob, pose, self.eps)

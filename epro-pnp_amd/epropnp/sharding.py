@@ -63,24 +63,36 @@ class RcclComm:
     collective is one kernel in stream order between the step's own kernels: no hop, ~10 us of host time, and it is
     recorded by a hipGraph capture of the step like any other launch.
     The unique id is created on group rank 0 and broadcast through the torch group (which also proves the group works);
-    ncclCommInitRank is collective over the group."""
+    ncclCommInitRank is collective over the group.
+    `lib_path`: the shared library to bind instead of the librccl.so next to torch -- any library with RCCL's five entry points
+    (tests/stubs/rccl_stub.c drives this very class with 2 and 8 ranks on CPU tensors, where no multi-GPU node is at hand);
+    `device`: where the agreement tensors live (default: the current HIP device, or the CPU when there is none).
+
+    What the collective agreement covers: a missing library, a failed ncclGetUniqueId, an id that did not arrive, and an
+    ncclCommInitRank that RETURNS an error on some rank -- every rank then raises, none is left behind in a collective.  What
+    it cannot cover: an ncclCommInitRank that never returns on the healthy ranks because a peer died inside it; RCCL's own
+    bootstrap time-out (NCCL_SOCKET / comm-init time-outs) is the only way out of that, as for torch's own communicators."""
 
     _FLOAT32 = 7            # ncclFloat32 (rccl.h)
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, lib_path=None, device=None):
         import ctypes
         import os
         assert dist.is_initialized(), 'RcclComm needs an initialised torch.distributed group'
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self._comm = None
-        dev = torch.device('cuda', torch.cuda.current_device())
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+        dev = torch.device(device)
         # Every step that can fail on SOME ranks only (library not found, bootstrap refused) is followed by an agreement
         # over the torch group -- all_reduce(MIN) of a success flag -- so that either every rank ends up with the
         # communicator or every rank raises: a rank that fell back to c10d on its own while the others sit in
         # ncclCommInitRank / ncclAllGather would hang the job.
         lib = None
-        for cand in (os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'), 'librccl.so', 'librccl.so.1'):
+        cands = (lib_path,) if lib_path else (os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'), 'librccl.so',
+                                              'librccl.so.1')
+        for cand in cands:
             try:
                 lib = ctypes.CDLL(cand)
                 break
@@ -103,6 +115,8 @@ class RcclComm:
         box = torch.tensor(list(uid.internal), dtype=torch.uint8, device=dev)       # zeros on the other ranks
         dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ctypes.memmove(ctypes.byref(uid), bytes(box.cpu().tolist()), 128)
+        # once more BEFORE the collective init: every rank holds an id (an all-zero one means the broadcast did not deliver)
+        self._agree(any(uid.internal), dev, 'the unique id did not arrive')
         comm = ctypes.c_void_p()
         rc = lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank)      # collective over the group
         if rc == 0:
@@ -116,7 +130,16 @@ class RcclComm:
         self.device = dev
         RcclComm._live.add(self)
 
-    _live = set()       # communicators not yet destroyed (ObjectExchange.close / close_all before destroy_process_group)
+    # communicators not yet destroyed (ObjectExchange.close / close_all before destroy_process_group).  Weak references: a
+    # communicator whose owner was dropped without close() is destroyed by __del__ instead of living as long as the process.
+    import weakref as _weakref
+    _live = _weakref.WeakSet()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: modules may be gone
+            pass
 
     def _agree(self, ok, dev, what):
         """Collective: raise on EVERY rank if `ok` is false on ANY rank."""
@@ -133,7 +156,7 @@ class RcclComm:
         """recv (world * n,) <- every rank's send (n,), fp32 contiguous device tensors; on the current stream."""
         assert send.dtype == torch.float32 and recv.dtype == torch.float32 and send.is_contiguous() and recv.is_contiguous()
         assert recv.numel() == self.world * send.numel()
-        stream = torch.cuda.current_stream(send.device).cuda_stream
+        stream = torch.cuda.current_stream(send.device).cuda_stream if send.is_cuda else 0
         self._check(self._lib.ncclAllGather(send.data_ptr(), recv.data_ptr(), send.numel(), self._FLOAT32, self._comm,
                                             stream), 'ncclAllGather')
 
@@ -142,7 +165,7 @@ class RcclComm:
         still alive at interpreter exit is torn down by RCCL's own atexit handlers in an order that can hang or warn with
         several ranks."""
         if getattr(self, '_comm', None) is not None:
-            if torch.cuda.is_available():
+            if torch.cuda.is_available() and self.device.type == 'cuda':
                 torch.cuda.synchronize()            # no collective of ours may still be in flight
             self._lib.ncclCommDestroy(self._comm)
             self._comm = None
@@ -184,9 +207,12 @@ class ObjectExchange:
     before `dist.destroy_process_group()`.
     Without a process group (or with one rank and `force_collective=False`) no collective is issued."""
 
-    def __init__(self, num_obj, group=None, force_collective=False, direct=True):
+    def __init__(self, num_obj, group=None, force_collective=False, direct=True, rccl_lib=None):
+        """rccl_lib: path of the RCCL library for the direct route (default: torch's own librccl.so).  With one given, the
+        direct route is also taken for CPU tensors -- tests/stubs/rccl_stub.c, the multi-rank test of this branch."""
         self.num_obj, self.group, self.force = int(num_obj), group, bool(force_collective)
         self.direct, self._comm, self.route = bool(direct), None, None
+        self._rccl_lib = rccl_lib
         self._key = None
         self._local = self._scal = None
         self.disabled = False       # timing A/B only (bench.py): the step without its exchange
@@ -244,14 +270,15 @@ class ObjectExchange:
         else:
             parts = ([scal] if scal is not None else []) + [local.reshape(-1)]
             torch.cat(parts, out=self._send[:self._n_scal + n])               # one kernel
-        if self.direct and local.is_cuda and self._comm is None:
+        direct_ok = local.is_cuda or self._rccl_lib is not None
+        if self.direct and direct_ok and self._comm is None:
             try:
-                self._comm = RcclComm(self.group)
+                self._comm = RcclComm(self.group, lib_path=self._rccl_lib, device=local.device)
             except Exception as e:         # no librccl / bootstrap refused ON ANY RANK (RcclComm agrees collectively, so
                 import warnings            # every rank lands here together): c10d's route still works, say so once
                 warnings.warn(f'ObjectExchange: direct RCCL communicator unavailable ({e}); using torch.distributed')
                 self.direct = False
-        if self.direct and local.is_cuda:
+        if self.direct and direct_ok:
             self._comm.all_gather(self._recv, self._send)
             self.route = 'rccl ncclAllGather on the current stream'
         else:

@@ -86,7 +86,9 @@ def _mixture_logq(samples, props, dof, K):
 
 @pytest.mark.parametrize('dof,S,K,N', [(6, 64, 4, 96), (4, 64, 4, 96), (6, 60, 3, 70), (6, 200, 2, 130), (4, 100, 1, 33),
                                        (6, 320, 2, 600), (6, 48, 2, 1300), (6, 32, 2, 2300), (6, 32, 2, 512), (4, 32, 2, 2040),
-                                       (6, 32, 2, 800), (6, 40, 2, 2048)])
+                                       (6, 32, 2, 800), (6, 40, 2, 2048),
+                                       # sample counts after which the LDS layout is not a multiple of 4 floats (rred / cpart are read as float4)
+                                       (4, 6, 2, 64), (4, 510, 2, 96), (6, 9, 3, 64), (6, 27, 3, 200)])
 def test_logweights_consistent_with_own_samples(backend, dof, S, K, N):
     """Tight check that does not depend on the (ill-conditioned) proposal fit: recompute cost and proposal mixture
     density with the oracle AT THE KERNEL'S OWN samples and fitted proposals; log-weights must agree to 1e-4."""

@@ -90,19 +90,21 @@ def test_shard_range_covers_everything():
             assert max(e[1] - e[0] for e in edges) - min(e[1] - e[0] for e in edges) <= 1
 
 
-def _bench_worker(rank, world, port, ret):
+def _bench_worker(rank, world, port, ret, config='C4', objects='9', stub=None):
     """bench.py's own main() as one of two gloo ranks: the emulation build is installed HERE, from the outside; bench.py gets
     a CPU device and the gloo backend through its test hook and skips only what needs the GPU (hipGraph, HIP events, roofline)."""
     import contextlib
     import io
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    if stub:
+        os.environ['BENCH_RCCL_LIB'] = stub
     import conftest
     import install as emu
     emu.install(conftest._emu_lib())
     import bench
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        rc = bench.main(['--gpus', str(world), '--config', 'C4', '--objects', '9', '--points', '24', '--samples', '16', '--amis-iters', '2',
+        rc = bench.main(['--gpus', str(world), '--config', config, '--objects', objects, '--points', '24', '--samples', '16', '--amis-iters', '2',
                          '--lm-iters', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-hipgraph'], device='cpu', backend='gloo')
     ret[rank] = (rc, buf.getvalue(), dist.is_initialized())
 
@@ -130,6 +132,36 @@ def test_bench_strong_scaling_step_two_gloo_ranks():
     assert c['bytes_per_rank'] == 9 * 4 * 4 + 4 and c['gathered_equals_local_bitwise'] is True and 'gloo' in c['route']
     chk = c['replayed_step_check']
     assert abs(chk['norm_factor_input_last_step'] - chk['evaluated_eagerly']) <= 1e-5 * abs(chk['evaluated_eagerly'])
+
+
+@pytest.mark.parametrize('config,objects', [('C4', '21'), ('C2', '2'), ('C5', '2')])
+def test_bench_line_with_eight_ranks(tmp_path, config, objects):
+    """`bench.py --gpus 8` as the driver launches it at round end, here with EIGHT gloo ranks on the emulation build: the `ranks` block of
+    the JSON line for N = 8 (group size, all-reduce of ones, eight per-rank step times, max over ranks), weak configs C2 / C5 with
+    disjoint shards and no collective, and the strong Det step C4 -- 21 objects split 3,3,3,3,3,2,2,2 -- with its ONE collective
+    on the DIRECT RCCL route (ncclAllGather of the shared-memory stub through the same ctypes binding as on an 8-GPU node)."""
+    import json
+    import conftest
+    conftest._emu_lib()
+    stub = _build_rccl_stub(tmp_path) if config == 'C4' else None
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bench_worker, args=(8, _free_port(), ret, config, objects, stub), nprocs=8, join=True)
+        ret = dict(ret)
+    assert all(ret[r][0] == 0 and not ret[r][2] for r in range(8)) and all(ret[r][1] == '' for r in range(1, 8))
+    line = json.loads([ln for ln in ret[0][1].splitlines() if ln.startswith('{')][-1])
+    rk = line['ranks']
+    assert line['n_gpus'] == 8 and rk['rccl_world_size'] == 8 and rk['all_reduce_of_ones'] == 8.0 and len(rk['ms_per_step_per_rank']) == 8
+    assert sorted(rk['devices']) == list(range(8)) and line['ms_per_step'] >= rk['ms_per_step_max'] - 1e-3
+    if config == 'C4':
+        assert line['scaling'] == 'strong' and line['config'] == {'name': 'C4', 'objects_per_gpu': 3, 'objects_total': 21}
+        c = line['collective']
+        assert c['route'].startswith('rccl ncclAllGather') and c['gathered_equals_local_bitwise'] is True and c['bytes_per_rank'] == 21 * 4 * 4 + 4
+        chk = c['replayed_step_check']
+        assert abs(chk['norm_factor_input_last_step'] - chk['evaluated_eagerly']) <= 1e-5 * abs(chk['evaluated_eagerly'])
+    else:
+        assert line['scaling'] == 'weak' and 'collective' not in line and line['config']['objects_total'] == 16
+        assert abs(line['value'] - 16 / (line['ms_per_step'] * 1e-3)) <= 0.01 * line['value']       # whole-job aggregate over the 8 ranks
 
 
 def _nccl_worker(rank, world, port, ret):
@@ -274,3 +306,57 @@ def test_bench_multi_gpu_harness(config, form):
         assert line['collective']['gathered_equals_local_bitwise'] is True
     else:
         assert line['scaling'] == 'weak' and 'collective' not in line
+
+
+# ---- the direct-RCCL route of ObjectExchange with MORE THAN ONE rank ------------------------------------------
+# A one-GPU box can only ever run RcclComm with one rank, and gloo takes the c10d branch: the branch an 8-GPU node takes was never
+# reached by a multi-rank test.  tests/stubs/rccl_stub.c exports RCCL's five entry points over a shared-memory segment, and the same
+# ctypes path binds it here: 2 and 8 ranks, an uneven split, the collective agreement when ONE rank's ncclCommInitRank fails, teardown.
+def _build_rccl_stub(tmp):
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(str(tmp), 'librccl_stub.so')
+    subprocess.check_call(['gcc', '-O1', '-shared', '-fPIC', os.path.join(root, 'stubs', 'rccl_stub.c'), '-o', out, '-lrt'])
+    return out
+
+
+def _direct_worker(rank, world, port, stub, num_obj, fail_rank, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RCCL_STUB_TIMEOUT_MS'] = '1500'
+    if fail_rank is not None:
+        os.environ['RCCL_STUB_FAIL_RANK'] = str(fail_rank)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import warnings
+        from epropnp import sharding
+        full = torch.arange(num_obj * 4, dtype=torch.float32).reshape(num_obj, 4) * 0.5 + 1.0
+        lo, hi = sharding.shard_range(num_obj)
+        ex = sharding.ObjectExchange(num_obj, direct=True, rccl_lib=stub)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            ex.start(full[lo:hi].clone(), torch.tensor(float(rank + 1)))
+        ok = torch.equal(ex.objects(), full)                                        # every rank holds the whole batch, in order
+        ok = ok and abs(float(ex.world_mean()) - (world + 1) / 2.0) < 1e-6        # mean of 1 .. world
+        ok = ok and ex.scalar_slots().shape == (world,) and torch.equal(ex.scalar_slots(), torch.arange(1, world + 1, dtype=torch.float32))
+        if fail_rank is None:
+            ok = ok and ex.route.startswith('rccl') and not caught and len(sharding.RcclComm._live) == 1
+            ex.start(full[lo:hi, :2].contiguous())                                  # reuse, another row shape, no scalars
+            ok = ok and torch.equal(ex.objects(), full[:, :2])
+        else:       # ONE rank's init failed: EVERY rank fell back to c10d together (and said so), nobody hangs
+            ok = ok and ex.route.startswith('torch.distributed') and len(caught) == 1 and 'direct RCCL communicator unavailable' in str(caught[0].message)
+            ok = ok and ex._comm is None and len(sharding.RcclComm._live) == 0
+        ex.close()
+        ok = ok and ex._comm is None and len(sharding.RcclComm._live) == 0           # ncclCommDestroy on every rank
+        ret[rank] = bool(ok)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,num_obj,fail_rank', [(2, 5, None), (8, 600, None), (8, 601, None), (2, 7, 1), (8, 600, 3)])
+def test_direct_rccl_route_with_several_ranks(tmp_path, world, num_obj, fail_rank):
+    stub = _build_rccl_stub(tmp_path)
+    ret = mp.Manager().dict()
+    mp.spawn(_direct_worker, args=(world, _free_port(), stub, num_obj, fail_rank, ret), nprocs=world, join=True)
+    assert [ret.get(r) for r in range(world)] == [True] * world, dict(ret)

@@ -80,3 +80,53 @@ def test_layer_gradients_reach_pose_init_and_cam_mats(backend, dof, normalize):
     assert err_p.max().item() <= 2e-4, err_p
     ref_ksum = ref_k.sum(0)
     assert ((gk1.cpu().double() - ref_ksum).abs().max() / ref_ksum.abs().max()).item() <= 2e-4
+
+
+@pytest.mark.parametrize('dof,normalize', [(6, False), (4, True)])
+def test_pose_opt_plus_is_differentiable_wrt_cam_mats(backend, dof, normalize):
+    """with_pose_opt_plus=True and camera.cam_mats requiring grad: the reference differentiates LMSolver.gn_step + pose_add w.r.t. the
+    intrinsics too (levenberg_marquardt.py:70-72,243-265).  The fused Gauss-Newton kernels do not; the layer then takes the
+    PyTorch composite for pose_opt_plus -- same value to rounding, gradients to the intrinsics AND to the correspondences against
+    fp64 autograd of the oracle's gn_step at the layer's pose_opt (round 4 only warned here)."""
+    import warnings
+    from epropnp.camera import PerspectiveCamera
+    from epropnp.epropnp import EProPnP4DoF, EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver
+    B, N, S, K = 4, 96, 32, 2
+    prob = orc.make_problem(B, N, dof, seed=43)
+    noise = pack_noise(orc.make_noise(B, S, K, dof, seed=44), dof)
+    p, _, cf = make_layer_objects(prob, backend)
+    cls = EProPnP6DoF if dof == 6 else EProPnP4DoF
+    layer = cls(mc_samples=S, num_iter=K, normalize=normalize, solver=LMSolver(dof=dof, num_iter=4))
+    g = torch.Generator().manual_seed(9)
+    g_plus = torch.randn(B, 7 if dof == 6 else 4, generator=g)
+
+    def run(cam_grad):
+        x3d, x2d, w2d = (p[k].clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+        Kmat = p['cam_mats'].clone().requires_grad_(cam_grad)
+        cam = PerspectiveCamera(cam_mats=Kmat, z_min=0.1)
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')                  # (the round-4 RuntimeWarning must be gone)
+            out = layer.monte_carlo_forward(x3d, x2d, w2d, cam, cf, pose_init=p['pose_init'], force_init_solve=False,
+                                            noise=noise.to(backend), with_pose_opt_plus=True)
+        (out[2] * g_plus.to(backend)).sum().backward()
+        return out, x3d.grad, x2d.grad, w2d.grad, Kmat.grad
+    out0, gx0, gu0, gw0, gk0 = run(False)           # fused kernels
+    out1, gx1, gu1, gw1, gk1 = run(True)            # composite
+    assert gk0 is None and gk1 is not None
+    assert (out0[2] - out1[2]).abs().max().item() <= 2e-5 and torch.equal(out0[0], out1[0])
+    # fp64 autograd of the oracle at the layer's pose_opt
+    x3d, x2d, w2d = (prob[k].double().clone().requires_grad_(True) for k in ('x3d', 'x2d', 'w2d'))
+    Kd = prob['cam_mats'].double().clone().requires_grad_(True)
+    pose = out1[0].detach().cpu().double()
+    x3d_s, pose_s, offset = x3d, pose, None
+    if normalize:
+        offset, x3d_s, pose_s = orc.pnp_normalize(x3d, pose)
+    plus = orc.pose_add(pose_s, orc.gn_step(x3d_s, x2d, w2d, pose_s, orc.Cam(Kd, 0.1, None, None), prob['delta'].double()))
+    if normalize:
+        plus = orc.pnp_denormalize(offset, plus)
+    (plus * g_plus.double()).sum().backward()
+    for name, mine, ref in (('cam_mats', gk1, Kd.grad), ('x3d', gx1, x3d.grad), ('x2d', gu1, x2d.grad), ('w2d', gw1, w2d.grad),
+                            ('x3d (kernels)', gx0, x3d.grad)):
+        err = (mine.cpu().double() - ref).abs().reshape(B, -1).amax(1) / ref.abs().reshape(B, -1).amax(1).clamp(min=1e-12)
+        assert err.max().item() <= 2e-3, (name, err)
