@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 evidence run on the GPU box.  usage: tools/gpu_r04_evidence.sh [tag] [parts]   parts: any of t(ests) b(ench) p(mc) o(ther)
-TAG=${1:-r04}; PARTS=${2:-tbpoc}
+# Round-5 evidence run on the GPU box.  usage: tools/gpu_r05_evidence.sh [tag] [parts]   parts: any of t(ests) b(ench) p(mc) o(ther) c(onfigs + C5)
+TAG=${1:-r05}; PARTS=${2:-tbpoc}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 O=/root/repo/gpurun_out
@@ -12,10 +12,10 @@ if [[ $PARTS == *t* ]]; then
   cat $O/${TAG}_smoke.log
 fi
 if [[ $PARTS == *b* ]]; then
-  (timeout 900 python bench.py 2>&1 | tail -1) > $O/${TAG}_bench.json
+  (timeout 900 python bench.py 2>&1 | grep "^{" | tail -1) > $O/${TAG}_bench.json
   cut -c1-1800 $O/${TAG}_bench.json
   cd /tmp; rm -rf /tmp/prof
-  (timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python /root/repo/bench.py --no-cpu-baseline --no-hipgraph 2>&1 | tail -1) > $O/${TAG}_bench_under_rocprof.json
+  (timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python /root/repo/bench.py --no-cpu-baseline --no-hipgraph 2>&1 | grep "^{" | tail -1) > $O/${TAG}_bench_under_rocprof.json
   python /root/repo/tools/rocprof_summary.py /tmp/prof/bench_results.db | cut -c1-190 > $O/${TAG}_kernel_stats.txt
   head -14 $O/${TAG}_kernel_stats.txt
   cd /root/repo
@@ -30,7 +30,7 @@ if [[ $PARTS == *b* ]]; then
 fi
 if [[ $PARTS == *p* ]]; then
   cd /tmp
-  B="python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-hipgraph"
+  B="python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-hipgraph --no-large-sweep"      # every normal_equations_kernel dispatch has the C2 launch size
   i=0
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
              "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VALU_TRANS SQ_LDS_BANK_CONFLICT" \
@@ -53,9 +53,11 @@ fi
 if [[ $PARTS == *c* ]]; then
   # driver-reachable configs other than C2, and the C5 shard (8192 x 2048, IC-cold by construction): kernel trace + FETCH/WRITE
   for c in C1 C3 C3-train; do
-    (timeout 600 python bench.py --config $c --no-cpu-baseline 2>&1 | tail -1) > $O/${TAG}_bench_${c}.json
+    (timeout 600 python bench.py --config $c --no-cpu-baseline 2>&1 | grep "^{" | tail -1) > $O/${TAG}_bench_${c}.json
     cut -c1-500 $O/${TAG}_bench_${c}.json
   done
+  bash tools/gpu_step_sequences.sh $TAG C1 C3 C3-train C4 > /dev/null 2>&1
+  tail -1 $O/${TAG}_C4_step_sequence.txt
   cd /tmp
   B="python /root/repo/bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline --no-hipgraph"
   i=0
@@ -64,7 +66,7 @@ if [[ $PARTS == *c* ]]; then
     (timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $set -d /tmp/pmc5_$i -o p -- $B 2>&1 | grep -E "rror|ailed" | head -3)
   done
   # (without the `p` part in the same call the C2 entry is carried over from the committed profile of this round, not re-measured)
-  [ -f $O/${TAG}_pmc_traffic.json ] || cp /root/repo/profiles/${TAG}_pmc_traffic.json $O/${TAG}_pmc_traffic.json 2>/dev/null || cp /root/repo/profiles/r03_pmc_traffic.json $O/${TAG}_pmc_traffic.json
+  [ -f $O/${TAG}_pmc_traffic.json ] || cp /root/repo/profiles/${TAG}_pmc_traffic.json $O/${TAG}_pmc_traffic.json 2>/dev/null || true
   python /root/repo/tools/pmc_traffic.py /tmp/pmc5_1 /tmp/pmc5_2 C5:B8192:N2048:S1024:K4:L3 $O/${TAG}_pmc_traffic.json
   rm -rf /tmp/prof5
   (timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof5 -o bench -- $B 2>&1 | tail -1) > $O/${TAG}_bench_C5_under_rocprof.json
