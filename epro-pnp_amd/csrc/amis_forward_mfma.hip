@@ -446,8 +446,10 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
       if (w * o >= ptiles) break;
     }
   }
-  // 4-DoF with 16 resident tiles does not fit 256 VGPRs next to the von Mises sampler: stream the points through LDS
-  if (prob->dof == 4 && npt == 16) npt = 0;
+  // 4-DoF with 12 or 16 resident tiles does not fit 256 VGPRs next to the von Mises sampler -- those instantiations spill
+  // 120-308 B per lane and reload B-operand tuples INSIDE the sweep loop, the pattern of profiles/r05_bwd_scratch.txt --: stream the
+  // points through LDS instead (12 tiles were taken until round 5; EPROPNP_TUNE=fwd_mfma=4,12 still selects them)
+  if (prob->dof == 4 && npt >= 12) npt = 0;
   // few objects (less than two waves per SIMD otherwise): spread an object over 8 waves (B = 32: 86 vs 93 us)
   if (d.B < 512 && waves == 4 && npt == 8) { waves = 8; npt = 4; }
   { int ov[2]; if (tune_ints("fwd_mfma", ov, 2) && (ov[0] == 1 || ov[0] == 2 || ov[0] == 4 || ov[0] == 8) && (ov[1] == 0 || ov[1] == 1 || ov[1] == 2 || ov[1] == 4 || ov[1] == 8 || ov[1] == 12 || ov[1] == 16) && (ov[1] == 0 || ov[0] * ov[1] >= ptiles)) { waves = ov[0]; npt = ov[1]; } }

@@ -84,3 +84,27 @@ def test_forward_launches_agree_bit_for_bit(B, N, dof, bounded, proj, monkeypatc
         assert torch.equal(smp, first[0]) and torch.equal(logw, first[1]), (
             f'launch {rep} differs from launch 0: {int((logw != first[1]).sum())} log-weights, max |diff| '
             f'{float((logw - first[1]).abs().max()):.3e}')
+
+
+def test_all_valu_backward_launches_agree_bit_for_bit():
+    """Beyond ~2700 samples the backward's LDS pose table does not fit and the all-VALU kernel takes over (amis_kernels.hip): same rule."""
+    from epropnp import functional as F
+    dev = torch.device('cuda:0')
+    B, N, S = 300, 256, 2800
+    prob, (p, cam, cf) = _problem(B, N, 6, True, dev)
+    g = torch.Generator().manual_seed(11)
+    poses = prob['pose_gt'].unsqueeze(0).repeat(S, 1, 1)
+    poses[..., :3] += 0.2 * torch.randn(S, B, 3, generator=g)
+    q = poses[..., 3:] + 0.1 * torch.randn(S, B, 4, generator=g)
+    poses[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+    g_logw, g_init = torch.randn(S, B, generator=g), torch.randn(B, generator=g)
+    hp = F.PnPProblem(p['x3d'], p['x2d'], p['w2d'], cam, cf, 6)
+    args = (hp, poses.to(dev), g_logw.to(dev), p['pose_init'], g_init.to(dev))
+    first = None
+    for rep in range(6):
+        out = [t.clone() for t in F.amis_backward(*args)[:3]]
+        torch.cuda.synchronize()
+        if first is None:
+            first = out
+            continue
+        assert all(torch.equal(a, b) for a, b in zip(out, first)), f'launch {rep} differs from launch 0'

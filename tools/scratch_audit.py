@@ -22,8 +22,14 @@ spec = importlib.util.spec_from_file_location('epropnp_build', os.path.join(ROOT
 build = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(build)
 
-# instantiations with scratch inside an inner loop that are reachable only through an EPROPNP_TUNE override (tests, tools/tune.py)
-ALLOWED = ()
+# matrix-core instantiations with scratch inside an inner loop that no launcher selects by default: 4-DoF forward with 12 / 16
+# resident tiles (EPROPNP_TUNE=fwd_mfma=..; the launcher streams the points through LDS instead), the bounded fp32-projection forward
+# with 8 resident tiles (EPROPNP_FWD_PROJ=f32 only).  The all-VALU kernels of amis_kernels.hip / lm_kernel.hip are not subject to the
+# rule (no matrix-core operands; their 16-wave classes live on 128 VGPRs by design).
+ALLOWED = ('amis_forward_mfma_kernel<4, true, 12, false, false, true, false>', 'amis_forward_mfma_kernel<4, false, 12, false, false, true, false>',
+           'amis_forward_mfma_kernel<4, true, 16, false, false, true, false>', 'amis_forward_mfma_kernel<4, false, 16, false, false, true, false>',
+           'amis_forward_mfma_kernel<4, true, 16, false, false, false, false>', 'amis_forward_mfma_kernel<6, true, 8, false, false, false, false>')
+MFMA_FILES = ('amis_forward_mfma.hip', 'amis_backward_mfma.hip')
 
 
 def audit(src):
@@ -82,7 +88,7 @@ def main():
                     flag = ''
                     if inner:
                         flag = '  <-- scratch inside an inner loop' + (' (allowed: tuning override only)' if name in ALLOWED else '')
-                        if name not in ALLOWED:
+                        if name not in ALLOWED and src in MFMA_FILES:
                             bad.append(name)
                     print(f'  {name:70s} {m["private_segment_fixed_size"]:4d} B/lane  vgpr {m.get("vgpr_count", 0):3d}  '
                           f'{ {f"{op}@depth{d}": v for (op, d), v in sorted(ops.items())} }{flag}')
