@@ -15,6 +15,7 @@ import os
 import torch
 
 from . import functional as hip
+from ._dtype import fp32_boundary
 from . import proposals
 from .common import pnp_denormalize, pnp_normalize
 
@@ -126,12 +127,14 @@ class EProPnPBase(torch.nn.Module):
             self._calls += 1
         return cfg
 
+    @fp32_boundary
     def monte_carlo_forward(self, x3d, x2d, w2d, camera, cost_fun, pose_init=None, force_init_solve=True,
                             noise=None, **kwargs):
         """Weighted pose samples from the pose distribution defined by the correspondences.
 
         x3d (B,N,3), x2d (B,N,2), w2d (B,N,2); pose_init (B,4|7) optional (the target pose for the MC loss).
-        fp32 tensors on a HIP device only (no CPU / fp64 path); differentiable w.r.t. x3d, x2d, w2d, a tensor-valued
+        Tensors on a HIP device only (no CPU path); computed in fp32 -- other floating dtypes are cast on the way in and the
+        outputs / gradients back (_dtype.py); differentiable w.r.t. x3d, x2d, w2d, a tensor-valued
         cost_fun.delta, and -- as in the reference -- w.r.t. pose_init (through cost_init) and camera.cam_mats (through
         cost_init and the log-weights).
         Limits: the samples of ONE iteration (mc_samples / num_iter) must fit the LDS pose table (<~ 1500); the total

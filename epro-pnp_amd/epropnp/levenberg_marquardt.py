@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as hip
+from ._dtype import fp32_boundary
 from .common import evaluate_pnp, pnp_denormalize, pnp_normalize
 
 
@@ -51,6 +52,7 @@ class LMSolver(nn.Module):
         self.init_solver = init_solver
 
     # ------------------------------------------------------------------------------------------------
+    @fp32_boundary
     def forward(self, x3d, x2d, w2d, camera, cost_fun, with_pose_opt_plus=False, pose_init=None,
                 normalize_override=None, **kwargs):
         """-> pose_opt, pose_cov | None, cost | None, pose_opt_plus | None"""
@@ -83,6 +85,7 @@ class LMSolver(nn.Module):
                     initial_trust_region_radius=self.initial_trust_region_radius,
                     max_trust_region_radius=self.max_trust_region_radius, eps=self.eps)
 
+    @fp32_boundary
     def solve(self, x3d, x2d, w2d, camera, cost_fun, pose_init=None, cost_init=None, with_pose_cov=False,
               with_cost=False, force_init_solve=False, fast_mode=False):
         """x3d (B,N,3), x2d/w2d (B,N,2) -> pose_opt (B,4|7), pose_cov (B,d,d) | None, cost (B,) | None.
@@ -190,6 +193,7 @@ class RSLMSolver(LMSolver):
             rot = torch.where(nrm < self.eps, ident, rot / nrm.clamp(min=1e-30))
         return inds, rot
 
+    @fp32_boundary
     def solve(self, x3d, x2d, w2d, camera, cost_fun, **kwargs):
         """-> pose (B,4|7), None, min_cost (B,)"""
         with torch.no_grad():
