@@ -85,6 +85,33 @@ __global__ __launch_bounds__(MAXW * 64) void normal_equations_kernel(Problem p, 
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// Huber cost of ONE pose over the register-resident points of a lane (this lane's part of the object's sum)
+template <int DOF, int PPL, bool BOUNDS>
+__device__ __forceinline__ float resident_cost(const Point (&pts)[PPL], const float (&K)[9], const Bounds& bd, float delta,
+                                               float z_min, const float (&ps)[PoseLen<DOF>::value]) {
+  float R[9], KR[9], Kt[3];
+  pose_to_rot<DOF>(ps, R);
+  compose_kr_kt(K, R, ps, KR, Kt);
+  float c = 0.f;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    // exact Huber form on the IEEE path (matches cost_fun.py:8-12 bit-for-bit per point)
+    const Point& q = pts[k];
+    const float hx = KR[0] * q.X + KR[1] * q.Y + KR[2] * q.Z + Kt[0];
+    const float hy = KR[3] * q.X + KR[4] * q.Y + KR[5] * q.Z + Kt[1];
+    const float hz = KR[6] * q.X + KR[7] * q.Y + KR[8] * q.Z + Kt[2];
+    const float z = fmaxf(hz, z_min);
+    float px = hx / z, py = hy / z;
+    if (BOUNDS) {
+      px = clamp_lu(px, bd.lbx, bd.ubx);
+      py = clamp_lu(py, bd.lby, bd.uby);
+    }
+    const float rx = (px - q.u) * q.wu, ry = (py - q.v) * q.wv;
+    c += huber_exact(sqrtf(rx * rx + ry * ry), delta);
+  }
+  return c;
+}
+
 template <int DOF, int PPL, bool BOUNDS, int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void evaluate_cost_kernel(Problem p, const float* __restrict__ poses, int P,
                                                                     float* __restrict__ cost) {
@@ -106,27 +133,10 @@ __global__ __launch_bounds__(MAXW * 64) void evaluate_cost_kernel(Problem p, con
       c[jj] = 0.f;
       const int j = j0 + jj;
       if (j < P) {   // uniform branch
-        float ps[PL], R[9], KR[9], Kt[3];
+        float ps[PL];
 #pragma unroll
         for (int i = 0; i < PL; ++i) ps[i] = poses[((size_t)j * p.B + b) * PL + i];
-        pose_to_rot<DOF>(ps, R);
-        compose_kr_kt(K, R, ps, KR, Kt);
-#pragma unroll
-        for (int k = 0; k < PPL; ++k) {
-          // exact Huber form on the IEEE path (matches cost_fun.py:8-12 bit-for-bit per point)
-          const Point& q = pts[k];
-          const float hx = KR[0] * q.X + KR[1] * q.Y + KR[2] * q.Z + Kt[0];
-          const float hy = KR[3] * q.X + KR[4] * q.Y + KR[5] * q.Z + Kt[1];
-          const float hz = KR[6] * q.X + KR[7] * q.Y + KR[8] * q.Z + Kt[2];
-          const float z = fmaxf(hz, p.z_min);
-          float px = hx / z, py = hy / z;
-          if (BOUNDS) {
-            px = clamp_lu(px, bd.lbx, bd.ubx);
-            py = clamp_lu(py, bd.lby, bd.uby);
-          }
-          const float rx = (px - q.u) * q.wu, ry = (py - q.v) * q.wv;
-          c[jj] += huber_exact(sqrtf(rx * rx + ry * ry), delta);
-        }
+        c[jj] = resident_cost<DOF, PPL, BOUNDS>(pts, K, bd, delta, p.z_min, ps);
       }
     }
     block_sum<4>(c, scratch);
@@ -426,11 +436,21 @@ __global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__
 // center: offset[b] = mean_n x3d[b,n,:];  out[b,n,:] = x3d[b,n,:] - offset[b]
 // DOF != 0: the object's pose_init is moved into the centred frame by the same launch (shift_poses_kernel's arithmetic with
 // sign = +1, by thread 0) -- pnp_normalize's two steps in one launch of the one-call forward.
+// translation += sign * R o: ONE statement of the arithmetic for every kernel that moves a pose between the frames (the
+// centring kernels, shift_poses*, the fused centre + cost launch), so that they agree to the bit whichever one runs
+__device__ __forceinline__ void shift_translation(float* ps, const float (&R)[9], float ox, float oy, float oz, float sign) {
+  ps[0] += sign * (R[0] * ox + R[1] * oy + R[2] * oz);
+  ps[1] += sign * (R[3] * ox + R[4] * oy + R[5] * oz);
+  ps[2] += sign * (R[6] * ox + R[7] * oy + R[8] * oz);
+}
+
+// (block size: center_threads() -- the thread count fixes the order of the mean's sum, and center_cost_kernel below must
+// reproduce it)
 template <int DOF>
-__global__ __launch_bounds__(256) void center_points_kernel(const float* __restrict__ x3d, int B, int N,
-                                                             float* __restrict__ offset, float* __restrict__ out,
-                                                             const float* __restrict__ pose, float* __restrict__ pose_out) {
-  __shared__ float scratch[3 * 4];
+__global__ __launch_bounds__(1024) void center_points_kernel(const float* __restrict__ x3d, int B, int N,
+                                                              float* __restrict__ offset, float* __restrict__ out,
+                                                              const float* __restrict__ pose, float* __restrict__ pose_out) {
+  __shared__ float scratch[3 * 16];
   const int b = object_of_block(B);
   if (b >= B) return;
   const float* src = x3d + (size_t)b * N * 3;
@@ -452,13 +472,61 @@ __global__ __launch_bounds__(256) void center_points_kernel(const float* __restr
 #pragma unroll
       for (int k = 0; k < PL; ++k) ps[k] = pose[(size_t)b * PL + k];
       pose_to_rot<DOF == 0 ? 6 : DOF>(ps, R);
-      ps[0] += 1.0f * (R[0] * m0 + R[1] * m1 + R[2] * m2);
-      ps[1] += 1.0f * (R[3] * m0 + R[4] * m1 + R[5] * m2);
-      ps[2] += 1.0f * (R[6] * m0 + R[7] * m1 + R[8] * m2);
+      shift_translation(ps, R, m0, m1, m2, 1.0f);
 #pragma unroll
       for (int k = 0; k < PL; ++k) pose_out[(size_t)b * PL + k] = ps[k];
     }
   }
+}
+
+// pnp_normalize of the points and of pose_init (center_points_kernel<DOF>) AND the cost of pose_init in the centred frame
+// (evaluate_cost_kernel with one pose) in ONE launch: the first two launches of the one-call forward with normalize=True at the
+// launch-bound shapes (EPro-PnP-Det: 600 x 128).  The points are loaded once into registers, summed in center_points_kernel's
+// order (same block size: center_threads), centred in place and written out; the cost is resident_cost on those registers and
+// the same block_sum<4> -- offset, centred points, pose and cost are bit-identical to the two separate launches.
+template <int DOF, int PPL, bool BOUNDS, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void center_cost_kernel(Problem p, const float* __restrict__ pose,
+                                                                  float* __restrict__ offset, float* __restrict__ x3d_out,
+                                                                  float* __restrict__ pose_out, float* __restrict__ cost) {
+  constexpr int PL = PoseLen<DOF>::value;
+  __shared__ float scratch[4 * 16];
+  const int b = object_of_block(p.B);
+  if (b >= p.B) return;
+  float K[9], delta;
+  Bounds bd;
+  load_camera<BOUNDS>(p, b, K, bd, delta);
+  Point pts[PPL];
+  float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int n = (int)threadIdx.x + k * (int)blockDim.x;
+    pts[k] = load_point(p, b, n);
+    if (n < p.N) { s[0] += pts[k].X; s[1] += pts[k].Y; s[2] += pts[k].Z; }
+  }
+  block_sum<3>(s, scratch);
+  const float m0 = s[0] / (float)p.N, m1 = s[1] / (float)p.N, m2 = s[2] / (float)p.N;
+  float* dst = x3d_out + (size_t)b * p.N * 3;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int n = (int)threadIdx.x + k * (int)blockDim.x;
+    if (n < p.N) {      // (padding keeps its zero coordinates and zero weights, as evaluate_cost_kernel would load it)
+      pts[k].X -= m0; pts[k].Y -= m1; pts[k].Z -= m2;
+      dst[3 * n] = pts[k].X; dst[3 * n + 1] = pts[k].Y; dst[3 * n + 2] = pts[k].Z;
+    }
+  }
+  float ps[PL], R[9];
+#pragma unroll
+  for (int k = 0; k < PL; ++k) ps[k] = pose[(size_t)b * PL + k];
+  pose_to_rot<DOF>(ps, R);
+  shift_translation(ps, R, m0, m1, m2, 1.0f);
+  if (threadIdx.x == 0) {
+    offset[(size_t)b * 3] = m0; offset[(size_t)b * 3 + 1] = m1; offset[(size_t)b * 3 + 2] = m2;
+#pragma unroll
+    for (int k = 0; k < PL; ++k) pose_out[(size_t)b * PL + k] = ps[k];
+  }
+  float c[4] = {resident_cost<DOF, PPL, BOUNDS>(pts, K, bd, delta, p.z_min, ps), 0.f, 0.f, 0.f};
+  block_sum<4>(c, scratch);
+  if (threadIdx.x == 0) cost[b] = c[0];
 }
 
 // shift: out[j,b] = pose[j,b] with translation += sign * R(pose[j,b]) offset[b]
@@ -474,9 +542,7 @@ __global__ __launch_bounds__(256) void shift_poses_kernel(const float* __restric
     for (int k = 0; k < PL; ++k) ps[k] = pose[i * PL + k];
     pose_to_rot<DOF>(ps, R);
     const float ox = offset[(size_t)b * 3], oy = offset[(size_t)b * 3 + 1], oz = offset[(size_t)b * 3 + 2];
-    ps[0] += sign * (R[0] * ox + R[1] * oy + R[2] * oz);
-    ps[1] += sign * (R[3] * ox + R[4] * oy + R[5] * oz);
-    ps[2] += sign * (R[6] * ox + R[7] * oy + R[8] * oz);
+    shift_translation(ps, R, ox, oy, oz, sign);
 #pragma unroll
     for (int k = 0; k < PL; ++k) out[i * PL + k] = ps[k];
   }
@@ -501,9 +567,7 @@ __global__ __launch_bounds__(256) void shift_poses_pair_kernel(const float* __re
     for (int k = 0; k < PL; ++k) ps[k] = pose[i * PL + k];
     pose_to_rot<DOF>(ps, R);
     const float ox = offset[(size_t)b * 3], oy = offset[(size_t)b * 3 + 1], oz = offset[(size_t)b * 3 + 2];
-    ps[0] += sign * (R[0] * ox + R[1] * oy + R[2] * oz);
-    ps[1] += sign * (R[3] * ox + R[4] * oy + R[5] * oz);
-    ps[2] += sign * (R[6] * ox + R[7] * oy + R[8] * oz);
+    shift_translation(ps, R, ox, oy, oz, sign);
 #pragma unroll
     for (int k = 0; k < PL; ++k) out[i * PL + k] = ps[k];
   }
@@ -560,12 +624,14 @@ int launch_shift_poses_backward(const float* pose, const float* offset, const fl
   return check_launch("shift_poses_backward_kernel");
 }
 
+// threads per object of the centring kernels: the block size of the register-resident sweeps (choose_shape) wherever those
+// can hold the object -- the fused centre + cost launch sums the mean in that order -- and 256 beyond
+static int center_threads(int B, int N) { return N <= kMaxResidentPoints ? 64 * choose_shape(B, N).waves : 256; }
+
 int launch_center_points(const float* x3d, int B, int N, float* offset, float* out, hipStream_t st) {
   if (B <= 0) return EPROPNP_OK;
   if (!x3d || !offset || !out || N < 1) return fail(EPROPNP_EINVAL, "center_points: bad argument");
-  int threads = 64;
-  while (threads < 256 && threads * 2 < N) threads *= 2;
-  PNP_LAUNCH(center_points_kernel<0>, dim3(padded_object_grid(B)), dim3(threads), 0, st, x3d, B, N, offset, out,
+  PNP_LAUNCH(center_points_kernel<0>, dim3(padded_object_grid(B)), dim3(center_threads(B, N)), 0, st, x3d, B, N, offset, out,
              (const float*)nullptr, (float*)nullptr);
   return check_launch("center_points_kernel");
 }
@@ -575,13 +641,32 @@ int launch_center_points_shift(const float* x3d, int B, int N, float* offset, fl
   if (B <= 0) return EPROPNP_OK;
   if (!x3d || !offset || !out || !pose || !pose_out || N < 1 || (dof != 4 && dof != 6))
     return fail(EPROPNP_EINVAL, "center_points_shift: bad argument");
-  int threads = 64;
-  while (threads < 256 && threads * 2 < N) threads *= 2;
+  const int threads = center_threads(B, N);
   if (dof == 6)
     PNP_LAUNCH(center_points_kernel<6>, dim3(padded_object_grid(B)), dim3(threads), 0, st, x3d, B, N, offset, out, pose, pose_out);
   else
     PNP_LAUNCH(center_points_kernel<4>, dim3(padded_object_grid(B)), dim3(threads), 0, st, x3d, B, N, offset, out, pose, pose_out);
   return check_launch("center_points_kernel (+ pose_init)");
+}
+
+// prob: the problem on the caller's (uncentred) points.  -> offset (B,3), x3d_centered (B,N,3), pose_n (B,PL), cost (B,) of pose_n
+// on the centred points.  num_pts <= the register-resident limit (as evaluate_cost).
+int launch_center_cost(const epropnp_problem* prob, const float* pose, float* offset, float* x3d_centered, float* pose_n,
+                       float* cost, hipStream_t st) {
+  if (int rc = check_problem(prob)) return rc;
+  if (prob->num_obj == 0) return EPROPNP_OK;
+  if (!pose || !offset || !x3d_centered || !pose_n || !cost) return fail(EPROPNP_EINVAL, "center_cost: NULL pointer");
+  if (prob->num_pts > kMaxResidentPoints)
+    return fail(EPROPNP_EINVAL, "center_cost: num_pts %d exceeds the register-resident limit %d", prob->num_pts, kMaxResidentPoints);
+  const Problem d = to_device_problem(prob);
+  const Shape s = choose_shape(d.B, d.N);
+  const dim3 grid(padded_object_grid(d.B)), block(64 * s.waves);
+  dispatch_shape(prob->dof, s.ppl, has_bounds(prob), s.waves, [&](auto DOF, auto PPL, auto BND, auto MAXW) -> int {
+    PNP_LAUNCH((center_cost_kernel<decltype(DOF)::value, decltype(PPL)::value, decltype(BND)::value, decltype(MAXW)::value>),
+               grid, block, 0, st, d, pose, offset, x3d_centered, pose_n, cost);
+    return 0;
+  });
+  return check_launch("center_cost_kernel");
 }
 
 int launch_shift_poses(const float* pose, const float* offset, int P, int B, int dof, float sign, float* out,

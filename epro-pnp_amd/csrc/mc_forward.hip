@@ -67,17 +67,24 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
     if ((rc = launch_fill_u32(par->lm_scratch, 0xffffffffu, total / 4, st))) return rc;
     prefilled_exchange_range() = PrefilledRange{(const char*)par->lm_scratch, (const char*)par->lm_scratch + total};
   }
+  bool have_cost_init = false;
   if (par->normalize) {       // pnp_normalize (common.py:103-124)
-    {   // centred points and, in the same launch, pose_init in the centred frame
+    {   // centred points and, in the same launch, pose_init in the centred frame -- and its cost there (:121-124), where the
+        // object's points fit the registers of one workgroup
       StageScope ps("center_points", st);
-      rc = pose_init ? launch_center_points_shift(prob->x3d, B, prob->num_pts, offset, x3d_centered, pose_init, pose_init_n, prob->dof, st)
-                     : launch_center_points(prob->x3d, B, prob->num_pts, offset, x3d_centered, st);
+      if (pose_init && prob->num_pts <= kMaxResidentPoints) {
+        rc = launch_center_cost(prob, pose_init, offset, x3d_centered, pose_init_n, cost_init, st);
+        have_cost_init = true;
+      } else {
+        rc = pose_init ? launch_center_points_shift(prob->x3d, B, prob->num_pts, offset, x3d_centered, pose_init, pose_init_n, prob->dof, st)
+                       : launch_center_points(prob->x3d, B, prob->num_pts, offset, x3d_centered, st);
+      }
       if (rc) return rc;
     }
     q.x3d = x3d_centered;
     if (pose_init) pinit = pose_init_n;
   }
-  if (pinit) {                // cost of pose_init (:121-124)
+  if (pinit && !have_cost_init) {                // cost of pose_init (:121-124)
     StageScope ps("evaluate_cost", st);
     if ((rc = launch_evaluate_cost(&q, pinit, 1, cost_init, st))) return rc;
   }

@@ -200,6 +200,8 @@ unsigned long long rslm_scratch_bytes(const epropnp_problem* prob, int num_propo
 int launch_shift_poses_pair(const float* pose_a, float* out_a, int Pa, const float* pose_b, float* out_b, int Pb,
                             const float* offset, int B, int dof, float sign, hipStream_t st);
 int launch_center_points(const float* x3d, int B, int N, float* offset, float* out, hipStream_t st);
+int launch_center_cost(const epropnp_problem* prob, const float* pose, float* offset, float* x3d_centered, float* pose_n,
+                       float* cost, hipStream_t st);
 int launch_center_points_shift(const float* x3d, int B, int N, float* offset, float* out, const float* pose, float* pose_out,
                                int dof, hipStream_t st);
 int launch_shift_poses(const float* pose, const float* offset, int P, int B, int dof, float sign, float* out,

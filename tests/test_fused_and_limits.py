@@ -410,3 +410,24 @@ def test_delta_gradient_folded_into_the_backward_kernel_gpu(monkeypatch, dof, B,
     import install as emu
     emu.uninstall()
     _delta_fold_case(torch.device('cuda:0'), monkeypatch, dof, B, N, S, K, bounds, normalize, nsplit, impl)
+
+
+def test_center_and_cost_of_pose_init_are_one_launch(backend):
+    """normalize=True with a pose_init: pnp_normalize of the points and of pose_init and the cost of pose_init in the centred frame
+    leave the one-call forward as ONE launch (center_cost_kernel, csrc/eval_kernels.hip) -- counted through the library's own stage
+    records; test_fused_forward_equals_composite holds its results against the separate launches bit for bit."""
+    from epropnp import _hip
+    prob = orc.make_problem(7, 100, 4, seed=8, bounds='tensor')
+    p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
+    cf.set_param(p['x2d'], p['w2d'])
+    counts = {}
+    for normalize in (True, False):
+        layer = _layer(4, 32, 2, 3, normalize, False)
+        _hip.profile(enable=True, reset=True)
+        try:
+            layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], force_init_solve=False)
+            counts[normalize] = {s: _hip.profile_read(s)[1] for s in ('center_points', 'evaluate_cost', 'lm_solve', 'amis_forward')}
+        finally:
+            _hip.profile(enable=False, reset=True)
+    assert counts[True] == dict(center_points=1, evaluate_cost=0, lm_solve=1, amis_forward=1), counts
+    assert counts[False] == dict(center_points=0, evaluate_cost=1, lm_solve=1, amis_forward=1), counts
