@@ -84,7 +84,27 @@ struct AmisParams {
   int advance_count;
   int ablate;          // tuning builds only (-DPNP_TUNING): bit0 skip sweep, bit1 skip proposal refit, bit2 skip densities
   unsigned split_timeout;   // split over workgroups: shader cycles a part waits for a sibling's partial costs (wave_ops.h)
+  // optional, pnp_normalize'd problems of the one-call forward (mc_forward.hip): pnp_denormalize of the outputs by THIS launch --
+  // the samples are stored a second time with translation - R offset (the arithmetic of shift_poses_kernel, sign -1), and
+  // pose_opt likewise, instead of a launch of their own behind this one
+  const float* dn_offset;   // (B,3) object centres, or nullptr
+  float* dn_samples;        // (S,B,PL)
+  float* dn_pose_opt;       // (B,PL)
 };
+
+// pnp_denormalize of pose_opt (AmisParams.dn_*): one thread of the object's (first) workgroup
+template <int DOF>
+PNP_FN void denormalise_pose_opt(const AmisParams& a, const float* __restrict__ pose_opt, int b) {
+  constexpr int PL = PoseLen<DOF>::value;
+  if (a.dn_offset == nullptr || a.dn_pose_opt == nullptr) return;
+  float ps[PL], R[9];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) ps[i] = pose_opt[(size_t)b * PL + i];
+  pose_to_rot<DOF>(ps, R);
+  shift_translation(ps, R, a.dn_offset[(size_t)b * 3], a.dn_offset[(size_t)b * 3 + 1], a.dn_offset[(size_t)b * 3 + 2], -1.0f);
+#pragma unroll
+  for (int i = 0; i < PL; ++i) a.dn_pose_opt[(size_t)b * PL + i] = ps[i];
+}
 
 // AmisParams.advance: called once by every workgroup that takes part in the launch (`expected` of them), at its very end.  The last
 // one to arrive increments the caller's counters and returns the ticket to zero; every workgroup read *offset_dev when it started,
@@ -628,6 +648,13 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
     {   // project_b operands of this sample -> LDS row (read back as broadcast by every lane of the sweep)
       float R[9], KR[9], Kt[3];
       pose_to_rot<DOF>(ps, R);
+      if (pose_samples != nullptr && a.dn_samples != nullptr) {      // the sample in the caller's frame (AmisParams.dn_*)
+        float pd[PL];
+#pragma unroll
+        for (int i = 0; i < PL; ++i) pd[i] = ps[i];
+        shift_translation(pd, R, a.dn_offset[(size_t)b * 3], a.dn_offset[(size_t)b * 3 + 1], a.dn_offset[(size_t)b * 3 + 2], -1.0f);
+        store_pose<PL>(a.dn_samples + ((size_t)m * p.B + b) * PL, pd);
+      }
       compose_kr_kt(Kc, R, ps, KR, Kt);
       float4* row = reinterpret_cast<float4*>(ptab + 12 * (n - n0));
       // [x-row | y-row | z-row] of (K R | K t): doubles as the A operand of the MFMA sweep

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
     for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last pose tile
   if (tid < (DOF == 6 ? 2 : 1))      // 6-DoF: lane 1 fits the translation factor inside lane 0's rotation fit
     initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop, tid);
+  if (part == 0 && tid == T - 1) denormalise_pose_opt<DOF>(a, pose_opt, b);      // (a lane of the last wave: wave 0 is busy with the fit)
   const int nchunk = kRegs ? 1 : (p.N + NC - 1) / NC;
   auto load_chunk = [&](int c0) {
     const int cnt = min(NC, ((p.N - c0 + 15) >> 4) << 4);
@@ -430,7 +431,7 @@ unsigned long long amis_forward_split_bytes(const epropnp_problem* prob, int mc_
 
 int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_params* am, const float* pose_opt,
                              const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
-                             float* proposals, hipStream_t st) {
+                             float* proposals, hipStream_t st, const DenormOut* dn) {
   const Problem d = to_device_problem(prob);
   const int S = am->mc_samples, K = am->num_iter, s = S / K;
   const int PL = prob->dof == 6 ? 7 : 4;
@@ -494,6 +495,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   k.advance = (am->advance && am->advance_ticket && am->advance_count > 0) ? (unsigned long long*)am->advance : nullptr;
   k.advance_ticket = (int*)am->advance_ticket; k.advance_count = am->advance_count;
   k.split_timeout = split_timeout_cycles();
+  k.dn_offset = dn ? dn->offset : nullptr; k.dn_samples = dn ? dn->samples : nullptr; k.dn_pose_opt = dn ? dn->pose_opt : nullptr;
   { int ab[1]; if (tune_ints("ablate", ab, 1)) k.ablate = ab[0]; }
   sh.ahead = 1;
   auto lds_bytes = [&](bool spilled) {

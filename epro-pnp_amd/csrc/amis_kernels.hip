@@ -65,6 +65,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : 3) : 1)) vo
 
   if (tid < (DOF == 6 ? 2 : 1))
     initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop, tid);
+  if (tid == (int)blockDim.x - 1) denormalise_pose_opt<DOF>(a, pose_opt, b);
   __syncthreads();
 
   AmisCtx cx;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(MAXW * 64, (MAXW == 4 ? (PPL >= 8 ? 2 : (PPL == 4 ?
 // ================================================================================================================
 int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* am, const float* pose_opt,
                         const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
-                        float* proposals, hipStream_t st) {
+                        float* proposals, hipStream_t st, const DenormOut* dn) {
   if (int rc = check_problem(prob)) return rc;
   if (!am) return fail(EPROPNP_EINVAL, "amis_forward: params NULL");
   if (am->num_iter <= 0 || am->mc_samples <= 0 || am->mc_samples % am->num_iter != 0)
@@ -311,7 +312,7 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   {   // default: projection on the matrix cores (amis_forward_mfma.hip); EPROPNP_TUNE="fwd_impl=valu" keeps the VALU sweep
     const char* impl = tune_value("fwd_impl");
     if (!(impl && impl[0] == 'v'))
-      return launch_amis_forward_mfma(prob, am, pose_opt, pose_cov, noise, pose_samples, logweights, proposals, st);
+      return launch_amis_forward_mfma(prob, am, pose_opt, pose_cov, noise, pose_samples, logweights, proposals, st, dn);
   }
   if (prob->num_pts > kMaxResidentPoints)
     return fail(EPROPNP_EINVAL, "amis_forward: num_pts %d exceeds the register-resident limit %d", prob->num_pts,
@@ -344,6 +345,7 @@ int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* 
   k.advance = (am->advance && am->advance_ticket && am->advance_count > 0) ? (unsigned long long*)am->advance : nullptr;
   k.advance_ticket = (int*)am->advance_ticket; k.advance_count = am->advance_count;
   k.ablate = 0;
+  k.dn_offset = dn ? dn->offset : nullptr; k.dn_samples = dn ? dn->samples : nullptr; k.dn_pose_opt = dn ? dn->pose_opt : nullptr;
   { int ab[1]; if (tune_ints("ablate", ab, 1)) k.ablate = ab[0]; }
   // the float4-viewed arrays (ptab rows, wred) come first so that they are 16-B aligned for any S
   const size_t smem = sizeof(float) * (12 * (size_t)s + (size_t)PL * S + 3 * (size_t)S + (size_t)WP * s +

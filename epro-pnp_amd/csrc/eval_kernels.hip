@@ -484,14 +484,6 @@ __global__ __launch_bounds__(64) void rslm_draw_kernel(const float* __restrict__
 // center: offset[b] = mean_n x3d[b,n,:];  out[b,n,:] = x3d[b,n,:] - offset[b]
 // DOF != 0: the object's pose_init is moved into the centred frame by the same launch (shift_poses_kernel's arithmetic with
 // sign = +1, by thread 0) -- pnp_normalize's two steps in one launch of the one-call forward.
-// translation += sign * R o: ONE statement of the arithmetic for every kernel that moves a pose between the frames (the
-// centring kernels, shift_poses*, the fused centre + cost launch), so that they agree to the bit whichever one runs
-__device__ __forceinline__ void shift_translation(float* ps, const float (&R)[9], float ox, float oy, float oz, float sign) {
-  ps[0] += sign * (R[0] * ox + R[1] * oy + R[2] * oz);
-  ps[1] += sign * (R[3] * ox + R[4] * oy + R[5] * oz);
-  ps[2] += sign * (R[6] * ox + R[7] * oy + R[8] * oz);
-}
-
 // (block size: center_threads() -- the thread count fixes the order of the mean's sum, and center_cost_kernel below must
 // reproduce it)
 template <int DOF>

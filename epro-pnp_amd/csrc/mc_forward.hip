@@ -112,8 +112,15 @@ int launch_monte_carlo_forward(const epropnp_problem* prob, const epropnp_mc_par
     start = start_pose;
   }
   { StageScope ps("lm_solve", st); if ((rc = launch_lm_solve(&q, &par->lm, start, pose_opt_n, pose_cov, cost, nullptr, par->lm_scratch, par->lm_scratch_bytes, st, sel.cand ? &sel : nullptr))) return rc; }
-  { StageScope ps("amis_forward", st); if ((rc = launch_amis_forward(&q, &par->amis, pose_opt_n, pose_cov, noise, pose_samples_n, logweights, nullptr, st))) return rc; }
-  if (par->normalize) {       // pnp_denormalize (common.py:127-136)
+  {   // normalize: pnp_denormalize (common.py:127-136) of pose_opt and of the samples rides in the AMIS launch
+    const DenormOut dn = {offset, pose_samples, pose_opt};
+    const bool fold = par->normalize && !tune_flag("no_denorm_fold");
+    StageScope ps("amis_forward", st);
+    if ((rc = launch_amis_forward(&q, &par->amis, pose_opt_n, pose_cov, noise, pose_samples_n, logweights, nullptr, st, fold ? &dn : nullptr)))
+      return rc;
+    if (fold) return EPROPNP_OK;
+  }
+  if (par->normalize) {       // (EPROPNP_TUNE=no_denorm_fold: the separate launch, same bits)
     StageScope ps("shift_poses", st);
     if ((rc = launch_shift_poses_pair(pose_opt_n, pose_opt, 1, pose_samples_n, pose_samples, S, offset, B, prob->dof, -1.0f, st)))
       return rc;

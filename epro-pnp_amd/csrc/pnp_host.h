@@ -259,12 +259,15 @@ int launch_lm_solve(const epropnp_problem* prob, const epropnp_lm_params* lm, co
                     float* pose_cov, float* cost, int32_t* accept_mask, void* split_scratch,
                     unsigned long long split_scratch_bytes, hipStream_t st, const StartSelect* select = nullptr);
 unsigned long long lm_split_bytes(const epropnp_problem* prob, const epropnp_lm_params* lm);
+// (one-call forward on a pnp_normalize'd problem: the AMIS launch also writes pose_opt and the samples in the caller's frame --
+//  AmisParams.dn_* -- instead of a shift_poses_pair launch behind it)
+struct DenormOut { const float* offset; float* samples; float* pose_opt; };
 int launch_amis_forward(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
                         const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
-                        float* proposals, hipStream_t st);
+                        float* proposals, hipStream_t st, const DenormOut* dn = nullptr);
 int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_params* amis, const float* pose_opt,
                              const float* pose_cov, const float* noise, float* pose_samples, float* logweights,
-                             float* proposals, hipStream_t st);
+                             float* proposals, hipStream_t st, const DenormOut* dn = nullptr);
 int launch_amis_backward_split(const epropnp_problem* prob, const float* pose_samples, const float* grad_logweights,
                                int mc_samples, const float* pose_init, const float* grad_cost_init, int nsplit,
                                float* grad_x3d, float* grad_x2d, float* grad_w2d, float* grad_delta_parts, hipStream_t st);

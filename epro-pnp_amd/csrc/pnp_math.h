@@ -114,6 +114,16 @@ PNP_FN void pose_to_rot(const float* pose, float (&R)[9]) {
   else yaw_to_rot(pose[3], R);
 }
 
+// translation += sign * R o: ONE statement of the arithmetic for every kernel that moves a pose between the caller's frame and
+// the centred one (the centring kernels, shift_poses*, the fused centre + cost launch, the AMIS forward's denormalised outputs),
+// so that they agree to the bit whichever one runs
+PNP_FN void shift_translation(float* ps, const float (&R)[9], float ox, float oy, float oz, float sign) {
+  ps[0] += sign * (R[0] * ox + R[1] * oy + R[2] * oz);
+  ps[1] += sign * (R[3] * ox + R[4] * oy + R[5] * oz);
+  ps[2] += sign * (R[6] * ox + R[7] * oy + R[8] * oz);
+}
+
+
 // project_b operands: KR = K R, Kt = K t  (epropnp/camera.py:23-27)
 PNP_FN void compose_kr_kt(const float (&K)[9], const float (&R)[9], const float* t, float (&KR)[9], float (&Kt)[3]) {
 #pragma unroll

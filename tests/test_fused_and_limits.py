@@ -412,25 +412,36 @@ def test_delta_gradient_folded_into_the_backward_kernel_gpu(monkeypatch, dof, B,
     _delta_fold_case(torch.device('cuda:0'), monkeypatch, dof, B, N, S, K, bounds, normalize, nsplit, impl)
 
 
-def test_center_and_cost_of_pose_init_are_one_launch(backend):
+def test_center_and_cost_of_pose_init_are_one_launch(backend, monkeypatch):
     """normalize=True with a pose_init: pnp_normalize of the points and of pose_init and the cost of pose_init in the centred frame
-    leave the one-call forward as ONE launch (center_cost_kernel, csrc/eval_kernels.hip) -- counted through the library's own stage
-    records; test_fused_forward_equals_composite holds its results against the separate launches bit for bit."""
+    leave the one-call forward as ONE launch (center_cost_kernel, csrc/eval_kernels.hip), and pnp_denormalize of pose_opt and of the
+    samples rides in the AMIS launch (AmisParams.dn_*) -- counted through the library's own stage records;
+    test_fused_forward_equals_composite holds the results against the separate launches bit for bit, and so does
+    EPROPNP_TUNE=no_denorm_fold here."""
     from epropnp import _hip
     prob = orc.make_problem(7, 100, 4, seed=8, bounds='tensor')
     p, cam, cf = make_layer_objects(prob, backend, relative_delta=0.5)
     cf.set_param(p['x2d'], p['w2d'])
-    counts = {}
-    for normalize in (True, False):
+    noise = pack_noise(orc.make_noise(7, 32, 2, 4, seed=4), 4).to(backend)
+    counts, outs = {}, {}
+    for normalize, fold in ((True, True), (True, False), (False, True)):
+        set_tune(monkeypatch, **({} if fold else {'no_denorm_fold': True}))
         layer = _layer(4, 32, 2, 3, normalize, False)
         _hip.profile(enable=True, reset=True)
         try:
-            layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], force_init_solve=False)
-            counts[normalize] = {s: _hip.profile_read(s)[1] for s in ('center_points', 'evaluate_cost', 'lm_solve', 'amis_forward')}
+            out = layer.monte_carlo_forward(p['x3d'], p['x2d'], p['w2d'], cam, cf, pose_init=p['pose_init'], force_init_solve=False,
+                                            noise=noise)
+            counts[normalize, fold] = {s: _hip.profile_read(s)[1] for s in ('center_points', 'evaluate_cost', 'lm_solve', 'amis_forward',
+                                                                            'shift_poses')}
         finally:
             _hip.profile(enable=False, reset=True)
-    assert counts[True] == dict(center_points=1, evaluate_cost=0, lm_solve=1, amis_forward=1), counts
-    assert counts[False] == dict(center_points=0, evaluate_cost=1, lm_solve=1, amis_forward=1), counts
+        outs[normalize, fold] = [out[0].clone(), out[3].clone(), out[4].clone()]
+    assert counts[True, True] == dict(center_points=1, evaluate_cost=0, lm_solve=1, amis_forward=1, shift_poses=0), counts
+    assert counts[True, False] == dict(center_points=1, evaluate_cost=0, lm_solve=1, amis_forward=1, shift_poses=1), counts
+    assert counts[False, True] == dict(center_points=0, evaluate_cost=1, lm_solve=1, amis_forward=1, shift_poses=0), counts
+    for a, b in zip(outs[True, True], outs[True, False]):
+        assert torch.equal(a, b)
+    assert (outs[True, True][0] - outs[False, True][0]).abs().max() < 1e-2      # pose_opt in the caller's frame either way
 
 
 @pytest.mark.parametrize('B,S,weighted,nf_ranks', [(5, 16, False, 0), (600, 128, True, 1), (37, 20, True, 3), (4097, 8, False, 1)])

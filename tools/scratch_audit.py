@@ -24,11 +24,13 @@ spec.loader.exec_module(build)
 
 # matrix-core instantiations with scratch inside an inner loop that no launcher selects by default: 4-DoF forward with 12 / 16
 # resident tiles (EPROPNP_TUNE=fwd_mfma=..; the launcher streams the points through LDS instead), the bounded fp32-projection forward
-# with 8 resident tiles (EPROPNP_FWD_PROJ=f32 only).  The all-VALU kernels of amis_kernels.hip / lm_kernel.hip are not subject to the
+# with 8 resident tiles (EPROPNP_FWD_PROJ=f32 only), the 6-DoF split-projection forward with 16 resident tiles (more than 48 point
+# tiles go through the registers in chunks of 8 per wave; EPROPNP_TUNE=fwd_no_chunks / fwd_mfma=4,16 only).  The all-VALU kernels of amis_kernels.hip / lm_kernel.hip are not subject to the
 # rule (no matrix-core operands; their 16-wave classes live on 128 VGPRs by design).
 ALLOWED = ('amis_forward_mfma_kernel<4, true, 12, false, false, true, false>', 'amis_forward_mfma_kernel<4, false, 12, false, false, true, false>',
            'amis_forward_mfma_kernel<4, true, 16, false, false, true, false>', 'amis_forward_mfma_kernel<4, false, 16, false, false, true, false>',
-           'amis_forward_mfma_kernel<4, true, 16, false, false, false, false>', 'amis_forward_mfma_kernel<6, true, 8, false, false, false, false>')
+           'amis_forward_mfma_kernel<4, true, 16, false, false, false, false>', 'amis_forward_mfma_kernel<6, true, 8, false, false, false, false>',
+           'amis_forward_mfma_kernel<6, true, 16, false, false, true, false>', 'amis_forward_mfma_kernel<6, false, 16, false, false, true, false>')
 MFMA_FILES = ('amis_forward_mfma.hip', 'amis_backward_mfma.hip')
 
 
