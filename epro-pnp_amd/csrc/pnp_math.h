@@ -116,13 +116,17 @@ PNP_FN void pose_to_rot(const float* pose, float (&R)[9]) {
 
 // translation += sign * R o: ONE statement of the arithmetic for every kernel that moves a pose between the caller's frame and
 // the centred one (the centring kernels, shift_poses*, the fused centre + cost launch, the AMIS forward's denormalised outputs),
-// so that they agree to the bit whichever one runs
+// so that they agree to the bit whichever one runs.  Every product and sum is rounded on its own: left to -ffp-contract=fast the
+// same source line came out as different fma chains depending on whether `sign` was a literal or an argument at the call site
+// (literal: the outer add is re-associated into the chain), and the one-call forward then differed from the separate launches
+// in the last bit of pose_init's cost (4-DoF, tests/test_fused_and_limits.py on the GPU).
 PNP_FN void shift_translation(float* ps, const float (&R)[9], float ox, float oy, float oz, float sign) {
-  ps[0] += sign * (R[0] * ox + R[1] * oy + R[2] * oz);
-  ps[1] += sign * (R[3] * ox + R[4] * oy + R[5] * oz);
-  ps[2] += sign * (R[6] * ox + R[7] * oy + R[8] * oz);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float e = add_unfused(add_unfused(mul_unfused(R[3 * i], ox), mul_unfused(R[3 * i + 1], oy)), mul_unfused(R[3 * i + 2], oz));
+    ps[i] = add_unfused(ps[i], mul_unfused(sign, e));
+  }
 }
-
 
 // project_b operands: KR = K R, Kt = K t  (epropnp/camera.py:23-27)
 PNP_FN void compose_kr_kt(const float (&K)[9], const float (&R)[9], const float* t, float (&KR)[9], float (&Kt)[3]) {
