@@ -209,16 +209,6 @@ int epropnp_mc_loss_reduce(const float* loss, const float* weight, int32_t num_o
                                     (long long)norm_factor_in_stride, norm_factor, out, (hipStream_t)stream);
 }
 
-int epropnp_mc_loss_forward_reduce(const float* logweights, const float* cost_target, int32_t mc_samples, int32_t num_obj,
-                                   float* loss, float* lse, const float* weight, float scale, float momentum,
-                                   const float* norm_factor_in, int32_t norm_factor_in_count, int64_t norm_factor_in_stride,
-                                   float* norm_factor, float* out, int32_t* ticket, void* stream) {
-  pnp::StageScope prof_("mc_loss_forward", (hipStream_t)stream);
-  return pnp::launch_mc_loss_forward_reduce(logweights, cost_target, mc_samples, num_obj, loss, lse, weight, scale, momentum,
-                                            norm_factor_in, norm_factor_in_count, (long long)norm_factor_in_stride, norm_factor,
-                                            out, (int*)ticket, (hipStream_t)stream);
-}
-
 int epropnp_exchange_pack(const float* rows, uint64_t row_floats, const float* scalars, int32_t n_scalars,
                           const float* sum_src, uint64_t sum_floats, float sum_scale, const float* sum_row_weight,
                           int32_t sum_row_len, float* send, void* stream) {

@@ -271,8 +271,9 @@ __global__ __launch_bounds__(256) void adaptive_delta_kernel(const float* __rest
 // over 32 row groups; each thread keeps an online (max, sum) pair over batches of 8 independent loads, the 32 partials
 // of a column are merged through LDS.
 constexpr int kLossCols = 16, kLossRows = 32;
-__device__ __forceinline__ void mc_loss_forward_block(const float* __restrict__ logw, const float* __restrict__ ct, int S, int B,
-                                                      float* loss, float* lse) {
+__global__ __launch_bounds__(512) void mc_loss_forward_kernel(const float* __restrict__ logw, const float* __restrict__ ct,
+                                                               int S, int B, float* __restrict__ loss,
+                                                               float* __restrict__ lse) {
   __shared__ float smax[kLossRows][kLossCols + 1], ssum[kLossRows][kLossCols + 1];
   const int c = (int)(threadIdx.x % kLossCols), rg = (int)(threadIdx.x / kLossCols);
   const int b = (int)blockIdx.x * kLossCols + c;
@@ -325,12 +326,6 @@ __device__ __forceinline__ void mc_loss_forward_block(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(512) void mc_loss_forward_kernel(const float* __restrict__ logw, const float* __restrict__ ct,
-                                                               int S, int B, float* __restrict__ loss,
-                                                               float* __restrict__ lse) {
-  mc_loss_forward_block(logw, ct, S, B, loss, lse);
-}
-
 // g == nullptr: the reduced loss (mc_loss_reduce_kernel) -- every object's upstream gradient is the scalar
 // grad_out[0] * coef[0] (* weight[b]), read from device memory so that the node stays capturable.
 __global__ __launch_bounds__(256) void mc_loss_backward_kernel(const float* __restrict__ logw, const float* __restrict__ lse,
@@ -357,24 +352,13 @@ __global__ __launch_bounds__(256) void mc_loss_backward_kernel(const float* __re
 // scale = loss_weight / B (mean) | loss_weight (sum) | loss_weight / avg_factor.  The sum runs in a fixed order (thread t takes
 // b = t, t + T, ...; then the block tree): bit-reproducible.  The running estimate is written with separately rounded
 // products, as the reference's mul_ / add_ pair does.
-// (T: the thread count that fixes the order of the sum -- thread t < T takes b = t, t + T, ...; threads beyond T add zeros.
-//  COHERENT: the per-object losses were written by other workgroups of the SAME launch -- read them past the caches)
-template <bool COHERENT>
-__device__ __forceinline__ void mc_loss_reduce_block(const float* loss, const float* __restrict__ weight, int B, int T, float scale,
-                                                     float one_minus_m, float m, const float* __restrict__ nf_in, int nf_count,
-                                                     long long nf_stride, float* __restrict__ nf, float* __restrict__ out,
-                                                     float* red) {
+__global__ __launch_bounds__(1024) void mc_loss_reduce_kernel(const float* __restrict__ loss, const float* __restrict__ weight,
+                                                               int B, float scale, float one_minus_m, float m,
+                                                               const float* __restrict__ nf_in, int nf_count, long long nf_stride,
+                                                               float* __restrict__ nf, float* __restrict__ out) {
+  __shared__ float red[16];
   float acc = 0.f;
-  if ((int)threadIdx.x < T) {
-    for (int b = (int)threadIdx.x; b < B; b += T) {
-#ifndef EPROPNP_EMU
-      const float l = COHERENT ? __hip_atomic_load(loss + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : loss[b];
-#else
-      const float l = loss[b];
-#endif
-      acc += (weight != nullptr) ? l * weight[b] : l;
-    }
-  }
+  for (int b = (int)threadIdx.x; b < B; b += (int)blockDim.x) acc += (weight != nullptr) ? loss[b] * weight[b] : loss[b];
   float v[1] = {acc};
   block_sum<1>(v, red);
   if (threadIdx.x == 0) {
@@ -392,38 +376,6 @@ __device__ __forceinline__ void mc_loss_reduce_block(const float* loss, const fl
     out[0] = v[0] * c;
     out[1] = c;
   }
-}
-
-__global__ __launch_bounds__(1024) void mc_loss_reduce_kernel(const float* __restrict__ loss, const float* __restrict__ weight,
-                                                               int B, float scale, float one_minus_m, float m,
-                                                               const float* __restrict__ nf_in, int nf_count, long long nf_stride,
-                                                               float* __restrict__ nf, float* __restrict__ out) {
-  __shared__ float red[16];
-  mc_loss_reduce_block<false>(loss, weight, B, (int)blockDim.x, scale, one_minus_m, m, nf_in, nf_count, nf_stride, nf, out, red);
-}
-
-// The two kernels above as ONE launch (<= 4096 objects: the launch-bound shapes): every workgroup writes its 16 objects' losses,
-// releases them at device scope and takes a ticket; the last one to arrive reduces all of them in mc_loss_reduce_kernel's order
-// (256 threads' strides, the same block tree with four more waves adding zeros) and returns the ticket to zero.  `ticket`: a
-// device word that is zero between launches (the loss module keeps one next to its norm_factor buffer).
-constexpr int kLossReduceThreads = 256;
-__global__ __launch_bounds__(512) void mc_loss_forward_reduce_kernel(const float* __restrict__ logw, const float* __restrict__ ct,
-                                                                      int S, int B, float* loss, float* __restrict__ lse,
-                                                                      const float* __restrict__ weight, float scale,
-                                                                      float one_minus_m, float m, const float* __restrict__ nf_in,
-                                                                      int nf_count, long long nf_stride, float* __restrict__ nf,
-                                                                      float* __restrict__ out, int* __restrict__ ticket) {
-  __shared__ float red[16];
-  __shared__ int last;
-  mc_loss_forward_block(logw, ct, S, B, loss, lse);
-  __threadfence();                       // release: this workgroup's losses before its ticket
-  __syncthreads();
-  if (threadIdx.x == 0) last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();                       // acquire: everybody else's losses after the last ticket
-  mc_loss_reduce_block<true>(loss, weight, B, kLossReduceThreads, scale, one_minus_m, m, nf_in, nf_count, nf_stride, nf, out, red);
-  if (threadIdx.x == 0) atomicExch(ticket, 0);
 }
 
 // One wave per (proposal, object) row.  Keys live in LDS; each of the n_pts rounds is a wave-wide argmin.
@@ -1082,23 +1034,6 @@ int launch_mc_loss_reduce(const float* loss, const float* weight, int B, float s
   PNP_LAUNCH(mc_loss_reduce_kernel, dim3(1), dim3(B > 4096 ? 1024 : 256), 0, st, loss, weight, B, scale, one_minus_m, momentum,
              nf_in, nf_count, nf_stride, nf, out);
   return check_launch("mc_loss_reduce_kernel");
-}
-
-// forward + reduce; one launch with a ticket word and <= 4096 objects (EPROPNP_TUNE=no_loss_ticket: always two), same bits
-int launch_mc_loss_forward_reduce(const float* logw, const float* ct, int S, int B, float* loss, float* lse, const float* weight,
-                                  float scale, float momentum, const float* nf_in, int nf_count, long long nf_stride, float* nf,
-                                  float* out, int* ticket, hipStream_t st) {
-  if (ticket == nullptr || B <= 0 || B > 4096 || tune_flag("no_loss_ticket")) {
-    if (int rc = launch_mc_loss_forward(logw, ct, S, B, loss, lse, st)) return rc;
-    return launch_mc_loss_reduce(loss, weight, B, scale, momentum, nf_in, nf_count, nf_stride, nf, out, st);
-  }
-  if (!logw || !loss || !lse || !out || S < 1) return fail(EPROPNP_EINVAL, "mc_loss_forward_reduce: bad argument");
-  if (nf_in != nullptr && nf == nullptr) return fail(EPROPNP_EINVAL, "mc_loss_forward_reduce: norm_factor_in without norm_factor");
-  if (nf_in != nullptr && (nf_count < 1 || (nf_count > 1 && nf_stride < 1))) return fail(EPROPNP_EINVAL, "mc_loss_forward_reduce: bad norm_factor_in count / stride");
-  const float one_minus_m = (float)(1.0 - (double)momentum);
-  PNP_LAUNCH(mc_loss_forward_reduce_kernel, dim3((B + kLossCols - 1) / kLossCols), dim3(512), 0, st, logw, ct, S, B, loss, lse, weight,
-             scale, one_minus_m, momentum, nf_in, nf_count, nf_stride, nf, out, ticket);
-  return check_launch("mc_loss_forward_reduce_kernel");
 }
 
 int launch_mc_loss_reduce_backward(const float* logw, const float* lse, const float* weight, const float* coef,

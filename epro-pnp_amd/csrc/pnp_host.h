@@ -245,9 +245,6 @@ inline bool exchange_prefilled(const void* p, size_t bytes) {
 }
 int launch_mc_loss_reduce(const float* loss, const float* weight, int B, float scale, float momentum, const float* nf_in,
                           int nf_count, long long nf_stride, float* nf, float* out, hipStream_t st);
-int launch_mc_loss_forward_reduce(const float* logw, const float* ct, int S, int B, float* loss, float* lse, const float* weight,
-                                  float scale, float momentum, const float* nf_in, int nf_count, long long nf_stride, float* nf,
-                                  float* out, int* ticket, hipStream_t st);
 int launch_exchange_pack(const float* rows, size_t row_floats, const float* scalars, int n_scal, const float* sum_src,
                          size_t sum_floats, float sum_scale, const float* row_w, int row_len, float* send, hipStream_t st);
 int launch_mc_loss_reduce_backward(const float* logw, const float* lse, const float* weight, const float* coef,

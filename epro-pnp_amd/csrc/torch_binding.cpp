@@ -107,14 +107,15 @@ struct McPoseLoss : public torch::autograd::Function<McPoseLoss> {
 // (sum_b weight_b loss_b) * scale / norm_factor as a 0-dim tensor; norm_factor's running estimate is updated in place
 struct McPoseLossReduced : public torch::autograd::Function<McPoseLossReduced> {
   static Tensor forward(AutogradContext* ctx, const Tensor& logw, const OptTensor& cost_target, const OptTensor& weight,
-                        double scale, double momentum, const OptTensor& nf_in, const OptTensor& norm_factor, int64_t stream,
-                        const OptTensor& ticket) {
+                        double scale, double momentum, const OptTensor& nf_in, const OptTensor& norm_factor, int64_t stream) {
     const Tensor lw = logw.detach().contiguous();
     const int64_t S = lw.size(0), B = lw.size(1);
     Tensor ct, w;
     if (cost_target.has_value() && cost_target->defined()) ct = cost_target->detach().contiguous();
     if (weight.has_value() && weight->defined()) w = weight->detach().contiguous();
     Tensor loss = torch::empty({B}, lw.options()), lse = torch::empty({B}, lw.options()), out = torch::empty({2}, lw.options());
+    check(epropnp_mc_loss_forward(fptr(lw), fptr(ct), (int32_t)S, (int32_t)B, fptr(loss), fptr(lse), (void*)stream),
+          "epropnp_mc_loss_forward");
     // nf_in: a scalar, or the (ranks,) STRIDED view of the exchange's receive buffer whose mean the kernel takes itself
     int32_t nf_count = 1;
     int64_t nf_stride = 1;
@@ -122,10 +123,8 @@ struct McPoseLossReduced : public torch::autograd::Function<McPoseLossReduced> {
       nf_count = (int32_t)nf_in->numel();
       nf_stride = nf_in->stride(0);
     }
-    int32_t* tk = (ticket.has_value() && ticket->defined()) ? ticket->data_ptr<int32_t>() : nullptr;      // one launch with it
-    check(epropnp_mc_loss_forward_reduce(fptr(lw), fptr(ct), (int32_t)S, (int32_t)B, fptr(loss), fptr(lse), fptr(w), (float)scale,
-                                         (float)momentum, fptr(nf_in), nf_count, nf_stride, fptr(norm_factor), fptr(out), tk,
-                                         (void*)stream), "epropnp_mc_loss_forward_reduce");
+    check(epropnp_mc_loss_reduce(fptr(loss), fptr(w), (int32_t)B, (float)scale, (float)momentum, fptr(nf_in), nf_count, nf_stride,
+                                 fptr(norm_factor), fptr(out), (void*)stream), "epropnp_mc_loss_reduce");
     ctx->save_for_backward({lw, lse, out, w});
     ctx->saved_data["stream"] = stream;
     ctx->saved_data["has_cost_target"] = ct.defined();
@@ -133,7 +132,7 @@ struct McPoseLossReduced : public torch::autograd::Function<McPoseLossReduced> {
     return out.select(0, 0);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    if (!grads[0].defined()) return variable_list(9);
+    if (!grads[0].defined()) return variable_list(8);
     const auto saved = ctx->get_saved_variables();
     const Tensor &lw = saved[0], &lse = saved[1], &out = saved[2], &w = saved[3];
     const Tensor g = grads[0].to(torch::kFloat32).reshape({1}).contiguous();
@@ -143,7 +142,7 @@ struct McPoseLossReduced : public torch::autograd::Function<McPoseLossReduced> {
     check(epropnp_mc_loss_reduce_backward(fptr(lw), fptr(lse), fptr(w), fptr(out) + 1, fptr(g), (int32_t)S, (int32_t)B,
                                           fptr(glw), fptr(gct), (void*)ctx->saved_data["stream"].toInt()),
           "epropnp_mc_loss_reduce_backward");
-    variable_list r(9);
+    variable_list r(8);
     r[0] = glw;
     r[1] = gct;
     return r;
@@ -431,9 +430,8 @@ Tensor mc_pose_loss(const Tensor& logw, const OptTensor& cost_target, int64_t st
 }
 
 Tensor mc_pose_loss_reduced(const Tensor& logw, const OptTensor& cost_target, const OptTensor& weight, double scale,
-                            double momentum, const OptTensor& nf_in, const OptTensor& norm_factor, int64_t stream,
-                            const OptTensor& ticket) {
-  return McPoseLossReduced::apply(logw, cost_target, weight, scale, momentum, nf_in, norm_factor, stream, ticket);
+                            double momentum, const OptTensor& nf_in, const OptTensor& norm_factor, int64_t stream) {
+  return McPoseLossReduced::apply(logw, cost_target, weight, scale, momentum, nf_in, norm_factor, stream);
 }
 
 std::vector<OptTensor> fused_monte_carlo(const Tensor& x3d, const Tensor& x2d, const Tensor& w2d, const OptTensor& delta,

@@ -107,13 +107,12 @@ def _declare(lib):
     lib.epropnp_mc_loss_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.epropnp_mc_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.epropnp_mc_loss_reduce.argtypes = [vp, vp, i32, C.c_float, C.c_float, vp, i32, C.c_int64, vp, vp, vp]
-    lib.epropnp_mc_loss_forward_reduce.argtypes = [vp, vp, i32, i32, vp, vp, vp, C.c_float, C.c_float, vp, i32, C.c_int64, vp, vp, vp, vp]
     lib.epropnp_exchange_pack.argtypes = [vp, C.c_uint64, vp, i32, vp, C.c_uint64, C.c_float, vp, i32, vp, vp]
     lib.epropnp_mc_loss_reduce_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     for name in ('evaluate_cost', 'normal_equations', 'lm_solve', 'amis_forward', 'amis_backward', 'adaptive_delta',
                  'mc_loss_forward', 'mc_loss_backward', 'rslm_draw', 'gn_step_forward', 'gn_step_backward', 'rslm_solve', 'center_points', 'shift_poses', 'prepare_forward', 'prepare_backward', 'pose_opt_plus_forward', 'pose_opt_plus_backward', 'shift_poses_backward', 'prepare_dense_forward',
                  'prepare_dense_backward', 'amis_backward_split', 'monte_carlo_forward', 'cost_pose_cam_grad', 'mc_loss_reduce',
-                 'mc_loss_reduce_backward', 'mc_loss_forward_reduce'):
+                 'mc_loss_reduce_backward'):
         getattr(lib, 'epropnp_' + name).restype = C.c_int
     return lib
 
@@ -128,8 +127,7 @@ EXPORTS = ('epropnp_abi_version', 'epropnp_last_error', 'epropnp_noise_stride', 
            'epropnp_prepare_dense_forward', 'epropnp_prepare_dense_backward', 'epropnp_amis_backward_split',
            'epropnp_monte_carlo_forward', 'epropnp_cost_pose_cam_grad', 'epropnp_async_status',
            'epropnp_async_status_word', 'epropnp_amis_forward_split_bytes', 'epropnp_rslm_solve_scratch_bytes',
-           'epropnp_lm_solve_split_bytes', 'epropnp_mc_loss_reduce', 'epropnp_mc_loss_reduce_backward', 'epropnp_exchange_pack',
-           'epropnp_mc_loss_forward_reduce')
+           'epropnp_lm_solve_split_bytes', 'epropnp_mc_loss_reduce', 'epropnp_mc_loss_reduce_backward', 'epropnp_exchange_pack')
 
 
 def lib():

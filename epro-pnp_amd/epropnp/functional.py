@@ -654,11 +654,10 @@ def mc_pose_loss(logweights, cost_target):
 
 
 class _McPoseLossReduced(torch.autograd.Function):
-    """The reduced Monte-Carlo pose loss (mc_pose_loss_reduced): per-object forward + reduce (one launch with a ticket word, else
-    two), backward."""
+    """The reduced Monte-Carlo pose loss (mc_pose_loss_reduced) as three kernels: per-object forward, reduce, backward."""
 
     @staticmethod
-    def forward(ctx, logw, cost_target, weight, scale, momentum, nf_in, norm_factor, ticket=None):
+    def forward(ctx, logw, cost_target, weight, scale, momentum, nf_in, norm_factor):
         lw = _f32c(logw, 'pose_sample_logweights')
         S, B = lw.shape
         ct = None if cost_target is None else _f32c(cost_target, 'cost_target')
@@ -666,10 +665,10 @@ class _McPoseLossReduced(torch.autograd.Function):
         lse = torch.empty_like(loss)
         out = torch.empty(2, dtype=torch.float32, device=lw.device)
         st = _hip.stream_of(lw)
+        _hip.call('epropnp_mc_loss_forward', _hip.ptr(lw), _hip.ptr(ct), S, B, _hip.ptr(loss), _hip.ptr(lse), st)
         nf_count, nf_stride = (nf_in.numel(), nf_in.stride(0)) if (nf_in is not None and nf_in.dim() == 1 and nf_in.numel() > 1) else (1, 1)
-        _hip.call('epropnp_mc_loss_forward_reduce', _hip.ptr(lw), _hip.ptr(ct), S, B, _hip.ptr(loss), _hip.ptr(lse), _hip.ptr(weight),
-                  float(scale), float(momentum), _hip.ptr(nf_in), int(nf_count), int(nf_stride), _hip.ptr(norm_factor),
-                  _hip.ptr(out), _hip.ptr(ticket), st)
+        _hip.call('epropnp_mc_loss_reduce', _hip.ptr(loss), _hip.ptr(weight), B, float(scale), float(momentum),
+                  _hip.ptr(nf_in), int(nf_count), int(nf_stride), _hip.ptr(norm_factor), _hip.ptr(out), st)
         ctx.save_for_backward(lw, lse, out)
         ctx.weight = weight
         return out[0]
@@ -677,7 +676,7 @@ class _McPoseLossReduced(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * 8
+            return (None,) * 7
         lw, lse, out = ctx.saved_tensors
         S, B = lw.shape
         g = g.to(torch.float32).reshape(1).contiguous()
@@ -685,18 +684,14 @@ class _McPoseLossReduced(torch.autograd.Function):
         gct = torch.empty(B, dtype=torch.float32, device=lw.device) if ctx.needs_input_grad[1] else None
         _hip.call('epropnp_mc_loss_reduce_backward', _hip.ptr(lw), _hip.ptr(lse), _hip.ptr(ctx.weight), _hip.ptr(out[1:]),
                   _hip.ptr(g), S, B, _hip.ptr(glw), _hip.ptr(gct), _hip.stream_of(lw))
-        return glw, gct, None, None, None, None, None, None
+        return glw, gct, None, None, None, None, None
 
 
-def mc_pose_loss_reduced(logweights, cost_target, weight=None, scale=1.0, momentum=0.0, norm_factor_in=None, norm_factor=None,
-                         ticket=None):
+def mc_pose_loss_reduced(logweights, cost_target, weight=None, scale=1.0, momentum=0.0, norm_factor_in=None, norm_factor=None):
     """-> the 0-dim loss  (sum_b weight[b] (cost_target[b] + logsumexp_S logweights[:, b])) * scale / norm_factor  of both
     reference loss modules (losses.MonteCarloPoseLoss), NaN objects zeroed.  `norm_factor` (1,)/0-dim device buffer, updated IN
     PLACE to (1 - momentum) norm_factor + momentum * norm_factor_in first when `norm_factor_in` (device scalar) is given.
-    weight (B,) without grad, or None.
-    ticket: an int32 (1,) device tensor that is zero between calls (and is left zero) -- with it the per-object pass and the
-    reduce are ONE launch up to 4096 objects (epropnp_mc_loss_forward_reduce); calls sharing a ticket must not overlap in time
-    (the loss module keeps one per instance, next to `norm_factor`, which has the same rule).  Same bits either way."""
+    weight (B,) without grad, or None."""
     _f32c(logweights, 'pose_sample_logweights')
     if cost_target is not None:
         _f32c(cost_target, 'cost_target')
@@ -713,14 +708,11 @@ def mc_pose_loss_reduced(logweights, cost_target, weight=None, scale=1.0, moment
     if norm_factor is not None and (norm_factor.dtype != torch.float32 or not norm_factor.is_contiguous()
                                     or norm_factor.device != logweights.device):
         raise ValueError('norm_factor must be a contiguous float32 scalar on the device of the log-weights')
-    if ticket is not None and (ticket.dtype != torch.int32 or ticket.numel() < 1 or ticket.device != logweights.device
-                               or not ticket.is_contiguous()):
-        raise ValueError('ticket must be a contiguous int32 tensor on the device of the log-weights')
     ext = _hip.torch_ext()
     if ext is not None:
         return ext.mc_pose_loss_reduced(logweights, cost_target, w, float(scale), float(momentum), nf_in, norm_factor,
-                                        int(_hip.stream_of(logweights) or 0), ticket)
-    return _McPoseLossReduced.apply(logweights, cost_target, w, scale, momentum, nf_in, norm_factor, ticket)
+                                        int(_hip.stream_of(logweights) or 0))
+    return _McPoseLossReduced.apply(logweights, cost_target, w, scale, momentum, nf_in, norm_factor)
 
 
 def exchange_pack(send, rows, scalars=None, sum_of=None, sum_scale=1.0, sum_row_weight=None):

@@ -37,9 +37,6 @@ class MonteCarloPoseLoss(nn.Module):
         self.reduction = reduction
         self.loss_weight = loss_weight
         self.register_buffer('norm_factor', torch.tensor(init_norm_factor, dtype=torch.float))
-        # the ticket word of the one-launch reduced loss (epropnp_mc_loss_forward_reduce): zero between calls; not part of the
-        # state_dict (the reference's checkpoints carry `norm_factor` only)
-        self.register_buffer('_reduce_ticket', torch.zeros(1, dtype=torch.int32), persistent=False)
         self.momentum = momentum
 
     def forward(self, pose_sample_logweights, cost_target, norm_factor, weight=None, avg_factor=None,
@@ -59,13 +56,12 @@ class MonteCarloPoseLoss(nn.Module):
                 else:
                     nf = _world_mean(torch.as_tensor(norm_factor, dtype=torch.float, device=self.norm_factor.device))
         if scale is not None:
-            # the reduced loss as TWO launches (per-object loss + reduce + running estimate + scaling behind a ticket; backward)
-            # instead of the ~15 elementwise / reduce launches of the statement below -- a quarter of the Det step when it is
-            # replayed from a hipGraph (profiles/r03_det_loss_fused.txt); same value to rounding
+            # the reduced loss as THREE launches (per-object loss, reduce + running estimate + scaling, backward) instead of the
+            # ~15 elementwise / reduce launches of the statement below -- a quarter of the Det step when it is replayed from a
+            # hipGraph (profiles/r03_det_loss_fused.txt); same value to rounding
             from .functional import mc_pose_loss_reduced
             return mc_pose_loss_reduced(pose_sample_logweights, cost_target, weight, scale, self.momentum,
-                                        None if nf is None else (nf if slots is not None else nf.reshape(1)), self.norm_factor,
-                                        ticket=self._reduce_ticket)
+                                        None if nf is None else (nf if slots is not None else nf.reshape(1)), self.norm_factor)
         if nf is not None:
             with torch.no_grad():
                 self.norm_factor.mul_(1 - self.momentum).add_(self.momentum * nf)

@@ -288,16 +288,6 @@ int epropnp_mc_loss_reduce(const float* loss, const float* weight, int32_t num_o
                            const float* norm_factor_in, int32_t norm_factor_in_count, int64_t norm_factor_in_stride,
                            float* norm_factor, float* out, void* stream);
 
-/* epropnp_mc_loss_forward followed by epropnp_mc_loss_reduce -- same arguments, same results to the bit -- as ONE launch where the
- * shape is launch-bound (num_obj <= 4096): every workgroup releases its objects' losses at device scope and takes a ticket, the
- * last one reduces.  `ticket`: a device int32 that is ZERO on entry and is left zero (a word the caller keeps per call site: the
- * loss module holds one next to its norm_factor buffer; two launches sharing one ticket must not overlap).  ticket NULL, or more
- * than 4096 objects: the two launches. */
-int epropnp_mc_loss_forward_reduce(const float* logweights, const float* cost_target, int32_t mc_samples, int32_t num_obj,
-                                   float* loss, float* lse, const float* weight, float scale, float momentum,
-                                   const float* norm_factor_in, int32_t norm_factor_in_count, int64_t norm_factor_in_stride,
-                                   float* norm_factor, float* out, int32_t* ticket, void* stream);
-
 /* Send buffer of the Det step's one collective (sharding.ObjectExchange), packed by ONE launch:
  *   send[0 .. n_scalars)            = scalars[i]                       (or, with sum_src != NULL, send[0] = sum_scale * sum(sum_src[0 .. sum_floats)),
  *                                                                      a fixed-order sum -- the detection head's norm_factor input,

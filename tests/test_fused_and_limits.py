@@ -442,55 +442,3 @@ def test_center_and_cost_of_pose_init_are_one_launch(backend, monkeypatch):
     for a, b in zip(outs[True, True], outs[True, False]):
         assert torch.equal(a, b)
     assert (outs[True, True][0] - outs[False, True][0]).abs().max() < 1e-2      # pose_opt in the caller's frame either way
-
-
-@pytest.mark.parametrize('B,S,weighted,nf_ranks', [(5, 16, False, 0), (600, 128, True, 1), (37, 20, True, 3), (4097, 8, False, 1)])
-def test_reduced_loss_behind_a_ticket_is_the_two_launches(backend, monkeypatch, B, S, weighted, nf_ranks):
-    """epropnp_mc_loss_forward_reduce: the per-object pass and the reduce as one launch (the last workgroup to take a ticket
-    reduces) against the two launches it replaces (no ticket; EPROPNP_TUNE=no_loss_ticket): loss, running norm_factor and the
-    gradients agree to the bit, NaN objects included; the ticket is zero again afterwards; > 4096 objects take the two launches."""
-    from epropnp import _hip
-    from epropnp import functional as F
-    g = torch.Generator().manual_seed(B + S)
-    logw = (torch.randn(S, B, generator=g) * 3).to(backend)
-    logw[:, B // 2] = float('nan')
-    ct = torch.randn(B, generator=g).to(backend)
-    w = torch.rand(B, generator=g).to(backend) if weighted else None
-    nf_in = None if nf_ranks == 0 else (torch.rand(nf_ranks * 5, generator=g).to(backend) + 0.5)[::5]
-    if nf_in is not None and nf_ranks == 1:
-        nf_in = nf_in.contiguous()
-    results = []
-    for mode in ('ticket', 'none', 'tuned_off'):
-        set_tune(monkeypatch, **({'no_loss_ticket': True} if mode == 'tuned_off' else {}))
-        lw, c = logw.clone().requires_grad_(True), ct.clone().requires_grad_(True)
-        nf = torch.tensor([1.5], device=backend)
-        ticket = None if mode == 'none' else torch.zeros(1, dtype=torch.int32, device=backend)
-        _hip.profile(enable=True, reset=True)
-        try:
-            loss = F.mc_pose_loss_reduced(lw, c, w, scale=0.7 / B, momentum=0.01, norm_factor_in=nf_in, norm_factor=nf, ticket=ticket)
-            launches = (_hip.profile_read('mc_loss_forward')[1], _hip.profile_read('mc_loss_reduce')[1])
-        finally:
-            _hip.profile(enable=False, reset=True)
-        (loss * 1.3).backward()
-        if ticket is not None:
-            assert int(ticket.item()) == 0
-        assert launches == (1, 0), launches          # ONE host call either way (the library decides how many kernels)
-        assert torch.isfinite(loss)
-        results.append((loss.detach().clone(), nf.clone(), lw.grad.clone(), c.grad.clone()))
-    for other in results[1:]:
-        for a, b in zip(results[0], other):
-            assert torch.equal(a, b)
-    # which path ran: a ticket that does not start at zero is never completed by the one-launch kernel (it stays at start + number
-    # of workgroups, nobody reduces), and is not touched at all by the two launches
-    stale = torch.full((1,), 100000, dtype=torch.int32, device=backend)
-    set_tune(monkeypatch)
-    F.mc_pose_loss_reduced(logw, ct, w, scale=0.7 / B, momentum=0.0, norm_factor=torch.tensor([1.5], device=backend), ticket=stale)
-    assert int(stale.item()) == 100000 + ((B + 15) // 16 if B <= 4096 else 0)
-    # the module keeps its own ticket, outside the state_dict
-    from epropnp.losses import MonteCarloPoseLoss
-    mod = MonteCarloPoseLoss(momentum=0.01).to(backend)
-    assert '_reduce_ticket' not in mod.state_dict() and mod._reduce_ticket.dtype == torch.int32
-    lw = logw.clone().requires_grad_(True)
-    out = mod(lw, ct, torch.tensor(2.0, device=backend))
-    out.backward()
-    assert int(mod._reduce_ticket.item()) == 0 and torch.isfinite(out) and lw.grad is not None
