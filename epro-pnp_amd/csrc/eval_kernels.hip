@@ -97,9 +97,12 @@ __device__ __forceinline__ float resident_cost(const Point (&pts)[PPL], const fl
   for (int k = 0; k < PPL; ++k) {
     // exact Huber form on the IEEE path (matches cost_fun.py:8-12 bit-for-bit per point)
     const Point& q = pts[k];
-    const float hx = KR[0] * q.X + KR[1] * q.Y + KR[2] * q.Z + Kt[0];
-    const float hy = KR[3] * q.X + KR[4] * q.Y + KR[5] * q.Z + Kt[1];
-    const float hz = KR[6] * q.X + KR[7] * q.Y + KR[8] * q.Z + Kt[2];
+    // the fma chains are spelled out: left to -ffp-contract=fast, `a x + b y + c z + t` came out as fma(c, z, fma(a, x, b y)) + t
+    // in the kernel whose loop over poses hoists the pose-independent product b y (4-DoF: KR[1] = K[1]) and as
+    // fma(c, z, fma(b, y, a x)) + t in the one that evaluates a single pose -- the same cost, one ulp apart
+    const float hx = add_unfused(fmaf(KR[2], q.Z, fmaf(KR[1], q.Y, mul_unfused(KR[0], q.X))), Kt[0]);
+    const float hy = add_unfused(fmaf(KR[5], q.Z, fmaf(KR[4], q.Y, mul_unfused(KR[3], q.X))), Kt[1]);
+    const float hz = add_unfused(fmaf(KR[8], q.Z, fmaf(KR[7], q.Y, mul_unfused(KR[6], q.X))), Kt[2]);
     const float z = fmaxf(hz, z_min);
     float px = hx / z, py = hy / z;
     if (BOUNDS) {
@@ -107,7 +110,7 @@ __device__ __forceinline__ float resident_cost(const Point (&pts)[PPL], const fl
       py = clamp_lu(py, bd.lby, bd.uby);
     }
     const float rx = (px - q.u) * q.wu, ry = (py - q.v) * q.wv;
-    c += huber_exact(sqrtf(rx * rx + ry * ry), delta);
+    c += huber_exact(sqrtf(fmaf(rx, rx, mul_unfused(ry, ry))), delta);
   }
   return c;
 }
