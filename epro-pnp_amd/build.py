@@ -27,11 +27,13 @@ _NO_SLP = ['-fno-slp-vectorize']
 FILE_FLAGS = {'lm_kernel.hip': _NO_SLP, 'rslm_kernel.hip': _NO_SLP, 'amis_forward_mfma.hip': _NO_SLP,
               'eval_kernels.hip': _NO_SLP,      # normal_equations 21.6 -> 16.6 us, evaluate_cost 17 -> 13.9 us at C2
               'amis_backward_mfma.hip': _NO_SLP}
-# Translation units that issue v_mfma_f32_16x16x32_bf16: their DEVICE code goes through tools/pk_opsel_fix.py on its way from the
-# compiler to the assembler (the gfx950 erratum of profiles/r05_pk_opsel_erratum.txt: a packed fp32 instruction whose low lane
-# takes src0.lo and src1.hi returns wrong results while such an MFMA executes on the SIMD; swapping the two commuting sources is
-# the same arithmetic in a form that is clean), and the build fails if an unsafe form is left.
-ERRATUM_FILES = ('amis_forward_mfma.hip', 'amis_backward_mfma.hip')
+# The DEVICE code of every translation unit with kernels goes through tools/pk_opsel_fix.py on its way from the compiler to the
+# assembler (the gfx950 erratum of profiles/r05_pk_opsel_erratum.txt: a packed fp32 instruction whose low lane takes src0.lo and
+# src1.hi returns wrong results while a v_mfma_f32_16x16x32_bf16 executes on the SIMD; swapping the two commuting sources is the
+# same arithmetic in a form that is clean).  The build FAILS if a kernel that issues such an MFMA itself keeps the shape (the two
+# *_mfma.hip units); in the others -- which can only meet an MFMA of another stream's kernel -- the few shapes no swap cures stay.
+ERRATUM_FILES = ('amis_forward_mfma.hip', 'amis_backward_mfma.hip', 'amis_kernels.hip', 'gn_step_kernel.hip', 'eval_kernels.hip',
+                 'lm_kernel.hip', 'rslm_kernel.hip')
 LLVM_BIN = os.environ.get('EPROPNP_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
 HEADERS = ['pnp_math.h', 'wave_ops.h', 'pnp_sweep.h', 'pnp_host.h', 'dispatch.h', 'amis_common.h', 'lm_core.h', 'tuning.h']
 

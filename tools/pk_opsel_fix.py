@@ -14,8 +14,10 @@ gives the same arithmetic with the halves taken as (hi, lo) -- a form that is cl
 pair is a factor and the addend (a swap does not help) it refuses: such a shape has to go at the source (amis_backward_mfma.hip
 keeps the camera matrix in vector registers for that reason).
 
-    pk_opsel_fix.py in.s out.s      rewrite; prints how many instructions were swapped; fails on an instruction it cannot fix
+    pk_opsel_fix.py in.s out.s      rewrite; prints how many instructions were swapped and how many it could not fix (left as they are)
     pk_opsel_fix.py --audit in.s    list kernels that contain v_mfma_f32_16x16x32_bf16 AND the unsafe form (exit 1 if any)
+The build runs both on every translation unit: kernels without a matrix instruction are rewritten too (they may share a SIMD with
+one that has, from another stream), only a kernel WITH a bf16 MFMA fails the build.
 """
 import re
 import sys
@@ -85,14 +87,17 @@ def main():
             print(f'{n:3d} unsafe packed fp32 instruction(s) next to v_mfma_f32_16x16x32_bf16 in {k}')
         sys.exit(1 if report else 0)
     src, dst = sys.argv[1], sys.argv[2]
-    out, n = [], 0
+    out, n, left = [], 0, 0
     for line in open(src).read().split('\n'):
         if unsafe(line)[1]:
-            line = fix_line(line)
-            n += 1
+            try:
+                line = fix_line(line)
+                n += 1
+            except SystemExit:
+                left += 1
         out.append(line)
     open(dst, 'w').write('\n'.join(out))
-    print(f'pk_opsel_fix: {n} instruction(s) swapped in {src}')
+    print(f'pk_opsel_fix: {n} instruction(s) swapped, {left} left (no swap helps) in {src}')
 
 
 if __name__ == '__main__':
