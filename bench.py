@@ -162,12 +162,43 @@ def cpu_baseline(N, S, K, L, total_objects=1024, chunk=64, one_thread_objects=16
         ref['source'] = 'profiles/r05_cpu_reference_vs_oracle.json'
     except (OSError, ValueError):
         pass
-    return dict(value=round(value, 2), unit='instances/s', cores=best_threads, kind='port', host_cores=host_cores,
-                procedure=f'BASELINE.md section 3: {total_objects} objects in chunks of {chunk}, 1 warm-up chunk, median of 3 passes',
-                pass_seconds=[round(t, 3) for t in passes], tried_threads_inst_per_s_one_chunk=tried,
-                one_thread=one_thread, all_cores=all_cores, reference_vs_port=ref,
-                sample=f'{total_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd; oracle = PyTorch-CPU restatement with the '
-                       f'reference op structure) in chunks of {chunk} objects on {best_threads} threads; larger CPU chunks are slower per object (256: ~100/s)')
+    port = dict(value=round(value, 2), unit='instances/s', cores=best_threads, kind='port',
+                pass_seconds=[round(t, 3) for t in passes])
+    out = dict(port, host_cores=host_cores,
+               procedure=f'BASELINE.md section 3: {total_objects} objects in chunks of {chunk}, 1 warm-up chunk, median of 3 passes',
+               tried_threads_inst_per_s_one_chunk=tried, one_thread=one_thread, all_cores=all_cores, reference_vs_port=ref,
+               sample=f'{total_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd; oracle = PyTorch-CPU restatement with the '
+                      f'reference op structure) in chunks of {chunk} objects on {best_threads} threads; larger CPU chunks are slower per object (256: ~100/s)')
+    # north_star: "the reference's own PyTorch-CPU solver timed on the host cores".  Where a reference checkout is reachable
+    # ($EPROPNP_REFERENCE, default /root/reference -- the build container; it does not travel to the GPU box) the UNMODIFIED modules
+    # are timed by the same procedure in a process of their own (oracle/cpu_baseline_runner.py) and become the headline: kind
+    # "reference", with the port's figure beside it.
+    timed_ref = reference_cpu_baseline(N, S, K, L, total_objects, chunk, best_threads)
+    if timed_ref is not None:
+        out.update(value=timed_ref['value'], kind='reference', pass_seconds=timed_ref['pass_seconds'], port=port,
+                   sample=f'{total_objects} objects x N={N}, S={S}, K={K}, L={L} (fwd+bwd) through the UNMODIFIED reference modules '
+                          f'({timed_ref["where"]}; epropnp/epropnp.py:87-196) in chunks of {chunk} objects on {best_threads} threads')
+    return out
+
+
+def reference_cpu_baseline(N, S, K, L, total_objects, chunk, threads, bound_s=None):
+    """The unmodified reference timed by oracle/cpu_baseline_runner.py in a subprocess, or None when no checkout is reachable (the
+    GPU box) or the run does not finish within the bound (BENCH_CPU_REFERENCE_BOUND_S, default 240 s)."""
+    import subprocess
+    root = os.environ.get('EPROPNP_REFERENCE', '/root/reference')
+    if not os.path.isdir(os.path.join(root, 'epropnp')):
+        return None
+    bound_s = bound_s or float(os.environ.get('BENCH_CPU_REFERENCE_BOUND_S', '240'))
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'cpu_baseline_runner.py'), 'reference', str(N), str(S), str(K), str(L),
+                            str(total_objects), str(chunk), str(threads)], capture_output=True, text=True, timeout=bound_s)
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        if r.returncode != 0 or 'value' not in res:
+            return None
+        res['where'] = root
+        return res
+    except Exception:
+        return None
 
 
 def hipgraph_replay():
@@ -249,7 +280,64 @@ MAX_SWEEP_SETS = 256           # tiny workloads (C1: 2 KB per set) cannot be rot
 LARGE_SWEEP = (8192, 2048)     # `roofline.large`: the C5-shard Jacobian sweep (470 MB per launch: no cache can serve it)
 
 
-def single_sweep(F, make_problem, pose, bytes_per_set, windows=8):
+class ClockSampler:
+    """Engine clock, memory clock and package power of THE device under test, read from the amdgpu hwmon nodes
+    (/sys/class/drm/card*/device/hwmon/hwmon*/{freq1_input, freq2_input, power1_input}: Hz, Hz, microwatt) by a background thread
+    while a timed window runs -- so that an HBM figure that moves from box to box can be read next to the clocks it was taken at
+    (VERDICT r05 item 7).  The card is matched by PCI address; where sysfs is not readable the record says so."""
+
+    def __init__(self, device_index=0, period_s=0.0005):
+        import glob
+        self.period_s, self.samples, self.dir, self.note = period_s, [], None, None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+            for d in sorted(glob.glob('/sys/class/drm/card*/device')):
+                if os.path.basename(os.path.realpath(d)) == want:
+                    hw = sorted(glob.glob(os.path.join(d, 'hwmon', 'hwmon*')))
+                    if hw and os.path.exists(os.path.join(hw[0], 'freq1_input')):
+                        self.dir, self.pci = hw[0], want
+            if self.dir is None:
+                self.note = f'no amdgpu hwmon node for PCI device {want}'
+        except Exception as e:      # no sysfs, no such attribute: the record says so
+            self.note = f'{type(e).__name__}: {e}'
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return int(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+        if self.dir is not None:
+            def run():
+                while not self._stop.is_set():
+                    self.samples.append((self._read('freq1_input'), self._read('freq2_input'), self._read('power1_input')))
+                    self._stop.wait(self.period_s)
+            self._thread = threading.Thread(target=run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.dir is not None:
+            self._thread.join()
+
+    def summary(self):
+        if self.dir is None:
+            return {'available': False, 'note': self.note}
+
+        def stat(i, scale):
+            v = [s[i] / scale for s in self.samples if s[i] is not None]
+            return None if not v else {'min': round(min(v), 1), 'mean': round(sum(v) / len(v), 1), 'max': round(max(v), 1)}
+        return {'available': True, 'source': f'{self.dir} (PCI {self.pci})', 'samples': len(self.samples),
+                'sclk_mhz': stat(0, 1e6), 'mclk_mhz': stat(1, 1e6), 'power_w': stat(2, 1e6)}
+
+
+def single_sweep(F, make_problem, pose, bytes_per_set, windows=32):
     """normal_equations_kernel alone (one logical sweep = one physical read of the correspondences), IC-COLD: the launches
     rotate over `sets` distinct copies of the problem buffers, > 2x the 256 MiB Infinity Cache in total, so that a set has
     been evicted long before it comes round again and every read is served by HBM (back-to-back launches on ONE 59 MB set
@@ -261,16 +349,21 @@ def single_sweep(F, make_problem, pose, bytes_per_set, windows=8):
         for hp in probs:        # host-side pause that follows the step loop
             F.normal_equations(hp, pose)
     evs = []
-    for _ in range(windows):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for hp in probs:
-            F.normal_equations(hp, pose)
-        e1.record()
-        evs.append((e0, e1))
-    torch.cuda.synchronize()
+    with ClockSampler() as clk:
+        for _ in range(windows):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for hp in probs:
+                F.normal_equations(hp, pose)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) / sets for a, b in evs)
+    LAST_SWEEP_CLOCKS[0] = clk.summary()
     return sum(ts) / len(ts), ts[len(ts) // 2], sets
+
+
+LAST_SWEEP_CLOCKS = [None]      # clocks / power sampled during the most recent single_sweep (bench line: roofline.clocks)
 
 
 def main(argv=None, device=None, backend='nccl'):
@@ -288,6 +381,8 @@ def main(argv=None, device=None, backend='nccl'):
     ap.add_argument('--amis-iters', type=int, default=None)
     ap.add_argument('--lm-iters', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='time the cpu_baseline leg of the chosen config and print it; needs no GPU (kind "reference" where a checkout is reachable)')
     ap.add_argument('--no-hipgraph', action='store_true', help='skip the informational hipGraph replay measurement')
     ap.add_argument('--cpu-sample', type=int, default=1024, help='objects of the workload the cpu_baseline leg times (in chunks of 64)')
     ap.add_argument('--no-large-sweep', action='store_true',
@@ -306,6 +401,12 @@ def main(argv=None, device=None, backend='nccl'):
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
     default_shape = all(cfg[k] == CONFIGS[args.config][k] for k in cfg)
+    if args.cpu_baseline_only:       # the host-core baseline alone (no device touched): kind "reference" where a checkout is reachable
+        Nc, Sc, Kc, Lc = cfg['points'], cfg['samples'], cfg['amis_iters'], cfg['lm_iters']
+        res = (cpu_baseline(Nc, Sc, Kc, Lc, args.cpu_sample) if args.config != 'C5'
+               else cpu_baseline(Nc, Sc, Kc, Lc, total_objects=8, chunk=8, one_thread_objects=2))
+        print(json.dumps({'cpu_baseline': res, 'config': args.config}))
+        return res
 
     # plain `python bench.py --gpus N`: spawn the N ranks ourselves (BENCH_SELF_LAUNCH=1 takes this route for N = 1 too)
     if (args.gpus > 1 or os.environ.get('BENCH_SELF_LAUNCH') == '1') and 'RANK' not in os.environ:
@@ -633,6 +734,7 @@ def main(argv=None, device=None, backend='nccl'):
         mk = lambda: F.PnPProblem(x3d.detach().clone(), x2d.detach().clone(), w2d.detach().clone(), camera, cost_fun, dof)
         ne_mean_ms, ne_median_ms, ne_sets = single_sweep(F, mk, prob['pose_init'], ne_bytes)
         ne_gbs = ne_bytes / (ne_mean_ms * 1e-3) / 1e9
+        ne_clocks = LAST_SWEEP_CLOCKS[0]
         ne_traffic, ne_src = measured_traffic('normal_equations_kernel', shape_key) if shape_key else (None, None)
         names = {'C2': 'C2 batched synthetic', 'C5': 'C5 stress (one shard per GPU)', 'C4': 'C4 EPro-PnP-Det nuScenes shape',
                  'C1': 'C1 demo/fit_identity.ipynb plumbing case', 'C3': 'C3 EPro-PnP-6DoF LineMOD shape, dense 64x64 crops',
@@ -649,13 +751,13 @@ def main(argv=None, device=None, backend='nccl'):
             lcf = AdaptiveHuberPnPCost(relative_delta=0.5)
             lcf.set_param(lp['x2d'], lp['w2d'])
             lmk = lambda: F.PnPProblem(lp['x3d'].clone(), lp['x2d'].clone(), lp['w2d'].clone(), lcam, lcf, 6)
-            l_mean, l_med, l_sets = single_sweep(F, lmk, lp['pose_init'], l_bytes, windows=6)
+            l_mean, l_med, l_sets = single_sweep(F, lmk, lp['pose_init'], l_bytes, windows=12)
             l_traffic, l_src = measured_traffic('normal_equations_kernel', f'C5:B{LB}:N{LN}:S1024:K4:L3')
             large = {'workload': f'{LB} objects x N={LN} points (the C5 shard), one Jacobian sweep', 'achieved': round(l_bytes / (l_mean * 1e-3) / 1e9, 1),
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(l_bytes / (l_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      'algorithmic_bytes_per_launch': l_bytes, 'launch_ms': round(l_mean, 5), 'launch_ms_median': round(l_med, 5),
                      'cache_state': f'IC-cold: {l_sets} copies x {l_bytes / 2 ** 20:.0f} MiB', 'traffic': l_traffic,
-                     'traffic_source': l_src}
+                     'traffic_source': l_src, 'clocks': LAST_SWEEP_CLOCKS[0]}
             del lp, lmk
         par = (f'one batch of {total} objects split x{world} ({B} on rank 0), ONE all_gather_into_tensor (pose outputs + '
                f'norm_factor) inside the step') if strong else f'objects sharded x{world}, no data-path collective'
@@ -700,6 +802,8 @@ def main(argv=None, device=None, backend='nccl'):
                          'traffic': ne_traffic, 'traffic_source': ne_src,
                          'algorithmic_bytes_per_launch': ne_bytes,
                          'launch_ms': round(ne_mean_ms, 5), 'launch_ms_median': round(ne_median_ms, 5),
+                         # engine / memory clock and package power sampled from the amdgpu hwmon nodes WHILE the windows above ran
+                         'clocks': ne_clocks,
                          'fused_lm': {'kernel': 'lm_solve_kernel (1+L Jacobian sweeps in one launch, points read once)',
                                       'launch_ms': round(t_lm, 4),
                                       'physical_frac': None if lm_traffic is None else round(lm_traffic / (t_lm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -35,7 +35,7 @@ namespace pnp {
 // known-bad shape in a kernel with a bf16 MFMA (tools/pk_opsel_fix.py --audit, run by the build), and every instantiation passes the
 // repeated-launch test at full occupancy (tests/test_determinism_gpu.py) -- a defect of this kind is invisible to a tolerance.
 template <int DOF, bool BOUNDS, int NPT, bool BF16>
-constexpr int bwd_min_waves() { return (BOUNDS && BF16 && NPT == 4) ? 2 : PNP_BWD_MINW; }
+constexpr int bwd_min_waves() { return (BOUNDS && BF16 && NPT == 4) ? PNP_BWD_BND_MINW : PNP_BWD_MINW; }
 
 template <int DOF, bool BOUNDS, int NPT, bool BF16 = false>
 __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) void amis_backward_mfma_kernel(Problem p, const float* __restrict__ pose_samples,
@@ -62,9 +62,10 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
   int* idx = reinterpret_cast<int*>(wraw + P16);        // [P16]      sample index of compacted pose c
   float* red = reinterpret_cast<float*>(idx + P16);     // [80]       reductions, lane counts, active count
   float* hist = red + 80;                               // [kDropHistFloats] weight histogram of the drop threshold
+  int* tnear = reinterpret_cast<int*>(hist + kDropHistFloats);      // [P16 / 16]  1: a pair of (pose tile, object) may reach the depth clamp
   // [gw_rows][2] this object's grad_w2d, parked until the threshold's gradient (one number per object, known only after the
   // last chunk) can be added on the way out: the fold below then costs no second pass over grad_w2d in global memory
-  float* gwl = hist + kDropHistFloats;
+  float* gwl = reinterpret_cast<float*>(tnear + (P16 >> 4));
   const bool fold = (p.delta_stats != nullptr) && (nsplit == 1);
   const bool park = fold && (gw_rows >= p.N);
 
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
   const float front_scale = to_vgpr(0x1p60f);
   const float front_off = to_vgpr(-nextafterf(p.z_min, -1.0f) * 0x1p60f);
   const float tiny_v = to_vgpr(1e-30f);     // keeps rsq finite at a zero residual; folded into the norm's first fma
+  const float zmin_margin = p.z_min * 1.001f + 1e-6f;
 
   const bool with_init = (pose_init != nullptr) && (g_init != nullptr);
   const int P = S + (with_init ? 1 : 0);      // pose index S = pose_init
@@ -97,6 +99,15 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
     if (m < S) amax = fmaxf(amax, fabsf(w));
   }
   amax = block_max(amax, red);          // (barriers inside: wraw is visible to every wave afterwards)
+  __syncthreads();
+  // |X| <= Robj for every point of the OBJECT (not of this workgroup's share: the choice it feeds below must not depend on how the
+  // points are dealt to workgroups and waves).  +inf / NaN coordinates: Robj = +inf or the finite rest; see the tile bounds.
+  float r2obj = 0.f;
+  for (int n = tid; n < p.N; n += T) {
+    const float* X = p.x3d + ((size_t)b * p.N + n) * 3;
+    r2obj = fmaxf(r2obj, fmaf(X[0], X[0], fmaf(X[1], X[1], X[2] * X[2])));
+  }
+  const float Robj = sqrtf(block_max(r2obj, red));
   __syncthreads();
   PNP_PHASE(0);
   const float askip = mass_drop_threshold([&](int m) { return fabsf(wraw[m]); }, S, amax, drop_eps, hist);
@@ -148,6 +159,24 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
     }
   }
   __syncthreads();
+  // Which pose tiles can reach the depth clamp: h_z = (K R_j)_3 . X + (K t_j)_z >= (K t_j)_z - |(K R_j)_3| |X|, so against a tile
+  // with min_j (K t_j)_z - max_j |(K R_j)_3| Robj > z_min (+ a margin for the rounding of the projection) no pair of the object
+  // needs max(h_z, z_min) or the clamp's 0/1 gradient factor.  A function of the object and the tile only.
+  for (int t = tid; t < ntile; t += T) {
+    float zlo = 3.0e38f, kn2 = 0.f;
+    bool finite = true;
+    for (int r = 0; r < 16; ++r) {
+      const float4 rz = *reinterpret_cast<const float4*>(ptab + 12 * (t * 16 + r) + 8);
+      const float n2 = fmaf(rz.x, rz.x, fmaf(rz.y, rz.y, rz.z * rz.z));
+      zlo = fminf(zlo, rz.w);
+      kn2 = fmaxf(kn2, n2);
+      finite = finite && (fabsf(rz.w) < 3.0e38f) && (n2 < 3.0e38f);        // (false for NaN as well)
+    }
+    const float reach = sqrtf(kn2) * Robj;
+    const bool clear = finite && ((zlo - reach) > fmaf(1e-3f, fabsf(zlo) + reach, zmin_margin));      // (NaN / inf reach: false)
+    tnear[t] = clear ? 0 : 1;
+  }
+  __syncthreads();
   PNP_PHASE(3);
 
   const int col = lane & 15, kk = lane >> 4, g4 = kk * 4;
@@ -168,8 +197,15 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
       A1x[i] = A1y[i] = A2x[i] = A2y[i] = 0.f;
       gXv[i] = gYv[i] = gZv[i] = 0.f;
     }
+    float gsat = 0.f;           // sum_pairs a_j min(|r|^2, 1): the second term of d/d delta (below)
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < ntile; ++t) {
+    // One pose tile against this wave's point tiles.  NEAR = false: every depth h_z of the tile's pairs is known to lie in front of
+    // z_min (tnear above), so max(h_z, z_min) = h_z and the clamp's 0/1 gradient factor is 1: three instructions per pair less.
+    // The clear tiles are swept first, then the few that may reach the clamp (two loops: one loop holding both bodies cost the
+    // four-tile instantiation 18 VGPRs and its place at three waves per SIMD); tnear depends on the object and the tile only, so a
+    // point's sums run over the poses in the same order however the points are dealt to workgroups and waves.
+    auto tile = [&](int t, auto NEARC) {
+      constexpr bool NEAR = decltype(NEARC)::value;
       const float* arow = ptab + 12 * (t * 16 + col) + kk;
       const typename Proj::T ax = Proj::a(arow[0]), ay = Proj::a(arow[4]), az = Proj::a(arow[8]);
       const float4 a4 = *reinterpret_cast<const float4*>(wtab + t * 16 + g4);
@@ -188,26 +224,49 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
         const float4 w4 = rW[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float front = sat_fma(hz[r], front_scale, front_off);
-          const float zc = clamp_below(hz[r], zmin_v);
+          const float zc = NEAR ? clamp_below(hz[r], zmin_v) : hz[r];
           const float rz = fast_rcp(zc);
-          const float ppx = hx[r] * rz, ppy = hy[r] * rz;          // un-clamped projection
-          float px = ppx, py = ppy;
-          if (BOUNDS) {
-            px = clamp_lu(px, bd.lbx, bd.ubx);
-            py = clamp_lu(py, bd.lby, bd.uby);
-          }
-          const float rx = fmaf(px, w4.x, w4.z), ry = fmaf(py, w4.y, w4.w);
-          const float s2 = fmaf(rx, rx, fmaf(ry, ry, tiny_v));   // |r|^2 + 1e-30: one v_max less per pair than clamping
-          const float rs = fast_rsqrt(s2);
+          float rx, ry, ghx, ghy, ghz, crx, cry, coef;
           // Huber weight min(1, delta / rho) = min(1, rs) straight from the reciprocal norm (rho * rs = 1): ONE clamped
-          // multiply where rho, min(rho, 1) and their product with rs took three.  d huber / d delta = max(rho - delta, 0)
-          // (/ delta) = rho (1 - c1): exactly 0 for an inlier (c1 = 1), as in the reference.
-          const float c1 = sat_mul(rs, one_v);
-          const float coef = aw[r] * c1;
-          const float rho = s2 * rs;
-          gd = fmaf(aw[r], fmaf(-rho, c1, rho), gd);
-          const float crx = coef * rx, cry = coef * ry;
+          // multiply where rho, min(rho, 1) and their product with rs took three.
+          // d huber / d delta = max(rho - delta, 0) (/ delta) = coef |r|^2 - a min(|r|^2, 1) (residuals in units of delta; outlier:
+          // a rho - a, inlier: a rho^2 - a rho^2 = 0): the first term is what A2x + A2y accumulate anyway, the second costs one clamped
+          // multiply and one fma per pair (`gsat`) where rho, rho (1 - c1) and the accumulation took three.
+          if (!BOUNDS) {
+            // no projection clamp: the weight goes into the reciprocal depth once (w / z), which serves the residual and the
+            // gradient w.r.t. (h_x, h_y) -- one multiply per pair less than projecting first
+            const float wrx = w4.x * rz, wry = w4.y * rz;
+            rx = fmaf(hx[r], wrx, w4.z);
+            ry = fmaf(hy[r], wry, w4.w);
+            const float s2 = fmaf(rx, rx, fmaf(ry, ry, tiny_v));   // |r|^2 + 1e-30: one v_max less per pair than clamping
+            const float c1 = sat_mul(fast_rsqrt(s2), one_v);
+            coef = aw[r] * c1;
+            gsat = fmaf(aw[r], sat_mul(s2, one_v), gsat);
+            crx = coef * rx;
+            cry = coef * ry;
+            ghx = crx * wrx;
+            ghy = cry * wry;
+            ghz = -rz * fmaf(ghx, hx[r], ghy * hy[r]);             // = -(ghx p_x + ghy p_y)
+          } else {
+            const float ppx = hx[r] * rz, ppy = hy[r] * rz;        // un-clamped projection
+            const float px = clamp_lu(ppx, bd.lbx, bd.ubx), py = clamp_lu(ppy, bd.lby, bd.uby);
+            rx = fmaf(px, w4.x, w4.z);
+            ry = fmaf(py, w4.y, w4.w);
+            const float s2 = fmaf(rx, rx, fmaf(ry, ry, tiny_v));
+            const float c1 = sat_mul(fast_rsqrt(s2), one_v);
+            coef = aw[r] * c1;
+            gsat = fmaf(aw[r], sat_mul(s2, one_v), gsat);
+            crx = coef * rx;
+            cry = coef * ry;
+            float gpx = crx * w4.x, gpy = cry * w4.y;
+            gpx = (px == ppx) ? gpx : 0.f;     // the clamp passes no gradient where it is active: inside [lb, ub] <=> clamp(x) == x
+            gpy = (py == ppy) ? gpy : 0.f;
+            ghx = gpx * rz;
+            ghy = gpy * rz;
+            ghz = fmaf(-ghx, ppx, -(ghy * ppy));
+          }
+          // "in front of the depth clamp" as a 0/1 factor from ONE full-rate instruction (front_scale above)
+          if (NEAR) ghz *= sat_fma(hz[r], front_scale, front_off);
           // d/dw = crx * (px - u) = crx * rx / w and d/du = -crx * w: the per-point factors are applied once at the end
           A2x[i] = fmaf(crx, rx, A2x[i]);
           A2y[i] = fmaf(cry, ry, A2y[i]);
@@ -215,18 +274,21 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
           // chunk kept `A1 += round(coef r)`, and the same point came out 1 ulp apart in the split and the unsplit launch)
           A1x[i] = fmaf(coef, rx, A1x[i]);
           A1y[i] = fmaf(coef, ry, A1y[i]);
-          float gpx = crx * w4.x, gpy = cry * w4.y;
-          if (BOUNDS) {                  // the clamp passes no gradient where it is active: inside [lb, ub] <=> clamp(x) == x
-            gpx = (px == ppx) ? gpx : 0.f;
-            gpy = (py == ppy) ? gpy : 0.f;
-          }
-          const float ghx = gpx * rz, ghy = gpy * rz;
-          const float ghz = fmaf(-ghx, ppx, -(ghy * ppy)) * front;
           gXv[i] = fmaf(krx[r].x, ghx, fmaf(kry[r].x, ghy, fmaf(krz[r].x, ghz, gXv[i])));
           gYv[i] = fmaf(krx[r].y, ghx, fmaf(kry[r].y, ghy, fmaf(krz[r].y, ghz, gYv[i])));
           gZv[i] = fmaf(krx[r].z, ghx, fmaf(kry[r].z, ghy, fmaf(krz[r].z, ghz, gZv[i])));
         }
       }
+    };
+    for (int t = 0; t < ntile; ++t)
+      if (wave_uniform(tnear[t] == 0)) tile(t, std::false_type{});
+    for (int t = 0; t < ntile; ++t)
+      if (wave_uniform(tnear[t] != 0)) tile(t, std::true_type{});
+    {   // d/d delta of this chunk: sum_pairs coef |r|^2 (= the sums behind d/dw, before their per-point factors) - sum_pairs a min(|r|^2, 1)
+      float a2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) a2 += A2x[i] + A2y[i];
+      gd += a2 - gsat;
     }
     // ---- outputs of this chunk: sums over the 4 pose groups of a point via MFMAs against indicator columns ----
     // The lane geometry is re-derived here behind an opaque copy of the lane index: as invariants of the chunk loop the four
@@ -303,7 +365,7 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
   const Problem d = to_device_problem(prob);
   const int P = mc_samples + ((pose_init && grad_cost_init) ? 1 : 0);
   const int P16 = ((P + 15) / 16) * 16 + 16;
-  size_t smem = sizeof(float) * (15 * (size_t)P16 + 80 + kDropHistFloats);
+  size_t smem = sizeof(float) * (15 * (size_t)P16 + 80 + kDropHistFloats + (size_t)(P16 >> 4));
   if (smem > 160 * 1024) return 1;
   // grad_w2d rows parked in LDS while the threshold's gradient is folded in (kernel comment): when the fold applies and the
   // rows fit next to three workgroups' pose tables per CU

@@ -17,6 +17,9 @@
 #ifndef PNP_FWD_MINW       // waves per SIMD the fp32-projection 6-DoF forward is compiled for (the bf16 one: 3)
 #define PNP_FWD_MINW 4
 #endif
+#ifndef PNP_BWD_BND_MINW   // ... of its instantiation with a projection clamp, four resident tiles and the split projection
+#define PNP_BWD_BND_MINW 3
+#endif
 #ifndef PNP_BWD_MINW       // waves per SIMD of the MFMA backward with <= 4 resident point tiles
 #define PNP_BWD_MINW 3
 #endif
