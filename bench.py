@@ -417,6 +417,13 @@ def main(argv=None, device=None, backend='nccl'):
     on_gpu = device is None
     if on_gpu:
         assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback)'
+        have, local_world = torch.cuda.device_count(), int(os.environ.get('LOCAL_WORLD_SIZE', '1'))
+        if have <= local_rank or have < local_world:
+            # a launcher asked for more ranks than this node shows devices: say so in one line and leave BEFORE the rendezvous
+            # (a rank that dies inside init_process_group leaves its peers waiting for the timeout)
+            sys.stderr.write(f'bench.py: rank {rank} (local rank {local_rank} of {local_world}) finds {have} visible HIP device(s): '
+                             f'--gpus {args.gpus} needs one device per rank (check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)\n')
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         dev = torch.device('cuda', local_rank)
     else:
@@ -630,12 +637,21 @@ def main(argv=None, device=None, backend='nccl'):
         # of ones, and every rank's device index / step time gathered over RCCL
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
-        mine = torch.tensor([float(rank), float(torch.cuda.current_device() if on_gpu else rank), my_ms], device=dev, dtype=torch.float64)
-        allr = torch.empty(world * 3, device=dev, dtype=torch.float64)
+        # (the PHYSICAL device of a rank: its PCI address -- under per-rank HIP_VISIBLE_DEVICES every rank calls its device "0")
+        pci = rank
+        if on_gpu:
+            pr = torch.cuda.get_device_properties(dev)
+            pci = (int(pr.pci_domain_id) << 16) | (int(pr.pci_bus_id) << 8) | int(pr.pci_device_id)
+        mine = torch.tensor([float(rank), float(torch.cuda.current_device() if on_gpu else rank), my_ms, float(pci)], device=dev, dtype=torch.float64)
+        allr = torch.empty(world * 4, device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(allr, mine)
-        allr = allr.view(world, 3).cpu()
+        allr = allr.view(world, 4).cpu()
+        pcis = [int(v) for v in allr[:, 3]]
+        assert len(set(pcis)) == world, f'{world} ranks on {len(set(pcis))} distinct devices: {pcis} (two ranks share a GPU)'
         ranks.update(process_group=dist.get_backend(), rccl_world_size=dist.get_world_size(), all_reduce_of_ones=float(ones),
-                     devices=[int(v) for v in allr[:, 1]], device_name=torch.cuda.get_device_name(dev) if on_gpu else 'cpu (test hook)',
+                     devices=[int(v) for v in allr[:, 1]],
+                     pci_addresses=[f'{v >> 16:04x}:{(v >> 8) & 0xff:02x}:{v & 0xff:02x}.0' for v in pcis] if on_gpu else None,
+                     device_name=torch.cuda.get_device_name(dev) if on_gpu else 'cpu (test hook)',
                      ms_per_step_per_rank=[round(float(v), 4) for v in allr[:, 2]],
                      ms_per_step_min=round(float(allr[:, 2].min()), 4), ms_per_step_max=round(float(allr[:, 2].max()), 4))
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -517,13 +517,6 @@ struct AmisCtx {
   float* rred;    // [kRefitRedFloats] scratch of the refit's single-wave transposed reductions (nullptr: DPP / readlane chains)
   int S, K, s, T, tid, b;
   int cstride;    // row stride of cpart (s, or s rounded up to 16 for the MFMA kernel)
-  // Depth-clamp bookkeeping of the MFMA sweep (nullptr: off): r2w[0 .. T/64) = max |X|^2 over the object's points, one slot per wave
-  // (their maximum is robj^2), then at r2w + 8 the int flags tnear[t]: some pair of (pose tile t, object) may have a depth
-  // h_z = (K R)_3 . X + (K t)_z below z_min.  amis_draw sets the flag of the tile of every sample whose lower bound
-  // (K t)_z - |(K R)_3| robj does not clear z_min (+ a margin for the rounding of the projection).  Flags are only ever SET: a tile
-  // that once held such a sample keeps the general sweep body (same results, one instruction per pair more), which spares a
-  // reset and its barrier per iteration -- such samples are the far tail of the proposals.
-  float* r2w = nullptr;
 };
 
 // Base draws of sample m of object b: 3 normals + Chi2(3) for the Student-t translation, 4 normals for the ACG
@@ -668,13 +661,6 @@ PNP_FN void amis_draw(const AmisCtx& cx, const Problem& p, const AmisParams& a, 
       row[0] = make_float4(KR[0], KR[1], KR[2], Kt[0]);
       row[1] = make_float4(KR[3], KR[4], KR[5], Kt[1]);
       row[2] = make_float4(KR[6], KR[7], KR[8], Kt[2]);
-      if (cx.r2w != nullptr) {
-        float r2 = 0.f;
-        for (int w = 0; w < (T >> 6); ++w) r2 = fmaxf(r2, cx.r2w[w]);
-        const float reach = sqrtf(fmaf(KR[6], KR[6], fmaf(KR[7], KR[7], KR[8] * KR[8])) * r2);
-        const bool clear = (Kt[2] - reach) > fmaf(1e-3f, fabsf(Kt[2]) + reach, fmaf(p.z_min, 1.001f, 1e-6f));   // (NaN / inf: not clear)
-        if (!clear) atomicOr(reinterpret_cast<int*>(cx.r2w + 8) + ((n - n0) >> 4), 1);
-      }
     }
   }
 

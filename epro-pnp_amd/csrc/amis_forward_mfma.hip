@@ -38,8 +38,7 @@ namespace pnp {
 // the pose's sum by delta^2 once.
 // FOLDED: hx, hy are the MFMA results against the point's B operand pre-scaled by wu / wv (register mode without a
 // projection clamp), so the residual is ONE fma per coordinate: r = (wu h_x) / z - u wu.
-// NEAR = false: the caller knows every depth of the tile to lie in front of z_min (AmisCtx.tnear), max(h_z, z_min) = h_z.
-template <bool BOUNDS, bool FOLDED = false, bool NEAR = true>
+template <bool BOUNDS, bool FOLDED = false>
 __device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& hy, const floatx4& hz, const float4& w4,
                                              float zmin_v, float one_v, const Bounds& bd, f32x2 (&acc2)[2]) {
   static_assert(!(BOUNDS && FOLDED), "the clamp acts on the un-weighted projection");
@@ -48,7 +47,7 @@ __device__ __forceinline__ void huber_cost_4(const floatx4& hx, const floatx4& h
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     // z = max(h_z, z_min) as one instruction (compare+select measured 3.4 ns per pair against 1.8 ns, tools/ubench)
-    const float z0 = NEAR ? clamp_below(hz[2 * h], zmin_v) : hz[2 * h], z1 = NEAR ? clamp_below(hz[2 * h + 1], zmin_v) : hz[2 * h + 1];
+    const float z0 = clamp_below(hz[2 * h], zmin_v), z1 = clamp_below(hz[2 * h + 1], zmin_v);
     const f32x2 rz2 = {fast_rcp(z0), fast_rcp(z1)};
     const f32x2 hx2 = {hx[2 * h], hx[2 * h + 1]}, hy2 = {hy[2 * h], hy[2 * h + 1]};
     f32x2 rx2, ry2;
@@ -160,9 +159,6 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   float* rred = red + 256;               // [kRefitRedFloats] the refit's transposed reductions (amis_common.h: wave_sum_t)
   float* nzb = (s <= T) ? ptab : rred + kRefitRedFloats;   // [s][8] base noise drawn ahead; shares the pose table's LDS when
                                               // one sample per lane suffices (amis_draw separates the two uses)
-  // register mode: [8] the waves' max |X|^2 over the object's points | [s16 / 16] "this pose tile may reach the depth clamp" (AmisCtx.r2w)
-  float* r2w = rred + kRefitRedFloats + ((s <= T) ? 0 : 8 * s);
-  int* tnear = (kRegs && !SPILL) ? reinterpret_cast<int*>(r2w + 8) : nullptr;
 
   float Kc[9], delta;
   Bounds bd;
@@ -181,24 +177,6 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
 
   if (!tiled)
     for (int i = tid; i < 12 * (s16 - s); i += T) ptab[12 * s + i] = 0.f;   // padding poses of the last pose tile
-  if (tnear != nullptr) {
-    // a tile with padding poses (zero rows: depth 0) keeps the general body; the others start clear and are flagged by amis_draw
-    for (int t = tid; t < (s16 >> 4); t += T) tnear[t] = (t * 16 + 16 > s) ? 1 : 0;
-    // |X| <= robj over ALL points of the object (not this workgroup's share of them: every part of a split object must make the
-    // same choices).  Waves 1.. do it (wave 0 goes straight to the proposal fit); the W maxima meet behind the barrier below.
-    if (W == 1 || wv > 0) {
-      const int T1 = (W == 1) ? T : T - 64, t1 = (W == 1) ? tid : tid - 64;
-      float r2 = 0.f;
-      for (int n = t1; n < p.N; n += T1) {
-        const float* X = p.x3d + ((size_t)b * p.N + n) * 3;
-        r2 = fmaxf(r2, fmaf(X[0], X[0], fmaf(X[1], X[1], X[2] * X[2])));
-      }
-      r2 = wave_max(r2);
-      if (lane == 0) r2w[wv] = r2;
-    } else if (lane == 0) {
-      r2w[0] = 0.f;
-    }
-  }
   if (tid < (DOF == 6 ? 2 : 1))      // 6-DoF: lane 1 fits the translation factor inside lane 0's rotation fit
     initial_fit<DOF>(pose_opt + (size_t)b * PL, pose_cov + (size_t)b * DOF * DOF, a.eps, a.dispersion, prop, tid);
   if (part == 0 && tid == T - 1) denormalise_pose_opt<DOF>(a, pose_opt, b);      // (a lane of the last wave: wave 0 is busy with the fit)
@@ -234,52 +212,39 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
   }
   amis_base_noise<DOF>(cx, a, 0, 64);     // waves 1.. draw the first iteration's base noise while lane 0 fits proposal 0
   __syncthreads();
-  if (tnear != nullptr) cx.r2w = r2w;
 
   const int g4 = (lane >> 4) * 4, col = lane & 15, kk = lane >> 4;
   // register mode: every pose tile of the iteration against the point tiles in this wave's registers -> cpart[wv][pose]
   // (issuing the next pose tile's first MFMAs ahead of the current tile's VALU work, to fill the wait states at the
   // head of this loop, was measured: 0.655 vs 0.641 ms at C2 -- the hand-off copies cost more than the s_nops)
-  auto sweep_tile = [&](int t, bool accumulate, auto NEARC) {
-    constexpr bool NEAR = decltype(NEARC)::value;
-    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-    const float* arow = ptab + 12 * (t * 16 + col) + kk;
-    const typename Proj::T ax = Proj::a(arow[0]), ay = Proj::a(arow[4]), az = Proj::a(arow[8]);
-    f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-#pragma unroll
-    for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
-      floatx4 hx, hy, hz;
-      if constexpr (kFold) {
-        hx = mfma_16x16x4(ax, rW[i].x, zero);
-        hy = mfma_16x16x4(ay, rW[i].y, zero);
-        hz = mfma_16x16x4(az, rB[i], zero);
-      } else {
-        hx = Proj::mma(ax, rB[i], zero);
-        hy = Proj::mma(ay, rB[i], zero);
-        hz = Proj::mma(az, rB[i], zero);
-      }
-      huber_cost_4<BOUNDS, kFold, NEAR>(hx, hy, hz, rW[i], zmin_v, one_v, bd, acc2);
-    }
-    // the four poses' sums over this row's 16 points: lane col < 4 ends up with pose g4 + col (wave_ops.h: row_sum16_of4)
-    const float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
-    const float tot = row_sum16_of4(acc);
-    if (col < 4) {
-      float* dst = cpart + wv * s16 + t * 16 + g4 + col;
-      if constexpr (CHUNKED) *dst = accumulate ? fmaf(tot, delta_sq, *dst) : tot * delta_sq;
-      else *dst = tot * delta_sq;
-    }
-  };
-  // The pose tiles whose depths all clear z_min first (no depth clamp in their pairs: one instruction per pair less), then the few
-  // that may reach it (cx.tnear; every tile writes its own costs, so the order is free; two loops because one loop holding both
-  // bodies costs registers the eight-tile instantiation does not have).
   auto sweep_regs = [&](bool accumulate = false) {      // accumulate: a later chunk of the same iteration adds to the wave's row
-    if (tnear == nullptr) {
-      for (int t = 0; t < (s16 >> 4); ++t) sweep_tile(t, accumulate, std::true_type{});
-    } else {
-      for (int t = 0; t < (s16 >> 4); ++t)
-        if (wave_uniform(tnear[t] == 0)) sweep_tile(t, accumulate, std::false_type{});
-      for (int t = 0; t < (s16 >> 4); ++t)
-        if (wave_uniform(tnear[t] != 0)) sweep_tile(t, accumulate, std::true_type{});
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < (s16 >> 4); ++t) {
+      const float* arow = ptab + 12 * (t * 16 + col) + kk;
+      const typename Proj::T ax = Proj::a(arow[0]), ay = Proj::a(arow[4]), az = Proj::a(arow[8]);
+      f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
+        floatx4 hx, hy, hz;
+        if constexpr (kFold) {
+          hx = mfma_16x16x4(ax, rW[i].x, zero);
+          hy = mfma_16x16x4(ay, rW[i].y, zero);
+          hz = mfma_16x16x4(az, rB[i], zero);
+        } else {
+          hx = Proj::mma(ax, rB[i], zero);
+          hy = Proj::mma(ay, rB[i], zero);
+          hz = Proj::mma(az, rB[i], zero);
+        }
+        huber_cost_4<BOUNDS, kFold>(hx, hy, hz, rW[i], zmin_v, one_v, bd, acc2);
+      }
+      // the four poses' sums over this row's 16 points: lane col < 4 ends up with pose g4 + col (wave_ops.h: row_sum16_of4)
+      const float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
+      const float tot = row_sum16_of4(acc);
+      if (col < 4) {
+        float* dst = cpart + wv * s16 + t * 16 + g4 + col;
+        if constexpr (CHUNKED) *dst = accumulate ? fmaf(tot, delta_sq, *dst) : tot * delta_sq;
+        else *dst = tot * delta_sq;
+      }
     }
   };
   PNP_PHASE(0);
@@ -536,7 +501,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
   auto lds_bytes = [&](bool spilled) {
     return sizeof(float) * (12 * (size_t)sh.s16 + 8 * (size_t)sh.chunk + (spilled ? 0 : (((size_t)(PL + 3) * S + 3) & ~(size_t)3)) +
                             (size_t)(npt ? (G > 1 ? waves + G : waves) : 1) * sh.s16 + (G > 1 ? 4 : 0) + (size_t)K * kPropStride + 256 +
-                            kRefitRedFloats + (size_t)(sh.s16 >> 4) + 8 +        // (+ tnear, r2w: register mode)
+                            kRefitRedFloats +
                             ((s <= 64 * waves || !sh.ahead) ? 0 : 8 * (size_t)s));      // (s <= lanes: the noise shares the pose table)
   };
   size_t smem = lds_bytes(false);
@@ -555,7 +520,7 @@ int launch_amis_forward_mfma(const epropnp_problem* prob, const epropnp_amis_par
     smem = lds_bytes(true);
     if (smem > 160 * 1024) {
       sh.ahead = 0;
-      const size_t fixed = sizeof(float) * (8 * (size_t)sh.chunk + (size_t)K * kPropStride + 256 + kRefitRedFloats + (size_t)(sh.s16 >> 4) + 8);
+      const size_t fixed = sizeof(float) * (8 * (size_t)sh.chunk + (size_t)K * kPropStride + 256 + kRefitRedFloats);
       const size_t rows = (160 * 1024 - fixed) / (sizeof(float) * 13);         // 12 pose-table floats + 1 cost per sample
       if ((size_t)sh.s16 > rows) sh.s16 = (int)(rows / 16) * 16;
       if (sh.s16 < 16) return fail(EPROPNP_EINVAL, "amis_forward: no LDS left for a pose tile (%d points per chunk)", sh.chunk);

@@ -198,9 +198,6 @@ __device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // exact-zero test of a wave-uniform float without a vector compare
 __device__ __forceinline__ bool uniform_is_zero(float a) { return __builtin_amdgcn_readfirstlane(__float_as_int(a)) == 0; }
-// a condition every lane of the wave agrees on, as a SCALAR branch condition (the compiler cannot always prove the agreement --
-// values that came through LDS -- and would predicate both arms of the branch instead of jumping over one)
-__device__ __forceinline__ bool wave_uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 #else
 typedef floatx4_emu floatx4;
 typedef float f32x2 __attribute__((vector_size(8)));
@@ -209,7 +206,6 @@ __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
   return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
 }
 __device__ __forceinline__ bool uniform_is_zero(float a) { return a == 0.f; }
-__device__ __forceinline__ bool wave_uniform(bool c) { return c; }
 #endif
 
 // ---- bf16x3-split projection: v_mfma_f32_16x16x32_bf16 --------------------------------------------------------------------

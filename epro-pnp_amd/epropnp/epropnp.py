@@ -303,8 +303,16 @@ class EProPnPBase(torch.nn.Module):
             first = pair[0:1] if bump_self else pair[1:2]
             par.amis.advance, par.amis.advance_ticket = _hip.ptr(first), _hip.ptr(pair[2:3])
             par.amis.advance_count = 2 if (bump_self and bump_init) else 1
-        pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
-            x3d, x2d, w2d, None if fold else delta, prob, pose_init, par, noise, bool(with_cost))
+        try:
+            pose_opt, samples, logw, cost, cost_init, pose_opt_n, x3d_c, offset = hip.fused_monte_carlo(
+                x3d, x2d, w2d, None if fold else delta, prob, pose_init, par, noise, bool(with_cost))
+        except Exception:
+            # A call that failed between its launches may have left the advance ticket part-way (some workgroups counted, the last
+            # one never arrived): every later step would then miss or mis-time the counters' increment and REUSE its samples in
+            # silence.  Put the ticket back to zero in stream order before the error travels on.
+            if in_kernel:
+                pair[2:3].zero_()
+            raise
         del keep
         if not in_kernel:
             if bump_init:

@@ -136,7 +136,24 @@ class RcclComm:
     _live = _weakref.WeakSet()
 
     def __del__(self):
+        # A dropped owner: destroy the communicator -- unless this garbage collection happens to run inside a hipGraph capture,
+        # where close()'s device synchronisation would invalidate the capture (and a destroy on one rank while its peers may still be
+        # inside a collective is no better): then the communicator is leaked with a warning.  close() / close_all() on every rank
+        # before destroy_process_group() remain the supported teardown.
         try:
+            if getattr(self, '_comm', None) is None:
+                return
+            capturing = False
+            try:
+                capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+            except Exception:
+                capturing = False
+            if capturing:
+                import warnings
+                warnings.warn('RcclComm dropped during a stream capture: its communicator is leaked (call close() on every rank)',
+                              ResourceWarning)
+                RcclComm._live.discard(self)
+                return
             self.close()
         except Exception:       # interpreter shutdown: modules may be gone
             pass

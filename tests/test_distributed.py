@@ -360,3 +360,57 @@ def test_direct_rccl_route_with_several_ranks(tmp_path, world, num_obj, fail_ran
     ret = mp.Manager().dict()
     mp.spawn(_direct_worker, args=(world, _free_port(), stub, num_obj, fail_rank, ret), nprocs=world, join=True)
     assert [ret.get(r) for r in range(world)] == [True] * world, dict(ret)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('form', ['torchrun', 'plain'])
+def test_bench_refuses_more_ranks_than_devices(form):
+    """`bench.py --gpus N` on a node that shows fewer than N devices leaves with ONE line and status 2 in both launch forms --
+    before the rendezvous, so that no rank is left waiting for a peer that died (the first SCALE run on an 8-GPU node should
+    yield a curve or this line, not a timeout)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = torch.cuda.device_count()
+    n = have + 1
+    tail = [os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1', '--config', 'C2', '--objects', '64',
+            '--no-cpu-baseline', '--no-hipgraph']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE'):
+        env.pop(k, None)
+    if form == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert 'visible HIP device' in r.stderr or 'HIP device(s) are visible' in r.stderr, r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('visible', [None, '0'])
+def test_real_rccl_world_of_one_under_device_masks(visible):
+    """What the stub of tests/stubs/rccl_stub.c cannot stand in for: the REAL librccl.so behind sharding.RcclComm (ncclGetUniqueId,
+    ncclCommInitRank, ncclAllGather on the caller's stream, ncclCommDestroy), with and without a HIP_VISIBLE_DEVICES mask, through
+    bench.py's C4 step under the launcher -- the line must name the direct route, carry the rank's PCI address, and tear down clean."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', BENCH_SELF_LAUNCH='1', BENCH_REPORT_TEARDOWN='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE'):
+        env.pop(k, None)
+    if visible is not None:
+        env['HIP_VISIBLE_DEVICES'] = visible
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--config', 'C4',
+           '--route', 'direct', '--no-cpu-baseline', '--no-hipgraph']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['collective']['route'].startswith('rccl ncclAllGather'), line['collective']['route']
+    rk = line['ranks']
+    assert rk['rccl_world_size'] == 1 and len(rk['pci_addresses']) == 1 and len(set(rk['pci_addresses'])) == 1
+    td = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"teardown"')][-1])['teardown']
+    assert td == {'rccl_comms_closed': True, 'process_group_destroyed': True}

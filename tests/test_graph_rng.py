@@ -110,3 +110,32 @@ def test_training_step_replays_from_a_hip_graph():
                                                         os.path.join(os.path.dirname(here), 'epro-pnp_amd'))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert 'GRAPH-REPLAY-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_failed_call_leaves_the_advance_ticket_clean(backend, monkeypatch):
+    """The sampler's launch advances the device-side Philox counters itself, behind a ticket its workgroups count up (AmisParams.advance).
+    A call that fails part-way must not leave that ticket half-counted: the two calls after an injected failure draw fresh, different
+    samples and the counter has moved by exactly two."""
+    from epropnp import functional as F
+    from epropnp.epropnp import EProPnP6DoF
+    from epropnp.levenberg_marquardt import LMSolver
+    p = orc.make_problem(5, 48, dof=6, seed=3)
+    d, cam, cf = make_layer_objects(p, backend, relative_delta=0.5)
+    cf.set_param(d['x2d'], d['w2d'])
+    layer = EProPnP6DoF(mc_samples=32, num_iter=4, solver=LMSolver(dof=6, num_iter=3), seed=9).enable_graph_safe_rng(backend)
+    call = lambda: layer.monte_carlo_forward(d['x3d'], d['x2d'], d['w2d'], cam, cf, pose_init=d['pose_init'], force_init_solve=False)
+    first = call()[3].clone()
+    assert int(layer._rng_pair[0]) == 1 and int(layer._rng_pair[2]) == 0
+    real = F.fused_monte_carlo
+
+    def failing(*a, **k):
+        layer._rng_pair[2] = 3                      # as if three workgroups had counted and the launch then died
+        raise RuntimeError('injected launch failure')
+    monkeypatch.setattr(F, 'fused_monte_carlo', failing)
+    with pytest.raises(RuntimeError, match='injected'):
+        call()
+    monkeypatch.setattr(F, 'fused_monte_carlo', real)
+    assert int(layer._rng_pair[2]) == 0, 'the ticket was left part-way'
+    second, third = call()[3].clone(), call()[3].clone()
+    assert int(layer._rng_pair[0]) == 3 and int(layer._rng_pair[2]) == 0
+    assert not torch.equal(first, second) and not torch.equal(second, third)
