@@ -165,10 +165,10 @@ PNP_FIT_FN void fit_translation(fit_t (&C)[3][3], const float* fallback_diag, fl
 constexpr int kRefitMaxVals = 21;
 constexpr int kRefitRedFloats = kRefitMaxVals * kSumTRow + 24;     // rows of 64 + 4 floats, then the totals
 
+// (lane: the caller's lane index -- passed in so that a kernel can hand over an opaque copy, amis_forward_mfma.hip)
 template <int NV>
-PNP_FN void wave_sum_t(float (&v)[NV], float* lds) {
+PNP_FN void wave_sum_t(float (&v)[NV], float* lds, int lane) {
   static_assert(NV <= kRefitMaxVals, "scratch rows");
-  const int lane = lane_id();
   float* tot = lds + kRefitMaxVals * kSumTRow;
 #pragma unroll
   for (int i = 0; i < NV; ++i) lds[i * kSumTRow + lane] = v[i];
@@ -193,9 +193,9 @@ PNP_FN void wave_sum_t(float (&v)[NV], float* lds) {
 
 // the refit's cross-lane sums: transposed through `scratch`, or (no scratch: the all-VALU forward kernel) wave_sum chains
 template <int NV>
-PNP_FN void refit_sum(float (&v)[NV], float* scratch) {
+PNP_FN void refit_sum(float (&v)[NV], float* scratch, int lane) {
   if (scratch != nullptr) {
-    wave_sum_t<NV>(v, scratch);
+    wave_sum_t<NV>(v, scratch, lane);
   } else {
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
@@ -723,7 +723,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
     __syncthreads();
     return;
   }
-  const int T = 64, tid = lane_id();
+  const int T = 64, tid = cx.tid;      // (wave 0: the thread index IS the lane index)
   PNP_REFIT_BEGIN();
   if (PNP_ABLATED(a, 2)) {
     for (int i = tid; i < kPropStride; i += T) nrec[i] = rec[i];
@@ -758,7 +758,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       mom[16] += iw * q3 * q0; mom[17] += iw * q3 * q1; mom[18] += iw * q3 * q2; mom[19] += iw * q3 * q3;
       mom[20] += iw;
     }
-    if (!PNP_ABLATED(a, 16)) refit_sum<21>(mom, cx.rred);
+    if (!PNP_ABLATED(a, 16)) refit_sum<21>(mom, cx.rred, tid);
     const float invZ = 1.0f / mom[0];
     const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
     const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;
@@ -816,7 +816,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
         acc[3] += iw * q2 * q0; acc[4] += iw * q2 * q1; acc[5] += iw * q2 * q2;
         acc[6] += iw * q3 * q0; acc[7] += iw * q3 * q1; acc[8] += iw * q3 * q2; acc[9] += iw * q3 * q3;
       }
-      refit_sum<11>(acc, cx.rred);
+      refit_sum<11>(acc, cx.rred, tid);
     }
     PNP_REFIT_PHASE(1);
     if (tid < 2) {      // lane 0: rotation factor, lane 1: translation factor (the same instructions)
@@ -857,7 +857,7 @@ PNP_FN void amis_refit(const AmisCtx& cx, const AmisParams& a, int it) {
       mom[10] += e * sy;
       mom[11] += e * cy;
     }
-    refit_sum<12>(mom, cx.rred);
+    refit_sum<12>(mom, cx.rred, tid);
     const float invZ = 1.0f / mom[0];
     const float dl0 = mom[1] * invZ, dl1 = mom[2] * invZ, dl2 = mom[3] * invZ;
     const float mu0 = p0 + dl0, mu1 = p1 + dl1, mu2 = p2 + dl2;

@@ -363,11 +363,17 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
     PNP_PHASE(2);
 
     if (tiled) __syncthreads();
-    amis_weights<DOF>(cx, a, it, tiled ? 0 : WPs);
+    // The phases behind the sweep address LDS by thread index (cst / mixl / lgw / cpart + tid + k s ...).  As invariants of the iteration
+    // loop those addresses were computed once in front of it and stayed live across the sweep -- six to eight VGPRs the eight-tile
+    // instantiation does not have: they were spilled before every sweep and reloaded behind it (28-32 B per lane, 30 MB of scratch
+    // traffic per launch at C2).  Behind an opaque copy of the thread index they are recomputed here, per iteration, for a few integer adds.
+    AmisCtx cxw = cx;
+    cxw.tid = (int)f32_bits(to_vgpr(bits_f32((unsigned)tid)));
+    amis_weights<DOF>(cxw, a, it, tiled ? 0 : WPs);
     __syncthreads();
     PNP_PHASE(3);
     if (it == K - 1) break;
-    amis_refit<DOF>(cx, a, it);
+    amis_refit<DOF>(cxw, a, it);
     PNP_PHASE(4);
   }
 

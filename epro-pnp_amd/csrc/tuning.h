@@ -17,13 +17,10 @@
 #ifndef PNP_FWD_MINW       // waves per SIMD the fp32-projection 6-DoF forward is compiled for (the bf16 one: 3)
 #define PNP_FWD_MINW 4
 #endif
-#ifndef PNP_BWD_MINW2      // ... with <= 2 resident point tiles: four waves per SIMD (128 VGPRs)
-#define PNP_BWD_MINW2 4
-#endif
 #ifndef PNP_BWD_MINW4      // ... with four resident point tiles (few objects, or pose tables that leave room for two workgroups per CU only)
 #define PNP_BWD_MINW4 2
 #endif
-#ifndef PNP_BWD_MINW       // waves per SIMD of the MFMA backward with <= 4 resident point tiles
+#ifndef PNP_BWD_MINW       // waves per SIMD of the MFMA backward with <= 2 resident point tiles
 #define PNP_BWD_MINW 3
 #endif
 
