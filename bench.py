@@ -265,7 +265,7 @@ def measured_traffic(kernel, shape_key):
     exact shape is on file, so a stale number can never be attached to a changed workload."""
     # newest committed profile of this shape.  (r04_pmc_traffic.json is not consulted: its C2 `normal_equations_kernel` entry averages
     # 121 C2-size with 27 C5-size dispatches -- tools/pmc_traffic.py grouped by kernel name only then; it groups by launch size now.)
-    for name in ('r05_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name))).get(shape_key, {}).get(kernel)
         except (OSError, ValueError):
@@ -579,12 +579,20 @@ def main(argv=None, device=None, backend='nccl'):
     # sit in a hipGraph at all.  BENCH_PROF_IN_REGION=1 puts them back into the timed region of an eager GPU-bound run.
     prof_in_region = (launch == 'eager' and args.config not in LAUNCH_BOUND and os.environ.get('BENCH_PROF_IN_REGION', '0') == '1')
     prof_steps = args.steps if prof_in_region else ((10 if args.config in LAUNCH_BOUND else 20) if on_gpu else 1)
+    step_clocks = None
     if not prof_in_region:
         fence()
         _hip.profile(enable=True, reset=True)
-        for _ in range(prof_steps):
-            step(timed=True)
-        fence()
+        if on_gpu and rank == 0:      # engine clock / power WHILE the step's kernels run (this window, not the timed one: the sampler is a host thread)
+            with ClockSampler(dev.index or 0, period_s=0.002) as clk:
+                for _ in range(prof_steps):
+                    step(timed=True)
+                fence()
+            step_clocks = clk.summary()
+        else:
+            for _ in range(prof_steps):
+                step(timed=True)
+            fence()
         _hip.profile(enable=False)
     graph, held = None, {}
     if launch == 'graph':
@@ -838,6 +846,9 @@ def main(argv=None, device=None, backend='nccl'):
                                          'unit': 'TFLOP/s', 'frac': round(bw_tf / FP32_VECTOR_PEAK_TF, 4),
                                          'flops_per_point_pose': 80, 'launch_ms': round(t_bw, 4)}},
             'kernel_ms': {n: round(v[0] * (v[1] / prof_steps), 4) for n, v in stage_ms.items() if v[1]},   # per step
+            # engine / memory clock and package power sampled while the kernel_ms window ran (the sustained state the kernel times
+            # were taken in: the AMIS kernels run close to the board's power cap, and boxes differ in where that puts the clock)
+            'clocks_under_step_load': step_clocks,
             'loss': round(loss_val, 5),
         }
         if events_in_region is not None:

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-5 evidence run on the GPU box.  usage: tools/gpu_r05_evidence.sh [tag] [parts]   parts: any of t(ests) b(ench) p(mc) o(ther) c(onfigs + C5)
-TAG=${1:-r05}; PARTS=${2:-tbpoc}
+# Round-6 evidence run on the GPU box.  usage: tools/gpu_r06_evidence.sh [tag] [parts]   parts: any of t(ests) b(ench) p(mc) o(ther) c(onfigs + C5)
+TAG=${1:-r06}; PARTS=${2:-tbpoc}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 O=/root/repo/gpurun_out
