@@ -15,7 +15,8 @@
 //     measured: 12 more MFMAs per 16x16 tile for 3 useful output columns of 16, each waiting on VALU results and on
 //     the previous accumulate -- 1.6-1.9 ms instead of 1.08 ms at C2 (profiles/r01_bwd_mfma_sweep.txt).  Dropped.
 //   * the VALU keeps what is genuinely per pair: perspective divide, weighted residual, Huber weight, and the
-//     accumulation of the gradients (~40 instructions, 2 of them transcendental).
+//     accumulation of the gradients -- since round 6 on explicit 2-vectors: two point-poses per v_pk_*_f32 (26 wave-level
+//     instructions per pair, 2 of them transcendental; the loop is bound by how often a wave gets to issue, profiles/r06_bwd_packed.txt).
 // The weighted poses are built ONCE into an LDS table (compacted: the low-weight tail whose total |weight| is below
 // drop_eps -- default 2^-24 -- of the object's total is dropped before tiling, mass_drop_threshold in amis_common.h;
 // EPROPNP_BWD_DROP=0 keeps every non-zero sample), then every wave sweeps all pose tiles for its own points.
