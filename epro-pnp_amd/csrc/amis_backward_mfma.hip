@@ -26,9 +26,9 @@
 
 namespace pnp {
 
-// Register budget (the packed pair loop of round 6, compiled WITHOUT the SLP vectoriser -- build.py): <= 2 resident point tiles fit
-// three waves per SIMD (bf16 projection: 138 VGPRs unbounded, 134 with the projection clamp); four resident tiles are compiled for two
-// (178 / 190 VGPRs): they serve the few-object launches and the pose tables that leave LDS for two workgroups per CU anyway (S >= 1024).
+// Register budget (the packed pair loop of round 6 with pair accumulators, compiled WITHOUT the SLP vectoriser -- build.py): <= 2
+// resident point tiles fit three waves per SIMD (bf16 projection: 152 VGPRs), four resident tiles are compiled for two (206 / 218
+// VGPRs with the projection clamp) -- and are the faster shape at C2 all the same (launcher comment).
 // Why no vectoriser: the packed fp32 instructions it forms include shapes that return wrong results on the MI355X while a bf16 MFMA of a
 // neighbouring wave executes (profiles/r05_pk_opsel_erratum.txt) -- the run-to-run different gradients of round 5.  The packed
 // arithmetic of this kernel is written by hand, on explicit 2-vectors, in shapes that the erratum does not touch (see the pair loop).
@@ -162,16 +162,20 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
     // this wave's point tiles q = wv + W * i of the chunk; lane = (point column, k)
     typename Proj::T rB[NPT];
     float4 rW[NPT];
-    float A1x[NPT], A1y[NPT], A2x[NPT], A2y[NPT];
-    float gXv[NPT], gYv[NPT], gZv[NPT];
+    // per resident tile: the four sums behind d/du, d/dw and the back-projected gradient, as PAIRS over the lane's poses (0, 2 | 1, 3):
+    // folded once per chunk (below).  14 VGPRs per tile instead of 7 -- the two-tile instantiation has them to spare below the
+    // three-waves-per-SIMD budget of 168, and they save 3.5 wave-level instructions per pair (8 scalar fmacs -> 4 packed fmas per two
+    // pairs, no folding adds per pose tile).
+    f32x2 A1x[NPT], A1y[NPT], A2x[NPT], A2y[NPT];
+    f32x2 gXv[NPT], gYv[NPT], gZv[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const Point q = load_point(p, b, c0 + (wv + W * i) * 16 + col);      // zero weight beyond N
       rB[i] = Proj::b((kk == 0) ? q.X : (kk == 1) ? q.Y : (kk == 2) ? q.Z : 1.0f);
       const float wu = q.wu * hs.inv_delta, wv = q.wv * hs.inv_delta;
       rW[i] = make_float4(wu, -q.u * wu, wv, -q.v * wv);      // (w_u, c_u | w_v, c_v): the factors in the low halves of their pairs
-      A1x[i] = A1y[i] = A2x[i] = A2y[i] = 0.f;
-      gXv[i] = gYv[i] = gZv[i] = 0.f;
+      A1x[i] = A1y[i] = A2x[i] = A2y[i] = f32x2{0.f, 0.f};
+      gXv[i] = gYv[i] = gZv[i] = f32x2{0.f, 0.f};
     }
     f32x2 gsat2 = {0.f, 0.f};   // sum_pairs a_j min(|r|^2, 1): the second term of d/d delta (below), poses (0, 2) | (1, 3) of the lanes
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -201,11 +205,6 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
         const floatx4 hz = Proj::mma(az, rB[i], zero);
         const float4 w4 = rW[i];
         const f32x2 wu2 = {w4.x, w4.x}, cu2 = {w4.y, w4.y}, wv2 = {w4.z, w4.z}, cv2 = {w4.w, w4.w};
-        // this tile's back-projection sums over the lane's four poses, as pairs (poses 0, 2 in the low halves, 1, 3 in the high ones);
-        // folded into the scalar accumulators behind the loop -- pair accumulators across the pose tiles would cost 3 VGPRs per resident
-        // tile.  (The four sums behind d/du, d/dw stay scalar fmacs: packed they would need as many instructions -- 8 fmas + 8 folding
-        // adds against 16 fmacs per tile -- and 8 registers more.)
-        f32x2 sX = {0.f, 0.f}, sY = sX, sZ = sX;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const f32x2 hx2 = {hx[2 * h], hx[2 * h + 1]}, hy2 = {hy[2 * h], hy[2 * h + 1]};
@@ -257,30 +256,27 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
           // "in front of the depth clamp" as a 0/1 factor from ONE full-rate instruction per pair (front_scale above)
           ghz2 = ghz2 * f32x2{sat_fma(hz0, front_scale, front_off), sat_fma(hz1, front_scale, front_off)};
           // d/dw = crx * (px - u) = crx * rx / w and d/du = -crx * w: the per-point factors are applied once at the end
-          A2x[i] = fmaf(crx2[0], rx2[0], A2x[i]); A2x[i] = fmaf(crx2[1], rx2[1], A2x[i]);
-          A2y[i] = fmaf(cry2[0], ry2[0], A2y[i]); A2y[i] = fmaf(cry2[1], ry2[1], A2y[i]);
-          A1x[i] = fmaf(coef2[0], rx2[0], A1x[i]); A1x[i] = fmaf(coef2[1], rx2[1], A1x[i]);
-          A1y[i] = fmaf(coef2[0], ry2[0], A1y[i]); A1y[i] = fmaf(coef2[1], ry2[1], A1y[i]);
+          A2x[i] = fma2(crx2, rx2, A2x[i]);
+          A2y[i] = fma2(cry2, ry2, A2y[i]);
+          A1x[i] = fma2(coef2, rx2, A1x[i]);
+          A1y[i] = fma2(coef2, ry2, A1y[i]);
           const f32x2 kxx2 = h ? f32x2{kxx.z, kxx.w} : f32x2{kxx.x, kxx.y}, kyx2 = h ? f32x2{kyx.z, kyx.w} : f32x2{kyx.x, kyx.y},
                       kzx2 = h ? f32x2{kzx.z, kzx.w} : f32x2{kzx.x, kzx.y};
           const f32x2 kxy2 = h ? f32x2{kxy.z, kxy.w} : f32x2{kxy.x, kxy.y}, kyy2 = h ? f32x2{kyy.z, kyy.w} : f32x2{kyy.x, kyy.y},
                       kzy2 = h ? f32x2{kzy.z, kzy.w} : f32x2{kzy.x, kzy.y};
           const f32x2 kxz2 = h ? f32x2{kxz.z, kxz.w} : f32x2{kxz.x, kxz.y}, kyz2 = h ? f32x2{kyz.z, kyz.w} : f32x2{kyz.x, kyz.y},
                       kzz2 = h ? f32x2{kzz.z, kzz.w} : f32x2{kzz.x, kzz.y};
-          sX = fma2(kxx2, ghx2, fma2(kyx2, ghy2, fma2(kzx2, ghz2, sX)));
-          sY = fma2(kxy2, ghx2, fma2(kyy2, ghy2, fma2(kzy2, ghz2, sY)));
-          sZ = fma2(kxz2, ghx2, fma2(kyz2, ghy2, fma2(kzz2, ghz2, sZ)));
+          gXv[i] = fma2(kxx2, ghx2, fma2(kyx2, ghy2, fma2(kzx2, ghz2, gXv[i])));
+          gYv[i] = fma2(kxy2, ghx2, fma2(kyy2, ghy2, fma2(kzy2, ghz2, gYv[i])));
+          gZv[i] = fma2(kxz2, ghx2, fma2(kyz2, ghy2, fma2(kzz2, ghz2, gZv[i])));
         }
-        gXv[i] += sX[0] + sX[1];
-        gYv[i] += sY[0] + sY[1];
-        gZv[i] += sZ[0] + sZ[1];
       }
     }
     const float gsat = gsat2[0] + gsat2[1];
     {   // d/d delta of this chunk: sum_pairs coef |r|^2 (= the sums behind d/dw, before their per-point factors) - sum_pairs a min(|r|^2, 1)
       float a2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < NPT; ++i) a2 += A2x[i] + A2y[i];
+      for (int i = 0; i < NPT; ++i) a2 += (A2x[i][0] + A2x[i][1]) + (A2y[i][0] + A2y[i][1]);
       gd += a2 - gsat;
     }
     // ---- outputs of this chunk: sums over the 4 pose groups of a point via MFMAs against indicator columns ----
@@ -294,15 +290,16 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       floatx4 D1 = zero;
-      D1 = mfma_16x16x4(gXv[i] * hs.delta_sq, ind0, D1);
-      D1 = mfma_16x16x4(gYv[i] * hs.delta_sq, ind1, D1);
-      D1 = mfma_16x16x4(gZv[i] * hs.delta_sq, ind2, D1);
+      D1 = mfma_16x16x4((gXv[i][0] + gXv[i][1]) * hs.delta_sq, ind0, D1);
+      D1 = mfma_16x16x4((gYv[i][0] + gYv[i][1]) * hs.delta_sq, ind1, D1);
+      D1 = mfma_16x16x4((gZv[i][0] + gZv[i][1]) * hs.delta_sq, ind2, D1);
       const float4 w4 = rW[i];
       floatx4 D2 = zero;
-      D2 = mfma_16x16x4(-w4.x * A1x[i] * hs.delta_sq, ind0, D2);                            // d/du
-      D2 = mfma_16x16x4(-w4.z * A1y[i] * hs.delta_sq, ind1, D2);                            // d/dv
-      D2 = mfma_16x16x4((w4.x != 0.f) ? A2x[i] * hs.delta / w4.x : 0.f, ind2, D2);          // d/dwu
-      D2 = mfma_16x16x4((w4.z != 0.f) ? A2y[i] * hs.delta / w4.z : 0.f, ind3, D2);          // d/dwv
+      const float a1x = A1x[i][0] + A1x[i][1], a1y = A1y[i][0] + A1y[i][1], a2x = A2x[i][0] + A2x[i][1], a2y = A2y[i][0] + A2y[i][1];
+      D2 = mfma_16x16x4(-w4.x * a1x * hs.delta_sq, ind0, D2);                               // d/du
+      D2 = mfma_16x16x4(-w4.z * a1y * hs.delta_sq, ind1, D2);                               // d/dv
+      D2 = mfma_16x16x4((w4.x != 0.f) ? a2x * hs.delta / w4.x : 0.f, ind2, D2);             // d/dwu
+      D2 = mfma_16x16x4((w4.z != 0.f) ? a2y * hs.delta / w4.z : 0.f, ind3, D2);             // d/dwv
       const int nb = c0 + (wv + W * i) * 16 + g4E;    // D rows: points nb + r; column = lane & 15
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -373,12 +370,12 @@ int launch_amis_backward_mfma(const epropnp_problem* prob, const float* pose_sam
   const int ptiles = (d.N + 15) / 16;
   int waves = (d.B < 512 && ptiles > 16) ? 8 : 4, npt = 1;
   while (npt < 4 && waves * npt < ptiles) npt *= 2;
-  // Round 6: where the grid fills the chip, TWO resident tiles per wave: 138 VGPRs = three waves per SIMD, where the four-tile
-  // instantiation of the packed pair loop needs 178 (two).  Every chunk of 128 points re-reads the pose rows, but the loop is bound by
-  // how often a wave gets to issue, not by its instruction count.  C2, packed loop: 4 x 2 836 us, 4 x 4 847 us; the scalar loop of
-  // round 5: 905 us either way (profiles/r06_bwd_packed.txt).  Where LDS leaves room for two workgroups per CU only (S >= 1024)
-  // four tiles stay: the occupancy is the pose table's there.
-  if (waves == 4 && npt == 4 && d.B >= 2 * device_cu_count() && 3 * smem <= 160 * 1024) npt = 2;
+  // Round 6, packed pair loop with pair accumulators (same-box A/Bs, profiles/r06_bwd_packed.txt): without a projection clamp 4 x 4
+  // wins -- 792 ... 819 us at 206 VGPRs (two waves per SIMD) against 808 ... 838 us for 4 x 2 at 152 VGPRs (three): with two point-poses
+  // per instruction the fewer instructions per pair of the four-tile loop (22.6 against 24.0) weigh more than the third wave.  With the
+  // clamp the four-tile loop needs 218 VGPRs and two tiles win where the grid fills the chip: 913 against 945 us.  (The scalar loop of
+  // round 5 preferred two tiles either way: 905 at 4 x 4, 868 at 4 x 2 with four waves.)  EPROPNP_TUNE=bwd_mfma=<waves>,<tiles> overrides.
+  if (has_bounds(prob) && waves == 4 && npt == 4 && d.B >= 2 * device_cu_count() && 3 * smem <= 160 * 1024) npt = 2;
   if (nsplit > 1) {      // 4 waves x the fewest tiles that still cover N with nsplit chunks in flight
     waves = 4; npt = 1;
     while (npt < 4 && waves * npt * nsplit < ptiles) npt *= 2;
