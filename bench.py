@@ -406,7 +406,7 @@ def main(argv=None, device=None, backend='nccl'):
         res = (cpu_baseline(Nc, Sc, Kc, Lc, args.cpu_sample) if args.config != 'C5'
                else cpu_baseline(Nc, Sc, Kc, Lc, total_objects=8, chunk=8, one_thread_objects=2))
         print(json.dumps({'cpu_baseline': res, 'config': args.config}))
-        return res
+        return None
 
     # plain `python bench.py --gpus N`: spawn the N ranks ourselves (BENCH_SELF_LAUNCH=1 takes this route for N = 1 too)
     if (args.gpus > 1 or os.environ.get('BENCH_SELF_LAUNCH') == '1') and 'RANK' not in os.environ:
