@@ -198,11 +198,30 @@ __global__ __launch_bounds__(512, (bwd_min_waves<DOF, BOUNDS, NPT, BF16>())) voi
       const float4* rows = reinterpret_cast<const float4*>(ptab + (t * 4 + kk) * 48);
       const float4 kxx = rows[0], kxy = rows[1], kxz = rows[2], kyx = rows[4], kyy = rows[5], kyz = rows[6], kzx = rows[8], kzy = rows[9],
                    kzz = rows[10];
+      // Four resident tiles (two waves per SIMD, registers to spare): a software pipeline over the tiles -- tile i + 1's three
+      // projections are issued in front of tile i's pair work, so that no wave waits out an MFMA's result latency in s_nops (29 -> 1
+      // per pose tile).  With one or two tiles the compiler's own placement is the better one (the fence costs it its freedom).
+      constexpr bool kPipe = (NPT == 4);
+      floatx4 hxn = zero, hyn = zero, hzn = zero;
+      if (kPipe) {
+        hxn = Proj::mma(ax, rB[0], zero); hyn = Proj::mma(ay, rB[0], zero); hzn = Proj::mma(az, rB[0], zero);
+      }
 #pragma unroll
       for (int i = 0; i < NPT; ++i) {
-        const floatx4 hx = Proj::mma(ax, rB[i], zero);
-        const floatx4 hy = Proj::mma(ay, rB[i], zero);
-        const floatx4 hz = Proj::mma(az, rB[i], zero);
+        floatx4 hx, hy, hz;
+        if (kPipe) {
+          hx = hxn; hy = hyn; hz = hzn;
+          if (i + 1 < NPT) {
+            hxn = Proj::mma(ax, rB[i + 1], zero);
+            hyn = Proj::mma(ay, rB[i + 1], zero);
+            hzn = Proj::mma(az, rB[i + 1], zero);
+            sched_fence();
+          }
+        } else {
+          hx = Proj::mma(ax, rB[i], zero);
+          hy = Proj::mma(ay, rB[i], zero);
+          hz = Proj::mma(az, rB[i], zero);
+        }
         const float4 w4 = rW[i];
         const f32x2 wu2 = {w4.x, w4.x}, cu2 = {w4.y, w4.y}, wv2 = {w4.z, w4.z}, cv2 = {w4.w, w4.w};
 #pragma unroll

@@ -95,7 +95,7 @@ struct MfmaShape {
 template <int DOF, bool BOUNDS, int NPT, bool SPILL = false, bool SPLIT = false, bool BF16 = false, bool CHUNKED = false>
 // (SPLIT grids are sized for one workgroup per CU: two waves per SIMD -- 256 VGPRs -- leave room for a second such launch and
 // for the part-recomputation path's second copy of the sweep without spilling)
-__global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 : PNP_FWD_MINW) : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
+__global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? PNP_FWD_BF16_MINW : PNP_FWD_MINW) : 2) : (NPT <= 2 ? 3 : 2))) void amis_forward_mfma_kernel(Problem p, AmisParams a_in, MfmaShape sh,
                                                                   const float* __restrict__ pose_opt,
                                                                   const float* __restrict__ pose_cov,
                                                                   const float* __restrict__ noise,
@@ -215,21 +215,38 @@ __global__ __launch_bounds__(512, SPLIT ? 2 : (DOF == 6 ? (NPT <= 8 ? (BF16 ? 3 
 
   const int g4 = (lane >> 4) * 4, col = lane & 15, kk = lane >> 4;
   // register mode: every pose tile of the iteration against the point tiles in this wave's registers -> cpart[wv][pose]
-  // (issuing the next pose tile's first MFMAs ahead of the current tile's VALU work, to fill the wait states at the
-  // head of this loop, was measured: 0.655 vs 0.641 ms at C2 -- the hand-off copies cost more than the s_nops)
+  // (issuing the next POSE tile's first MFMAs ahead of the current tile's VALU work, to fill the wait states at the
+  // head of this loop, was measured in round 1: 0.655 vs 0.641 ms at C2 -- the hand-off copies cost more than the s_nops.
+  // Round 6 pipelines over the resident POINT tiles inside a pose tile instead -- tile i + 1's three projections in front of
+  // tile i's Huber sweep, pinned by a scheduling fence: 48 -> 22 s_nops per pose tile, no register more at eight tiles,
+  // 539 -> 514 us at C2, 7.22 -> 6.77 ms at the C5 shard; same bits.  PNP_FWD_PIPE, tuning.h)
   auto sweep_regs = [&](bool accumulate = false) {      // accumulate: a later chunk of the same iteration adds to the wave's row
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < (s16 >> 4); ++t) {
       const float* arow = ptab + 12 * (t * 16 + col) + kk;
       const typename Proj::T ax = Proj::a(arow[0]), ay = Proj::a(arow[4]), az = Proj::a(arow[8]);
       f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+      constexpr int NT = kRegs ? NPT : 1;
+      constexpr bool kPipe = (PNP_FWD_PIPE != 0) && !kFold && NT >= 4;      // (tuning.h: software pipeline over the resident tiles)
+      floatx4 hxn = zero, hyn = zero, hzn = zero;
+      if (kPipe) {
+        hxn = Proj::mma(ax, rB[0], zero); hyn = Proj::mma(ay, rB[0], zero); hzn = Proj::mma(az, rB[0], zero);
+      }
 #pragma unroll
-      for (int i = 0; i < (kRegs ? NPT : 1); ++i) {
+      for (int i = 0; i < NT; ++i) {
         floatx4 hx, hy, hz;
         if constexpr (kFold) {
           hx = mfma_16x16x4(ax, rW[i].x, zero);
           hy = mfma_16x16x4(ay, rW[i].y, zero);
           hz = mfma_16x16x4(az, rB[i], zero);
+        } else if constexpr (kPipe) {
+          hx = hxn; hy = hyn; hz = hzn;
+          if (i + 1 < NT) {
+            hxn = Proj::mma(ax, rB[i + 1], zero);
+            hyn = Proj::mma(ay, rB[i + 1], zero);
+            hzn = Proj::mma(az, rB[i + 1], zero);
+            sched_fence();
+          }
         } else {
           hx = Proj::mma(ax, rB[i], zero);
           hy = Proj::mma(ay, rB[i], zero);

@@ -14,6 +14,12 @@
 #ifndef PNP_VM_TRIES       // attempts of the bounded Best-Fisher von Mises sampler
 #define PNP_VM_TRIES 16
 #endif
+#ifndef PNP_FWD_BF16_MINW  // waves per SIMD the split-projection 6-DoF forward with <= 8 resident tiles is compiled for
+#define PNP_FWD_BF16_MINW 3
+#endif
+#ifndef PNP_FWD_PIPE       // 1: the forward's sweep issues tile i + 1's projections in front of tile i's Huber sweep (round 6: -4.7 % at C2)
+#define PNP_FWD_PIPE 1
+#endif
 #ifndef PNP_FWD_MINW       // waves per SIMD the fp32-projection 6-DoF forward is compiled for (the bf16 one: 3)
 #define PNP_FWD_MINW 4
 #endif
