@@ -134,8 +134,10 @@ def build(emu=False, force=False, verbose=False, defines=(), tag=None, flags=(),
         lib = os.path.join(out_dir, 'libepropnp_emu.so')
         shim = os.path.join(ROOT, 'tests', 'emu', 'hip_emu.h')
         deps_common.append(shim)
-        cc = ['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-x', 'c++', '-include', shim, '-Wno-unknown-pragmas',
-              '-Wno-attributes']
+        # the kernel headers hold no test branches: <hip/hip_runtime.h> resolves to the shim, which supplies host functions under
+        # the names of the AMDGPU builtins the headers use (-ffp-contract=off: what `#pragma clang fp contract(off)` asks for)
+        cc = ['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-x', 'c++', '-include', shim,
+              '-I', os.path.join(ROOT, 'tests', 'emu', 'include'), '-ffp-contract=off', '-Wno-unknown-pragmas', '-Wno-attributes']
     else:
         out_dir = os.path.join(HERE, 'lib') if not tag else os.path.join(HERE, 'lib', 'variants', tag)
         lib = os.path.join(out_dir, 'libepropnp_hip.so')

@@ -11,22 +11,12 @@ typedef PNP_FIT_T fit_t;      // precision of the single-lane proposal fits (tun
 // min(x, 1) for x >= 0 through the clamp output modifier of a multiply by an opaque 1.0 (v_mul_f32 ... clamp, a full-rate
 // instruction; v_min_f32 issues at half that rate on gfx950, tools/ubench)
 __device__ __forceinline__ float sat_mul(float x, float one_v) {
-#ifndef EPROPNP_EMU
   return __builtin_amdgcn_fmed3f(x * one_v, 0.0f, 1.0f);
-#else
-  const float y = x * one_v;
-  return (y != y) ? 0.0f : fminf(fmaxf(y, 0.0f), 1.0f);       // dx10_clamp: NaN -> 0
-#endif
 }
 
 // clamp(a * b + c, 0, 1) as one v_fma_f32 ... clamp
 __device__ __forceinline__ float sat_fma(float a, float b, float c) {
-#ifndef EPROPNP_EMU
   return __builtin_amdgcn_fmed3f(fmaf(a, b, c), 0.0f, 1.0f);
-#else
-  const float y = fmaf(a, b, c);
-  return (y != y) ? 0.0f : fminf(fmaxf(y, 0.0f), 1.0f);
-#endif
 }
 
 // max(x, lo) for lo >= 0 as ONE v_max_i32 on the bit patterns: non-negative floats order like their bits and every
@@ -362,11 +352,7 @@ __device__ __attribute__((noinline)) float mass_drop_threshold(W&& wabs, int S, 
   for (int m = tid; m < S; m += T) {
     const float rel = fminf(wabs(m) * inv, 1.0f);                 // (a non-finite weight among finite ones: NaN -> 1.0f)
     // bin k holds 2^-(k+1) < rel <= 2^-k (k = 0..62); bin 63 holds the rest, zeros included
-#ifndef EPROPNP_EMU
     int k = (rel > 0.f) ? (int)(-__builtin_amdgcn_logf(rel)) : 63;
-#else
-    int k = (rel > 0.f) ? (int)(-log2f(rel)) : 63;
-#endif
     k = min(max(k, 0), 63);
     const unsigned long long q = (unsigned long long)(rel * 0x1p40f);
     if (q != 0ull) atomicAdd(&bins[k], q);
@@ -419,24 +405,14 @@ PNP_FN float proposal_logprob(const float* rec, const float* smp /*PL*/) {
 // re-evaluated in fp64 (a few per 10^4 attempts), so the outcome is that of the fp64 procedure.
 // `next(a, u1, u2, u3)` supplies the three uniforms of attempt a (from injected noise or Philox): no per-lane array.
 PNP_FN void sincos_half_pi(float u, float& s, float& c) {      // sin, cos of (pi / 2) u,  u in [0, 1]
-#ifndef EPROPNP_EMU
   s = __builtin_amdgcn_sinf(0.25f * u);      // hardware argument is in revolutions
   c = __builtin_amdgcn_cosf(0.25f * u);
-#else
-  s = sinf(1.5707963267948966f * u);
-  c = cosf(1.5707963267948966f * u);
-#endif
 }
 
 PNP_FN void sincos_rad(float x, float& s, float& c) {          // hardware sin / cos (argument in revolutions), |x| <~ 2 pi
-#ifndef EPROPNP_EMU
   const float rev = x * 0.15915494309189535f;
   s = __builtin_amdgcn_sinf(rev);
   c = __builtin_amdgcn_cosf(rev);
-#else
-  s = sinf(x);
-  c = cosf(x);
-#endif
 }
 
 template <class Uniforms>
@@ -451,11 +427,9 @@ PNP_FN float vm_sample_bounded(float loc, float kappa, Uniforms next) {
   float x = 0.f;
   bool done = false;
   for (int a = 0; a < kVmTries; ++a) {
-#ifndef EPROPNP_EMU
     // every active lane of the wave has accepted: the remaining attempts could not change anything (the acceptance
     // rate of Best-Fisher is >= 0.66, so a full wave is through after ~4-5 attempts instead of 16)
     if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-#endif
     float u1, u2, u3;
     next(a, u1, u2, u3);
     float sh, ch;
@@ -484,23 +458,18 @@ PNP_FN float vm_sample_bounded(float loc, float kappa, Uniforms next) {
 }
 
 
-// A sample's pose -> the (S, B, pose_len) output: 28 (16) contiguous bytes that are only dword-aligned.  Two (one) wide
-// stores with 4-byte alignment instead of seven (four) dword stores per lane (global memory takes unaligned wide accesses).
+// A sample's pose -> the (S, B, pose_len) output: 28 (16) contiguous bytes that are only dword-aligned.  Two (one) 16-byte
+// stores with 4-byte alignment instead of seven (four) dword stores per lane (global memory takes unaligned wide accesses); the
+// two of a 7-vector overlap in element 3, which the lane writes twice with the same value.
 template <int PL>
 PNP_FN void store_pose(float* dst, const float (&ps)[PL]) {
-#ifndef EPROPNP_EMU
-  typedef float f4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-  typedef float f3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+  typedef float f4_a4 __attribute__((vector_size(16), aligned(4)));
   const f4_a4 head = {ps[0], ps[1], ps[2], ps[3]};
   *reinterpret_cast<f4_a4*>(dst) = head;
   if (PL == 7) {
-    const f3_a4 tail = {ps[PL > 4 ? 4 : 0], ps[PL > 5 ? 5 : 0], ps[PL > 6 ? 6 : 0]};
-    *reinterpret_cast<f3_a4*>(dst + 4) = tail;
+    const f4_a4 tail = {ps[3], ps[PL > 4 ? 4 : 0], ps[PL > 5 ? 5 : 0], ps[PL > 6 ? 6 : 0]};
+    *reinterpret_cast<f4_a4*>(dst + 3) = tail;
   }
-#else
-#pragma unroll
-  for (int i = 0; i < PL; ++i) dst[i] = ps[i];
-#endif
 }
 
 // Per-thread view of one object's LDS-resident sampler state (shared by the VALU and the MFMA forward kernels).

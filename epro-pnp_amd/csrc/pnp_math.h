@@ -10,9 +10,7 @@
 //                                  torch/distributions/von_mises.py:24-89
 // The small dense algebra (6x6 / 4x4 / 3x3) is fully unrolled so that everything lives in VGPRs.
 #pragma once
-#ifndef EPROPNP_EMU
 #include <hip/hip_runtime.h>
-#endif
 #include <math.h>
 #include <stdint.h>
 
@@ -29,46 +27,24 @@ namespace pnp {
 // `contract` flag on BOTH operations; the pragma keeps it off the one formed here (HIP's __fmul_rn / __fadd_rn are plain
 // operators that -ffp-contract=fast still fuses).
 PNP_FN float mul_unfused(float a, float b) {
-#ifndef EPROPNP_EMU
 #pragma clang fp contract(off)
   const float m = a * b;
   return m;
-#else
-  volatile float m = a * b;
-  return m;
-#endif
 }
 PNP_FN float add_unfused(float a, float b) {
-#ifndef EPROPNP_EMU
 #pragma clang fp contract(off)
   const float m = a + b;
   return m;
-#else
-  volatile float m = a + b;
-  return m;
-#endif
 }
 
 PNP_FN float fast_rcp(float x) {
-#ifndef EPROPNP_EMU
   return __builtin_amdgcn_rcpf(x);
-#else
-  return 1.0f / x;
-#endif
 }
 PNP_FN float fast_rsqrt(float x) {
-#ifndef EPROPNP_EMU
   return __builtin_amdgcn_rsqf(x);
-#else
-  return 1.0f / sqrtf(x);
-#endif
 }
 PNP_FN float fast_sqrt(float x) {
-#ifndef EPROPNP_EMU
   return __builtin_amdgcn_sqrtf(x);
-#else
-  return sqrtf(x);
-#endif
 }
 
 template <int DOF>
@@ -95,14 +71,10 @@ PNP_FN void quat_to_rot(float w, float x, float y, float z, float (&R)[9]) {
 }
 
 PNP_FN void yaw_to_rot(float yaw, float (&R)[9]) {
-#ifndef EPROPNP_EMU
   // hardware sin / cos (argument in revolutions, ~2^-21 absolute error: 3e-5 px at 800 px focal length) instead of the
   // ~80-instruction libm pair; every kernel builds R through this function, so forward and backward stay consistent
   const float rev = yaw * 0.15915494309189535f;
   const float c = __builtin_amdgcn_cosf(rev), s = __builtin_amdgcn_sinf(rev);
-#else
-  const float c = cosf(yaw), s = sinf(yaw);
-#endif
   R[0] = c;   R[1] = 0.f; R[2] = s;
   R[3] = 0.f; R[4] = 1.f; R[5] = 0.f;
   R[6] = -s;  R[7] = 0.f; R[8] = c;
@@ -201,11 +173,7 @@ struct Bounds {   // projection clamp; only used when the kernel is instantiated
 // the equality tests of clip_jac still see the bound.  min + max are two half-rate instructions per coordinate: 8 of them per
 // two point-poses were a fifth of the AMIS sweeps' VALU time under a projection clamp (profiles/r03_tune_clamp_med3.txt).
 PNP_FN float clamp_lu(float x, float lo, float hi) {
-#ifndef EPROPNP_EMU
   return __builtin_amdgcn_fmed3f(x, lo, hi);
-#else
-  return fminf(fmaxf(x, lo), hi);
-#endif
 }
 
 // Huber cost of one point under pose (KR, Kt): cost-only path (project_b).  FAST selects the 1-ulp
@@ -241,9 +209,7 @@ PNP_FN float point_cost(const Point& p, const float (&KR)[9], const float (&Kt)[
 
 // Force a (possibly wave-uniform, SGPR-resident) value into a vector register.
 PNP_FN float to_vgpr(float x) {
-#ifndef EPROPNP_EMU
   asm volatile("" : "+v"(x));
-#endif
   return x;
 }
 
@@ -444,18 +410,10 @@ PNP_FN void scaled_inverse(const ScaledFactor<D>& f, float (&Hinv)[D][D]) {
 // natural log / exp on the hardware base-2 units (v_log_f32 / v_exp_f32, ~1 ulp): the densities need ~1e-6 ABSOLUTE
 // accuracy of a log-probability, which these give at a fifth of the instructions of the libm expansions
 PNP_FN float fast_log(float x) {
-#ifndef EPROPNP_EMU
   return 0.6931471805599453f * __builtin_amdgcn_logf(x);
-#else
-  return logf(x);
-#endif
 }
 PNP_FN float fast_exp(float x) {
-#ifndef EPROPNP_EMU
   return __builtin_amdgcn_exp2f(1.4426950408889634f * x);
-#else
-  return expf(x);
-#endif
 }
 constexpr float kLogPi = 1.1447298858494002f;
 constexpr float kLog2Pi = 1.8378770664093453f;
@@ -556,28 +514,17 @@ PNP_FN float race_inv_weight(float w) { return (w > 0.f) ? 1.0f / w : 0.f; }
 PNP_FN unsigned race_key(uint32_t rnd, float inv_w, int n) {
   if (!(inv_w > 0.f) || inv_w == INFINITY) return kRaceInf | (unsigned)n;
   // -ln(u) / w up to the constant factor ln 2 (irrelevant to the order): hardware log2, one multiply
-#ifndef EPROPNP_EMU
   const float k = fabsf(__builtin_amdgcn_logf(u01(rnd))) * inv_w;
-#else
-  const float k = fabsf(log2f(u01(rnd))) * inv_w;
-#endif
   unsigned bits;
   memcpy(&bits, &k, sizeof(bits));       // bit cast (compiles to a move)
   return ((bits < kRaceInf ? bits : kRaceInf - 1u) & ~kRaceIdxMask) | (unsigned)n;      // (an overflowing key stays below "never")
 }
 
 PNP_FN void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-#ifndef EPROPNP_EMU
   const float r = fast_sqrt(-1.3862943611198906f * __builtin_amdgcn_logf(u01(a)));   // -2 ln u = -2 ln2 log2 u
   const float rev = u01(b);
   n0 = r * __builtin_amdgcn_cosf(rev);
   n1 = r * __builtin_amdgcn_sinf(rev);
-#else
-  const float r = sqrtf(-2.0f * logf(u01(a)));
-  const float th = 6.283185307179586f * u01(b);
-  n0 = r * cosf(th);
-  n1 = r * sinf(th);
-#endif
 }
 
 }  // namespace pnp

@@ -27,13 +27,8 @@ struct Problem {
 // scope: the word may live in host memory (the library's default status word, pnp_host.h:default_status_word).
 __device__ __forceinline__ void raise_status(const Problem& p, int flags, int b) {
   if (p.status != nullptr && flags != 0) {
-#ifndef EPROPNP_EMU
     __hip_atomic_fetch_or(p.status, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_fetch_min(p.status + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-    atomicOr(p.status, flags);
-    atomicMin(p.status + 1, b);
-#endif
   }
 }
 
@@ -48,9 +43,7 @@ __device__ __forceinline__ int object_of_block(int B) {
 }
 __host__ __device__ __forceinline__ int padded_object_grid(int B) { return ((B + 7) >> 3) << 3; }
 
-#ifndef EPROPNP_EMU
-typedef float pnp_f32x2 __attribute__((ext_vector_type(2)));
-#endif
+typedef float pnp_f32x2 __attribute__((vector_size(8)));
 
 // NT: non-temporal loads for kernels that stream an object's correspondences exactly once (the Jacobian sweep, the LM
 // solve): the lines are not kept in L2 / the Infinity Cache on their way through (MI355X_MICROARCH.md "nt-weights").
@@ -60,7 +53,6 @@ __device__ __forceinline__ Point load_point(const Problem& p, int b, int n) {
   if (n < p.N) {
     const size_t i = (size_t)b * (size_t)p.N + (size_t)n;
     const float* a = p.x3d + i * 3;
-#ifndef EPROPNP_EMU
     if (NT) {
       q.X = __builtin_nontemporal_load(a); q.Y = __builtin_nontemporal_load(a + 1); q.Z = __builtin_nontemporal_load(a + 2);
       const pnp_f32x2 u = __builtin_nontemporal_load(reinterpret_cast<const pnp_f32x2*>(p.x2d + i * 2));
@@ -68,7 +60,6 @@ __device__ __forceinline__ Point load_point(const Problem& p, int b, int n) {
       q.u = u[0]; q.v = u[1]; q.wu = w[0]; q.wv = w[1];
       return q;
     }
-#endif
     q.X = a[0]; q.Y = a[1]; q.Z = a[2];
     const float2 u = *reinterpret_cast<const float2*>(p.x2d + i * 2);
     const float2 w = *reinterpret_cast<const float2*>(p.w2d + i * 2);
@@ -89,15 +80,10 @@ __device__ __forceinline__ Point load_point_streamed(const Problem& p, int b, in
   const int nc = min(n, p.N - 1);
   const size_t i = (size_t)b * (size_t)p.N + (size_t)nc;
   const float* a = p.x3d + i * 3;
-#ifndef EPROPNP_EMU
   q.X = __builtin_nontemporal_load(a); q.Y = __builtin_nontemporal_load(a + 1); q.Z = __builtin_nontemporal_load(a + 2);
   const pnp_f32x2 u = __builtin_nontemporal_load(reinterpret_cast<const pnp_f32x2*>(p.x2d + i * 2));
   const pnp_f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const pnp_f32x2*>(p.w2d + i * 2));
   q.u = u[0]; q.v = u[1]; q.wu = w[0]; q.wv = w[1];
-#else
-  q.X = a[0]; q.Y = a[1]; q.Z = a[2];
-  q.u = p.x2d[i * 2]; q.v = p.x2d[i * 2 + 1]; q.wu = p.w2d[i * 2]; q.wv = p.w2d[i * 2 + 1];
-#endif
   return q;
 }
 // ... and the masking of a lane beyond N, applied where the point is consumed (not at the load: that would wait for it)

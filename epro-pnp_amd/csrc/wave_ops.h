@@ -2,11 +2,11 @@
 //
 // On the device these are DPP row rotations (v_add_f32 ... row_ror) plus v_readlane, i.e. they never touch
 // LDS memory.  The reduction order is fixed, so results are run-to-run deterministic.
-// (tests/emu/hip_emu.h supplies a CPU stand-in for the same five primitives; it is test infrastructure.)
+// Everything here is written against the compiler's AMDGPU builtins, once.
 #pragma once
 
-#ifndef EPROPNP_EMU
 #include <hip/hip_runtime.h>
+#ifndef PNP_LAUNCH      // how a kernel is launched and how it names its dynamic LDS: a build may bring its own pair
 #define PNP_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
 #define PNP_DYN_SMEM(type, name)                                                  \
@@ -23,21 +23,9 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 // register-resident points it keeps point k's arithmetic ahead of point k+1's, so that the s_waitcnt in front of it waits for
 // point k's loads only and the arithmetic runs underneath the loads still in flight (otherwise the scheduler interleaves the
 // independent per-point chains and every wave waits for ALL of its loads before its first FMA).
-__device__ __forceinline__ void sched_fence() {
-#ifndef EPROPNP_EMU
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // wave index as a wave-uniform (scalar-register) value: lets the compiler keep everything derived from it in SGPRs
-__device__ __forceinline__ int wave_id() {
-#ifndef EPROPNP_EMU
-  return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#else
-  return (int)(threadIdx.x >> 6);
-#endif
-}
-
-#ifndef EPROPNP_EMU
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
@@ -67,39 +55,13 @@ __device__ __forceinline__ float wave_max(float x) {
   return fmaxf(fmaxf(wave_bcast(x, 0), wave_bcast(x, 16)), fmaxf(wave_bcast(x, 32), wave_bcast(x, 48)));
 }
 
-#else  // CPU stand-in (tests only)
-
-__device__ __forceinline__ float wave_bcast(float x, int src) { return emu::shfl(x, src); }
-__device__ __forceinline__ int wave_bcast(int x, int src) { return emu::shfl(x, src); }
-__device__ __forceinline__ float wave_sum(float x) {
-  for (int m : {8, 4, 2, 1}) {
-    int l = lane_id();
-    x += emu::shfl(x, (l & ~15) | ((l + m) & 15));
-  }
-  return (wave_bcast(x, 0) + wave_bcast(x, 16)) + (wave_bcast(x, 32) + wave_bcast(x, 48));
-}
-__device__ __forceinline__ float wave_max(float x) {
-  for (int m : {32, 16, 8, 4, 2, 1}) x = fmaxf(x, emu::shfl(x, lane_id() ^ m));
-  return x;
-}
-
-#endif
-
 // sum over the 16 lanes of a DPP row (every lane of the row receives it)
 __device__ __forceinline__ float row_sum16(float x) {
-#ifndef EPROPNP_EMU
   x += dpp_mov<0x128>(x);
   x += dpp_mov<0x124>(x);
   x += dpp_mov<0x122>(x);
   x += dpp_mov<0x121>(x);
   return x;
-#else
-  for (int m : {8, 4, 2, 1}) {
-    const int l = lane_id();
-    x += emu::shfl(x, (l & ~15) | ((l + m) & 15));
-  }
-  return x;
-#endif
 }
 
 // Row sums of FOUR values at once: lane l of a 16-lane row receives the row total of a[l & 3].  The first two butterfly steps
@@ -110,7 +72,6 @@ __device__ __forceinline__ float row_sum16_of4(const float (&a)[4]) {
   const bool o1 = (l & 1) != 0, o2 = (l & 2) != 0;
   float k01 = o1 ? a[1] : a[0], s01 = o1 ? a[0] : a[1];
   float k23 = o1 ? a[3] : a[2], s23 = o1 ? a[2] : a[3];
-#ifndef EPROPNP_EMU
   k01 += dpp_mov<0xB1>(s01);      // quad_perm:[1,0,3,2]
   k23 += dpp_mov<0xB1>(s23);
   float k = o2 ? k23 : k01;
@@ -118,64 +79,32 @@ __device__ __forceinline__ float row_sum16_of4(const float (&a)[4]) {
   k += dpp_mov<0x4E>(s);          // quad_perm:[2,3,0,1]
   k += dpp_mov<0x128>(k);         // row_ror:8
   k += dpp_mov<0x124>(k);         // row_ror:4
-#else
-  k01 += emu::shfl(s01, l ^ 1);
-  k23 += emu::shfl(s23, l ^ 1);
-  float k = o2 ? k23 : k01;
-  const float s = o2 ? k01 : k23;
-  k += emu::shfl(s, l ^ 2);
-  k += emu::shfl(k, (l & ~15) | ((l + 8) & 15));
-  k += emu::shfl(k, (l & ~15) | ((l + 4) & 15));
-#endif
   return k;
 }
 
 // sum over the 4 lanes of a quad (lanes 4q .. 4q+3; every lane of the quad receives (x0 + x1) + (x2 + x3))
 __device__ __forceinline__ float quad_sum(float x) {
-#ifndef EPROPNP_EMU
   x += dpp_mov<0xB1>(x);      // quad_perm:[1,0,3,2]
   x += dpp_mov<0x4E>(x);      // quad_perm:[2,3,0,1]
   return x;
-#else
-  x += emu::shfl(x, lane_id() ^ 1);
-  x += emu::shfl(x, lane_id() ^ 2);
-  return x;
-#endif
 }
 
 // max over the 16 lanes of a DPP row (every lane of the row receives it)
 __device__ __forceinline__ float row_max16(float x) {
-#ifndef EPROPNP_EMU
   x = fmaxf(x, dpp_mov<0x128>(x));
   x = fmaxf(x, dpp_mov<0x124>(x));
   x = fmaxf(x, dpp_mov<0x122>(x));
   x = fmaxf(x, dpp_mov<0x121>(x));
   return x;
-#else
-  for (int m : {8, 4, 2, 1}) {
-    const int l = lane_id();
-    x = fmaxf(x, emu::shfl(x, (l & ~15) | ((l + m) & 15)));
-  }
-  return x;
-#endif
 }
 
 // min over the 16 lanes of a DPP row / over the wave, unsigned (packed sort keys)
 __device__ __forceinline__ unsigned row_min16_u32(unsigned x) {
-#ifndef EPROPNP_EMU
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false));
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false));
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false));
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false));
   return x;
-#else
-  for (int m : {8, 4, 2, 1}) {
-    const int l = lane_id();
-    const unsigned o = (unsigned)emu::shfl((int)x, (l & ~15) | ((l + m) & 15));
-    x = o < x ? o : x;
-  }
-  return x;
-#endif
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
   x = row_min16_u32(x);
@@ -188,9 +117,8 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
 // ---- matrix core and packed-pair primitives (the AMIS sweeps) ------------------------------------------------------
 // v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) B(4x16) + C, exact f32 (a k-ordered fmaf chain).  Lane l holds A[l&15][l>>4],
 // B[l>>4][l&15] and D[4*(l>>4)+r][l&15], r = 0..3.
-#ifndef EPROPNP_EMU
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((vector_size(16)));
+typedef float f32x2 __attribute__((vector_size(8)));
 __device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -198,15 +126,6 @@ __device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) {
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // exact-zero test of a wave-uniform float without a vector compare
 __device__ __forceinline__ bool uniform_is_zero(float a) { return __builtin_amdgcn_readfirstlane(__float_as_int(a)) == 0; }
-#else
-typedef floatx4_emu floatx4;
-typedef float f32x2 __attribute__((vector_size(8)));
-__device__ __forceinline__ floatx4 mfma_16x16x4(float a, float b, floatx4 c) { return emu::mfma_16x16x4(a, b, c); }
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
-  return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
-}
-__device__ __forceinline__ bool uniform_is_zero(float a) { return a == 0.f; }
-#endif
 
 // ---- bf16x3-split projection: v_mfma_f32_16x16x32_bf16 --------------------------------------------------------------------
 // An fp32 product sum over k = 0..3 as ONE 32-deep bf16 MFMA: each fp32 operand is the sum of three bf16 pieces (split by
@@ -220,19 +139,13 @@ __device__ __forceinline__ bool uniform_is_zero(float a) { return a == 0.f; }
 // measured).  Do NOT route an operand or a result through an inline asm: an asm that takes a result in-out hides the MFMA ->
 // VALU dependence from the recogniser (the asm "redefines" the register), which is what made the round-3 attempts at this
 // projection wrong and run-to-run different (profiles/r04_bwd_bf16_projection.txt).
-#ifndef EPROPNP_EMU
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((vector_size(16)));
 __device__ __forceinline__ floatx4 mfma_16x16x32_bf16(u32x4 a, u32x4 b, floatx4 c) {
-  typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8_ __attribute__((vector_size(16)));
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
 }
 // {hi16(lo_src), hi16(hi_src)} as one v_perm_b32
 __device__ __forceinline__ unsigned bf16_pack_hi(unsigned lo_src, unsigned hi_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }
-#else
-typedef emu::u32x4_emu u32x4;
-__device__ __forceinline__ floatx4 mfma_16x16x32_bf16(u32x4 a, u32x4 b, floatx4 c) { return emu::mfma_16x16x32_bf16(a, b, c); }
-__device__ __forceinline__ unsigned bf16_pack_hi(unsigned lo_src, unsigned hi_src) { return (lo_src >> 16) | (hi_src & 0xffff0000u); }
-#endif
 __device__ __forceinline__ void bf16_split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {      // pieces in the HIGH halves
   unsigned u;
   __builtin_memcpy(&u, &x, 4);
@@ -291,15 +204,10 @@ __device__ __forceinline__ float bits_f32(unsigned u) { float x; __builtin_memcp
 __device__ __forceinline__ unsigned xwg_payload(float x) { return (x != x) ? 0x7fc00000u : f32_bits(x); }
 
 __device__ __forceinline__ void xwg_store(unsigned* p, unsigned v) {
-#ifndef EPROPNP_EMU
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  *p = v;
-#endif
 }
 
 __device__ __forceinline__ unsigned xwg_poll(const unsigned* p, unsigned timeout_cycles) {
-#ifndef EPROPNP_EMU
   unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (v != kXwgEmpty || timeout_cycles == 0) return v;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -308,21 +216,13 @@ __device__ __forceinline__ unsigned xwg_poll(const unsigned* p, unsigned timeout
     v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } while (v == kXwgEmpty && (unsigned long long)__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)timeout_cycles);
   return v;
-#else
-  (void)timeout_cycles;
-  return *p;
-#endif
 }
 
 // Orders this wave's earlier LDS writes before its later LDS reads of OTHER lanes' data.  The hardware executes a
 // wave's DS instructions in order, so no s_barrier is needed; this only stops the compiler from reordering.
 __device__ __forceinline__ void wave_lds_fence() {
-#ifndef EPROPNP_EMU
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-#else
-  emu::wave_sync();
-#endif
 }
 
 // Sum NV per-thread values over the whole workgroup; every thread receives the totals.

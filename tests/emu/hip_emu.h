@@ -235,6 +235,7 @@ inline float4 make_float4(float x, float y, float z, float w) { return float4{x,
 // v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) B(4x16) + C.  Lane l holds A[l&15][l>>4], B[l>>4][l&15] and
 // D[4*(l>>4)+r][l&15], r = 0..3.  k-ordered fmaf chain, like the hardware.
 typedef float floatx4_emu __attribute__((vector_size(16)));
+typedef unsigned u32x4_emu __attribute__((vector_size(16)));
 namespace emu {
 inline floatx4_emu mfma_16x16x4(float a, float b, floatx4_emu c) {
   Block& blk_ = blk();
@@ -269,7 +270,6 @@ inline floatx4_emu mfma_16x16x4(float a, float b, floatx4_emu c) {
 // v_mfma_f32_16x16x32_bf16: D(16x16) = A(16x32) B(32x16) + C.  Lane l holds the 8 bf16 A[l&15][8*(l>>4) .. +7] and
 // B[8*(l>>4) .. +7][l&15] as 4 dwords each (element 2i = low half of dword i); D layout as mfma_16x16x4.  Products of bf16
 // pairs are exact in fp32; the 32-term sum is accumulated in double and rounded once (the hardware's order is not specified).
-typedef unsigned u32x4_emu __attribute__((vector_size(16)));
 inline floatx4_emu mfma_16x16x32_bf16(u32x4_emu a, u32x4_emu b, floatx4_emu c) {
   Block& blk_ = blk();
   unsigned t = blk_.fibers[blk_.cur].tid.x;
@@ -302,3 +302,80 @@ inline floatx4_emu mfma_16x16x32_bf16(u32x4_emu a, u32x4_emu b, floatx4_emu c) {
   return d;
 }
 }  // namespace emu
+
+// ---- the gfx950 compiler builtins the kernel headers use, under their own names ------------------------------------------
+// The product headers (wave_ops.h, pnp_math.h, amis_common.h, pnp_sweep.h) are written against the AMDGPU builtins only and hold
+// no test branches; this section gives g++ a host function of the same name and meaning for each of them.  Cross-lane builtins
+// are cooperative exchanges between the fibers of a wave; the 1-ulp hardware approximations become the libm functions.
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+template <class T> inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T> inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
+template <class T> inline T __hip_atomic_fetch_or(T* p, T v, int, int) { const T o = *p; *p = o | v; return o; }
+template <class T> inline T __hip_atomic_fetch_min(T* p, T v, int, int) { const T o = *p; *p = v < o ? v : o; return o; }
+template <class T> inline T __builtin_nontemporal_load(const T* p) { return *p; }
+
+inline int __float_as_int(float x) { int i; std::memcpy(&i, &x, 4); return i; }
+inline float __int_as_float(int i) { float x; std::memcpy(&x, &i, 4); return x; }
+
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
+inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+inline float __builtin_amdgcn_logf(float x) { return log2f(x); }                  // v_log_f32 is base 2
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+inline float __builtin_amdgcn_sinf(float rev) { return (float)sin(6.283185307179586 * (double)rev); }      // argument in revolutions
+inline float __builtin_amdgcn_cosf(float rev) { return (float)cos(6.283185307179586 * (double)rev); }
+// v_med3_f32: the median; with a NaN among the operands the minimum of the others (fminf ignores a NaN)
+inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {
+  if (a != a || b != b || c != c) return fminf(fminf(a, b), c);
+  return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+}
+template <class V> inline V __builtin_elementwise_fma(V a, V b, V c) {
+  V r;
+  for (unsigned i = 0; i < sizeof(V) / sizeof(float); ++i) r[i] = fmaf(a[i], b[i], c[i]);
+  return r;
+}
+// v_perm_b32: byte k of the result is byte sel[k] of the 8 bytes {src0 (bytes 7..4), src1 (bytes 3..0)}; 0x0c selects 0x00
+inline unsigned __builtin_amdgcn_perm(unsigned src0, unsigned src1, unsigned sel) {
+  const uint64_t both = ((uint64_t)src0 << 32) | src1;
+  unsigned r = 0;
+  for (int k = 0; k < 4; ++k) {
+    const unsigned s = (sel >> (8 * k)) & 0xffu;
+    const unsigned byte = s < 8 ? (unsigned)(both >> (8 * s)) & 0xffu : (s == 0x0c ? 0u : 0xffu);
+    r |= byte << (8 * k);
+  }
+  return r;
+}
+
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __builtin_amdgcn_fence(int, const char*) {}
+inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }      // the fibers of a wave do not run in lock step: meet here
+// Workgroups run one after another, so a word another workgroup has not written yet never arrives: the clock jumps, a poll ends.
+inline unsigned long long __builtin_amdgcn_s_memtime() {
+  static unsigned long long t = 0;
+  return t += 1ull << 40;
+}
+// wave-uniform by contract of its callers
+inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+inline int __builtin_amdgcn_readlane(int x, int src) { return emu::shfl(x, src); }
+// Callers sit in divergent code and only test `ballot(p) == 0` to leave a retry loop early; a fiber cannot wait for lanes that
+// took another branch, so it sees its own bit only (it leaves when IT is done, which changes no result).
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) {
+  return p ? 1ull << (emu::blk().fibers[emu::blk().cur].tid.x & 63u) : 0ull;
+}
+// DPP controls in use: quad_perm (0x00..0xff) and row_ror:n (0x121..0x12f); all rows / banks enabled
+inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+  const int l = (int)(emu::blk().fibers[emu::blk().cur].tid.x & 63u);
+  int from;
+  if (ctrl >= 0 && ctrl <= 0xff) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+  else if (ctrl >= 0x121 && ctrl <= 0x12f) from = (l & ~15) | ((l - (ctrl & 15)) & 15);
+  else { std::fprintf(stderr, "emu: DPP control 0x%x is not emulated\n", ctrl); std::abort(); }
+  return emu::shfl(src, from);
+}
+inline floatx4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, floatx4_emu c, int, int, int) { return emu::mfma_16x16x4(a, b, c); }
+typedef unsigned short __bf16;           // storage only (g++ 11 has no such type); the emulation reads the bits
+typedef __bf16 bf16x8_emu __attribute__((vector_size(16)));
+inline floatx4_emu __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf16x8_emu a, bf16x8_emu b, floatx4_emu c, int, int, int) {
+  return emu::mfma_16x16x32_bf16(__builtin_bit_cast(u32x4_emu, a), __builtin_bit_cast(u32x4_emu, b), c);
+}
