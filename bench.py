@@ -514,13 +514,28 @@ def main(argv=None, device=None, backend='nccl'):
         # (sharding.ObjectExchange.start); this eager form is what `replayed_step_check` compares the replayed value with.
         return (scale_det * obj_weight[:, None]).sum() * nf_scale
 
+    # BENCH_HOST_SEGMENTS=1: host time of an eagerly launched step by segment (time.perf_counter between the statements below,
+    # no synchronisation), printed to stderr after the timed region -- tools/gpu_host_profile.sh
+    seg = {} if os.environ.get('BENCH_HOST_SEGMENTS') == '1' else None
+    seg_t = [0.0]
+
+    def mark(name):
+        if seg is not None:
+            now = time.perf_counter()
+            seg[name] = seg.get(name, 0.0) + (now - seg_t[0])
+            seg_t[0] = now
+
     def step(timed=False):
+        mark('between_steps')
         for t in (x3d, x2d, w2d):
             t.grad = None
+        mark('grads_to_none')
         cost_fun.set_param(x2d.detach(), w2d)
+        mark('set_param')
         pose_opt, _, plus, _, logw, cost_init = layer.monte_carlo_forward(
             x3d, x2d, w2d, camera, cost_fun, pose_init=pose_target, force_init_solve=force_init,
             **({'with_pose_opt_plus': True} if with_plus else {}))
+        mark('monte_carlo_forward')
         if loss_mod is None or caller:
             if loss_mod is None:
                 loss = monte_carlo_pose_loss(logw, cost_init).mean()   # Monte-Carlo pose (KL) loss, NaN -> 0
@@ -531,7 +546,9 @@ def main(argv=None, device=None, backend='nccl'):
                 loss_t = torch.where(dist_t < 0.05, 0.5 * dist_t.square() / 0.05, dist_t - 0.025).mean()
                 dot = (plus[:, 3:] * pose_target[:, 3:]).sum(-1)
                 loss = loss + 0.1 * loss_t + 0.1 * ((1 - dot.square()) * 2).mean()
+            mark('loss')
             loss.backward()
+            mark('backward')
             return loss
         # Det step.  pose_opt is final here: its all-gather (with the rank's norm_factor input in the same payload) is issued
         # now, in stream order (sharding.ObjectExchange: why not a side stream); the loss takes the world mean out of the
@@ -542,14 +559,18 @@ def main(argv=None, device=None, backend='nccl'):
             e0.record()
         # (the head's norm_factor input, deform_pnp_head.py:870, is summed inside the exchange's pack launch: sharding.ObjectExchange.start)
         exchange.start(pose_opt, sum_of=scale_det, sum_row_weight=obj_weight, sum_scale=nf_scale)
+        mark('exchange_start')
         layer_last_pose['pose_opt'] = pose_opt.detach()
         if timed:
             e1.record()                 # GPU time of the pack kernel + the RCCL kernel in stream order
             coll_events.append((e0, e1))
         # detection loss: per-object weights, avg_factor = the whole batch, world-mean EMA of norm_factor
         loss = loss_mod(logw, cost_init, exchange, weight=obj_weight, avg_factor=float(total))
+        mark('loss')
         loss.backward()
+        mark('backward')
         gathered['pose_opt'] = exchange.objects()
+        mark('exchange_objects')
         return loss
 
     def fence():
@@ -706,6 +727,23 @@ def main(argv=None, device=None, backend='nccl'):
         if dist is not None:
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
         eager_ms = float(te) / args.steps * 1e3
+
+    if seg is not None and on_gpu:
+        n_seg = 500
+        for _ in range(20):
+            step()
+        fence()
+        seg.clear()
+        seg_t[0] = t0 = time.perf_counter()
+        for _ in range(n_seg):
+            step()
+        t_host = time.perf_counter() - t0
+        fence()
+        t_all = time.perf_counter() - t0
+        print(json.dumps({'host_segments_us_per_step': {k: round(v / n_seg * 1e6, 2) for k, v in seg.items()},
+                          'host_us_per_step': round(t_host / n_seg * 1e6, 2), 'with_drain_us_per_step': round(t_all / n_seg * 1e6, 2),
+                          'steps': n_seg, 'config': args.config}), file=sys.stderr)
+        seg = None
 
     ms_without = None
     if strong:          # the collective's cost on the critical path, measured: the same steps without the exchange

@@ -23,7 +23,10 @@ def tune(key):
     """EPROPNP_TUNE="key=value;key2;...": the ONE string behind which launch-shape overrides, implementation selectors and
     phase ablation live (csrc/pnp_host.h: tune_value; tools/tune.py and the shape tests set it, users do not).  Returns the text
     behind `key=` ('' for a bare key) or None.  Read on every call: tests change the variable at run time."""
-    for item in os.environ.get('EPROPNP_TUNE', '').split(';'):
+    text = os.environ.get('EPROPNP_TUNE')
+    if not text:
+        return None
+    for item in text.split(';'):
         k, _, v = item.partition('=')
         if k == key:
             return v
@@ -223,6 +226,18 @@ _status_words = {}
 STATUS_MODE = os.environ.get('EPROPNP_ASYNC_STATUS', 'warn')     # 'warn' (default) | 'raise' | '0' (no status word at all)
 
 
+_has_gpu = None
+
+
+def _gpu_present():
+    """torch.cuda.is_available(), asked once: it is a driver query (hipGetDeviceCount, ~50 us on an MI355X box) and every entry
+    into the package passes through poll_status()."""
+    global _has_gpu
+    if _has_gpu is None:
+        _has_gpu = bool(torch.cuda.is_available())
+    return _has_gpu
+
+
 def poll_status():
     """The asynchronous half of the error convention.  Kernels report a damped normal-equation system without a Cholesky
     factor / a non-finite pose into the library's host-mapped status word of the current device; reading it is a plain
@@ -234,7 +249,7 @@ def poll_status():
     default is a RuntimeWarning naming the object; EPROPNP_ASYNC_STATUS=raise (or `_hip.STATUS_MODE = 'raise'`) turns it
     into the RuntimeError, `with numerics_check():` does so for a block, synchronously.  Events the reference takes in its
     stride (Cholesky fallback of a proposal, non-finite log-weight) are dropped here."""
-    dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    dev = torch.cuda.current_device() if _gpu_present() else 0
     w = _status_words.get((id(_lib), dev))
     if w is None:
         w = lib().epropnp_async_status_word()

@@ -14,9 +14,11 @@ import os
 
 import torch
 
+from . import _hip
 from . import functional as hip
 from ._dtype import fp32_boundary
 from . import proposals
+from .levenberg_marquardt import LMSolver, RSLMSolver
 from .common import pnp_denormalize, pnp_normalize
 
 
@@ -220,9 +222,6 @@ class EProPnPBase(torch.nn.Module):
         """The fused entry serves the reference's own solver stack: LMSolver with no or an RSLMSolver initialiser whose
         sub-problems fit the one-launch kernel.  Anything else (a custom solver object, > 16 points per proposal, > 512
         points with RSLM) takes the composite path below, made of the same kernels."""
-        import os
-        from . import _hip
-        from .levenberg_marquardt import LMSolver, RSLMSolver
         sv = self.solver
         if type(sv) is not LMSolver or sv.dof != self.dof or x3d.size(0) == 0 or hip.tune('no_fused_forward') is not None:
             return False
@@ -240,8 +239,6 @@ class EProPnPBase(torch.nn.Module):
 
     def _fused_forward(self, x3d, x2d, w2d, camera, cost_fun, pose_init, force_init_solve, noise, with_pose_opt_plus=False,
                        with_cost=False, fast_mode=False):
-        from . import _hip
-        from .levenberg_marquardt import RSLMSolver
         sv = self.solver
         prob = hip.PnPProblem(x3d, x2d, w2d, camera, cost_fun, self.dof)
         cfg = self._amis_config(noise)

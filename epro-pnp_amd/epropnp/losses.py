@@ -6,8 +6,12 @@ Covers both reference variants with one class:
     loss_weight, and the world-mean of `norm_factor` (mmdet `reduce_mean`) when torch.distributed is initialised.
 The loss is what seeds the backward of the HIP AMIS kernel: d loss / d logweights = softmax over samples.
 """
+import os
+
 import torch
 import torch.nn as nn
+
+from . import _hip
 
 
 def monte_carlo_pose_loss(pose_sample_logweights, cost_target):
@@ -80,8 +84,6 @@ class MonteCarloPoseLoss(nn.Module):
         """loss_weight / (what the sum over objects is divided by) when the fused kernels can produce the reduced loss, else
         None: fp32 (S,B) log-weights on the HIP path, a scalar reduction, a plain (B,) weight that needs no gradient, a plain
         number as avg_factor."""
-        import os
-        from . import _hip
         if os.environ.get('EPROPNP_LOSS_FUSED', '1') == '0':        # measurements: the composite statement
             return None
         if reduction not in ('mean', 'sum') or logw.dim() != 2 or logw.numel() == 0:
