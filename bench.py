@@ -745,6 +745,17 @@ def main(argv=None, device=None, backend='nccl'):
                           'steps': n_seg, 'config': args.config}), file=sys.stderr)
         seg = None
 
+    if os.environ.get('BENCH_TORCH_PROFILE') == '1' and on_gpu:      # CPU-side op times of the eager step (torch.profiler), to stderr
+        from torch.profiler import ProfilerActivity, profile
+        for _ in range(20):
+            step()
+        fence()
+        with profile(activities=[ProfilerActivity.CPU]) as tp:
+            for _ in range(200):
+                step()
+            fence()
+        print(tp.key_averages().table(sort_by='self_cpu_time_total', row_limit=45, max_name_column_width=70), file=sys.stderr)
+
     ms_without = None
     if strong:          # the collective's cost on the critical path, measured: the same steps without the exchange
         exchange.disabled = True
