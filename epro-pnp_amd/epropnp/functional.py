@@ -17,6 +17,8 @@ def _f32c(t, name):
     if t.dtype != torch.float32:
         raise TypeError(f'{name}: the HIP path computes in fp32, got {t.dtype}')
     _hip.check_device(t, name)
+    if not t.requires_grad and t.is_contiguous():      # nothing to cut off, nothing to copy: the tensor itself (two dispatcher calls less)
+        return t
     return t.detach().contiguous()
 
 
