@@ -101,3 +101,16 @@ def test_library_listings_hold_no_unsafe_packed_shape():
     text = open(os.path.join(ROOT, 'epro-pnp_amd', 'lib', 'amis_backward_mfma.dev.fixed.s')).read()
     packed = re.findall(r'^\s*v_pk_(?:mul|add|fma)_f32\b[^\n;]*', text, flags=re.M)
     assert packed and not any(re.search(r'\bop_sel:', p) for p in packed), [p for p in packed if re.search(r'\bop_sel:', p)][:3]
+
+
+def test_product_sources_hold_no_test_branches():
+    """The kernel sources and headers are written once, against the AMDGPU builtins: the CPU emulation of the tests supplies those
+    builtins under their own names from outside (tests/emu/hip_emu.h), so nothing under csrc/ or include/ may test for it."""
+    offenders = []
+    for d in (CSRC, os.path.join(ROOT, 'include')):
+        for name in sorted(os.listdir(d)):
+            if name.endswith(('.h', '.hip', '.cpp')):
+                text = open(os.path.join(d, name)).read()
+                if 'EPROPNP_EMU' in text or 'emu::' in text or 'hip_emu' in text:
+                    offenders.append(name)
+    assert not offenders, offenders
