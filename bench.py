@@ -40,6 +40,10 @@ IC-cold (launches rotate over distinct copies of the inputs, > 2 x the 256 MiB I
 `roofline_valu` reports the VALU-bound AMIS kernels against the fp32 vector peak.  `cpu_baseline` is the oracle (a
 PyTorch-CPU restatement with the reference's op structure, pinned to the reference and timed beside it in
 profiles/r02_cpu_reference_vs_oracle.txt) on a bounded sample of the same workload on the host cores.
+
+Diagnostics behind environment variables, after the timed region, to stderr (never part of the line): BENCH_HOST_SEGMENTS=1 --
+host time of an eagerly launched step by statement; BENCH_TORCH_PROFILE=1 -- torch.profiler's CPU-side op table of the same step
+(tools/gpu_host_segments.sh, profiles/r06_eager_host_time.txt).
 """
 import argparse
 import json
