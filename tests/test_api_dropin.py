@@ -522,3 +522,20 @@ def test_one_problem_per_monte_carlo_forward(backend, monkeypatch, dof, rslm, pl
     built.clear()
     layer.solver.solve(d['x3d'], d['x2d'], d['w2d'], cam, cf, pose_init=d['pose_init'])       # stand-alone: its own
     assert len(built) == 1
+
+
+def test_the_device_query_is_asked_once(backend, monkeypatch):
+    """`torch.cuda.is_available()` is a driver query (46 us per call on an MI355X box, profiles/r06_eager_host_time.txt): the status
+    poll that every entry into the package performs asks it once per process, not once per call."""
+    from epropnp import _hip
+    from epropnp import functional as F
+    asked = []
+    real = torch.cuda.is_available
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: (asked.append(1), real())[1])
+    monkeypatch.setattr(_hip, '_has_gpu', None)
+    p = orc.make_problem(3, 24, 6, seed=5)
+    d, cam, cf = make_layer_objects(p, backend)
+    for _ in range(4):
+        F.PnPProblem(d['x3d'], d['x2d'], d['w2d'], cam, cf, 6)
+        _hip.poll_status()
+    assert len(asked) == 1
