@@ -13,7 +13,10 @@
 //     the same MFMA with the roles swapped (A = the per-pair g_h values, which the forward MFMA leaves in exactly the
 //     lane layout an A operand needs; B = pose rows indexed by output coordinate), and that variant was built and
 //     measured: 12 more MFMAs per 16x16 tile for 3 useful output columns of 16, each waiting on VALU results and on
-//     the previous accumulate -- 1.6-1.9 ms instead of 1.08 ms at C2 (profiles/r01_bwd_mfma_sweep.txt).  Dropped.
+//     the previous accumulate -- 1.6-1.9 ms instead of 1.08 ms at C2 (profiles/r01_bwd_mfma_sweep.txt).  Dropped.  Round 6 built it
+//     again on v_mfma_f32_4x4x1_16b_f32 (2 passes; a block of four lanes = four points, no wasted columns to speak of): 31 % fewer
+//     packed instructions, 32 VGPRs less, 924-948 us against 780-793 -- vector arithmetic does not run underneath an MFMA on this
+//     part, of its own wave or of a neighbour (profiles/r06_mfma_valu_overlap.txt, tools/ubench/mfma_4x4x1_layout.hip).  Dropped.
 //   * the VALU keeps what is genuinely per pair: perspective divide, weighted residual, Huber weight, and the
 //     accumulation of the gradients -- since round 6 on explicit 2-vectors: two point-poses per v_pk_*_f32 (22.6 wave-level
 //     instructions per pair with four resident tiles, 2 of them transcendental; the loop is bound by how often a wave gets to issue, profiles/r06_bwd_packed.txt).
